@@ -1,0 +1,139 @@
+/*
+ * qcx.h -- C ABI of libqcx.so: the MI355X (gfx950) state-vector gate engine that
+ * replaces the gate-application path of adamalderton/QuantumComputer's
+ * qc_shor.c (cited as Q:line).  Plain C, plain pointers and sizes; no GSL, no
+ * torch types.  The library is HIP only: every entry point that computes
+ * returns QCX_HIP_ERROR when no gfx950 device is usable -- there is no CPU
+ * fallback.
+ *
+ * The reference has no library interface (every function is `static`, only
+ * `main` is exported, Q:242-1284); the seam this ABI fills is the set of
+ * gate/state functions the circuit builders call (Q:683, Q:687, Q:721, Q:729,
+ * Q:922-923, Q:928) plus the allocation block in main (Q:1316-1333).
+ * include/qcx_compat.h re-creates the reference's own names and signatures on
+ * top of this header so that the bodies of inverse_QFT / quantum_computation
+ * compile unchanged.
+ *
+ * Conventions kept from the reference
+ *   - qubit b is bit b of the state index (LSB = qubit 0, GET_BIT Q:150-151);
+ *     the M register is bits [0,M), the L register bits [M,M+L) (Q:620-652).
+ *   - amplitudes are interleaved (re, im) binary64, index ascending (Q:405-406).
+ *   - status values 0..4 are the reference's ErrorCode (Q:164-170).
+ * Differences
+ *   - gates return int status instead of void (a bad qubit index is an error
+ *     here; the reference silently computes garbage);
+ *   - the `gsl_spmatrix_complex *matrix` scratch argument is gone (no matrix is
+ *     ever built); qcx_compat.h accepts and ignores it;
+ *   - one state buffer, updated in place; swap_states is a no-op.
+ * All gate calls are asynchronous on the register's HIP stream; read-back,
+ * measurement and qcx_synchronize() wait.
+ */
+#ifndef QCX_H
+#define QCX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Q:164-170 ErrorCode, extended */
+enum {
+    QCX_NO_ERROR            = 0,
+    QCX_INSUFFICIENT_MEMORY = 1,
+    QCX_BAD_ARGUMENTS       = 2,
+    QCX_PERIOD_NOT_FOUND    = 3,
+    QCX_UNKNOWN_ERROR       = 4,
+    QCX_HIP_ERROR           = 5,   /* HIP runtime / no device */
+    QCX_BAD_QUBIT           = 6,   /* qubit index >= num_qubits, or control == target */
+    QCX_UNSUPPORTED         = 7    /* valid request this build cannot serve */
+};
+
+typedef struct qcx_register qcx_register;   /* replaces Register, Q:194-203 */
+typedef struct qcx_rng      qcx_rng;        /* replaces gsl_rng (mt19937), Q:1296-1299 */
+
+const char *qcx_version(void);
+const char *qcx_status_string(int status);
+int  qcx_device_count(int *count);
+int  qcx_set_device(int device);
+
+/* ---- register lifecycle: replaces Q:1316-1324 / Q:1330-1332 -------------- */
+int  qcx_register_create(int L_size, int M_size, qcx_register **out);
+int  qcx_register_destroy(qcx_register *reg);
+unsigned      qcx_num_qubits(const qcx_register *reg);   /* Register.num_qubits */
+unsigned long qcx_num_states(const qcx_register *reg);   /* Register.num_states */
+int  qcx_L_size(const qcx_register *reg);
+int  qcx_M_size(const qcx_register *reg);
+/* launch on a caller-owned hipStream_t (NULL = the register's own stream) */
+int  qcx_register_set_stream(qcx_register *reg, void *hip_stream);
+int  qcx_synchronize(qcx_register *reg);
+
+/* ---- gate layer ----------------------------------------------------------- */
+int  qcx_reset_register(qcx_register *reg);                                        /* Q:318-324 */
+int  qcx_hadamard_gate(unsigned qubit_num, qcx_register *reg);                     /* Q:442-484 */
+int  qcx_c_phase_shift_gate(unsigned c_qubit_num, unsigned qubit_num, double theta,
+                            qcx_register *reg);                                    /* Q:513-565 */
+int  qcx_c_amodc_gate(unsigned C, unsigned long long atox, unsigned c_qubit_num,
+                      qcx_register *reg);                                          /* Q:595-660 */
+int  qcx_swap_states(qcx_register *reg);                                           /* Q:242-249: no-op */
+/* host-side gate schedules */
+int  qcx_inverse_QFT(qcx_register *reg);                                           /* Q:678-690 */
+/* atox per control qubit: intpow_mode 0 = exact a^(2^k) mod C, 1 = the
+ * reference's 32-bit INT_POW(a, x) including its wrap (Q:158-159, Q:729) */
+int  qcx_quantum_computation(unsigned C, unsigned a, int intpow_mode, qcx_register *reg); /* Q:712-737 */
+
+/* ---- measurement: Q:272-306 ----------------------------------------------- */
+int  qcx_measure_state(qcx_register *reg, qcx_rng *rng, unsigned long *state_num);
+int  qcx_measure_state_r(qcx_register *reg, double r, unsigned long *state_num);   /* r supplied */
+
+/* ---- state access (replaces gsl_vector_complex_get/set uses, T:7-37) ------- */
+int  qcx_state_read(qcx_register *reg, unsigned long first, unsigned long count, double *out_re_im);
+int  qcx_state_write(qcx_register *reg, unsigned long first, unsigned long count, const double *in_re_im);
+int  qcx_norm2(qcx_register *reg, double *total_probability);                      /* T:28-37 */
+void *qcx_device_pointer(qcx_register *reg);      /* the amplitude buffer in HBM (for interop) */
+/* synthetic input for benches and full-size tests: component k (k = 2*index + {0 re, 1 im}) is
+ * ((splitmix64(seed + k) >> 11) * 2^-53 - 0.5) * sqrt(6 / 2^n); generated on the device */
+int  qcx_state_fill_random(qcx_register *reg, uint64_t seed);
+
+/* ---- HIP-event timing on the register's stream (bench / roofline) ---------- */
+int  qcx_timer_start(qcx_register *reg);
+int  qcx_timer_stop(qcx_register *reg, double *milliseconds);    /* waits for the stop event */
+
+/* ---- MT19937 with gsl_rng_mt19937 semantics (Q:1296-1299, Q:281) ----------- */
+qcx_rng      *qcx_rng_alloc(void);
+void          qcx_rng_set(qcx_rng *rng, unsigned long seed);    /* seed 0 -> 4357 like GSL */
+unsigned long qcx_rng_get(qcx_rng *rng);
+double        qcx_rng_uniform(qcx_rng *rng);                    /* get / 2^32 */
+void          qcx_rng_free(qcx_rng *rng);
+
+/* ---- shard-level entry points on caller-owned device memory ----------------
+ * One rank of a sharded register owns 2^n_local consecutive amplitudes; the
+ * index bits above n_local are the rank id.  These are what a
+ * multi-process host (one process per GPU) calls between its exchanges.
+ * `stream` is a hipStream_t (NULL = default stream).                          */
+int  qcx_shard_reset(void *amp, unsigned n_local, int holds_index_one, void *stream);
+int  qcx_shard_fill_random(void *amp, unsigned n_local, uint64_t first_global, uint64_t seed,
+                           double scale, void *stream);
+int  qcx_shard_hadamard(void *amp, unsigned n_local, unsigned q_local, void *stream);
+/* multiply by (cos_t + i sin_t) every amplitude whose local index has all bits of
+ * `mask_local` set; mask_local has 0, 1 or 2 bits (global control bits that are 1
+ * simply drop out of the mask; a global bit that is 0 means: do not call). */
+int  qcx_shard_phase(void *amp, unsigned n_local, uint64_t mask_local, double cos_t, double sin_t, void *stream);
+/* ctl_local < 0: the control is a global bit whose value on this rank is 1 */
+int  qcx_shard_camodc(void *amp, unsigned n_local, unsigned M, unsigned C, unsigned A,
+                      int ctl_local, void *stream);
+int  qcx_shard_norm2(const void *amp, unsigned n_local, double *out, void *stream);
+/* sequential cumulative scan of |amp|^2 over this shard continuing from cum_in
+ * (global index of local 0 = first_global; indices >= last_excluded are not
+ * examined, Q:283).  Synchronous. */
+int  qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_t first_global,
+                            uint64_t last_excluded, double cum_in, double r,
+                            int *found, uint64_t *index, double *cum_out, void *stream);
+/* zero the shard; if 0 <= local_index < 2^n_local set that amplitude to (1,0) */
+int  qcx_shard_collapse(void *amp, unsigned n_local, int64_t local_index, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QCX_H */

@@ -1,0 +1,106 @@
+"""ctypes loader for libqcx.so (include/qcx.h).
+
+The HIP library is the product: if it is missing this module raises -- there is
+no CPU fallback anywhere in quantumcomputer_amd.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqcx.so")
+
+# status codes (include/qcx.h; 0..4 are the reference's ErrorCode, qc_shor.c:164-170)
+NO_ERROR, INSUFFICIENT_MEMORY, BAD_ARGUMENTS, PERIOD_NOT_FOUND, UNKNOWN_ERROR = range(5)
+HIP_ERROR, BAD_QUBIT, UNSUPPORTED = 5, 6, 7
+
+
+class QcxError(RuntimeError):
+    def __init__(self, status, where=""):
+        self.status = status
+        msg = lib().qcx_status_string(status).decode()
+        detail = lib().qcx_last_error().decode()
+        super().__init__(f"{where}: {msg} ({status})" + (f" [{detail}]" if detail else ""))
+
+
+# every symbol include/qcx.h declares, with its ctypes signature
+_u, _ul, _ull, _i, _d, _p = C.c_uint, C.c_ulong, C.c_ulonglong, C.c_int, C.c_double, C.c_void_p
+_u64, _i64 = C.c_uint64, C.c_int64
+SIGNATURES = {
+    "qcx_version": (C.c_char_p, []),
+    "qcx_status_string": (C.c_char_p, [_i]),
+    "qcx_device_count": (_i, [C.POINTER(_i)]),
+    "qcx_set_device": (_i, [_i]),
+    "qcx_register_create": (_i, [_i, _i, C.POINTER(_p)]),
+    "qcx_register_destroy": (_i, [_p]),
+    "qcx_num_qubits": (_u, [_p]),
+    "qcx_num_states": (_ul, [_p]),
+    "qcx_L_size": (_i, [_p]),
+    "qcx_M_size": (_i, [_p]),
+    "qcx_register_set_stream": (_i, [_p, _p]),
+    "qcx_synchronize": (_i, [_p]),
+    "qcx_reset_register": (_i, [_p]),
+    "qcx_hadamard_gate": (_i, [_u, _p]),
+    "qcx_c_phase_shift_gate": (_i, [_u, _u, _d, _p]),
+    "qcx_c_amodc_gate": (_i, [_u, _ull, _u, _p]),
+    "qcx_swap_states": (_i, [_p]),
+    "qcx_inverse_QFT": (_i, [_p]),
+    "qcx_quantum_computation": (_i, [_u, _u, _i, _p]),
+    "qcx_measure_state": (_i, [_p, _p, C.POINTER(_ul)]),
+    "qcx_measure_state_r": (_i, [_p, _d, C.POINTER(_ul)]),
+    "qcx_state_read": (_i, [_p, _ul, _ul, _p]),
+    "qcx_state_write": (_i, [_p, _ul, _ul, _p]),
+    "qcx_norm2": (_i, [_p, C.POINTER(_d)]),
+    "qcx_device_pointer": (_p, [_p]),
+    "qcx_state_fill_random": (_i, [_p, _u64]),
+    "qcx_shard_fill_random": (_i, [_p, _u, _u64, _u64, _d, _p]),
+    "qcx_timer_start": (_i, [_p]),
+    "qcx_timer_stop": (_i, [_p, C.POINTER(_d)]),
+    "qcx_rng_alloc": (_p, []),
+    "qcx_rng_set": (None, [_p, _ul]),
+    "qcx_rng_get": (_ul, [_p]),
+    "qcx_rng_uniform": (_d, [_p]),
+    "qcx_rng_free": (None, [_p]),
+    "qcx_shard_reset": (_i, [_p, _u, _i, _p]),
+    "qcx_shard_hadamard": (_i, [_p, _u, _u, _p]),
+    "qcx_shard_phase": (_i, [_p, _u, _u64, _d, _d, _p]),
+    "qcx_shard_camodc": (_i, [_p, _u, _u, _u, _u, _i, _p]),
+    "qcx_shard_norm2": (_i, [_p, _u, C.POINTER(_d), _p]),
+    "qcx_shard_measure_scan": (_i, [_p, _u, _u64, _u64, _d, _d, C.POINTER(_i), C.POINTER(_u64), C.POINTER(_d), _p]),
+    "qcx_shard_collapse": (_i, [_p, _u, _i64, _p]),
+}
+# not in the public header: diagnostics / tuning hooks
+_EXTRA = {
+    "qcx_last_error": (C.c_char_p, []),
+    "qcx_tune_set": (_i, [C.c_char_p, C.c_long]),
+    "qcx_tune_get": (C.c_long, [C.c_char_p]),
+    "qcx_ref_int_pow": (_u, [_d, _d]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libqcx.so once; raise loudly if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `make -C quantumcomputer_amd/csrc` "
+                "(or __graft_entry__.build()); quantumcomputer_amd has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in {**SIGNATURES, **_EXTRA}.items():
+            fn = getattr(L, name)          # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status, where=""):
+    if status != NO_ERROR:
+        raise QcxError(status, where)
+
+
+def tune(**kv):
+    for k, v in kv.items():
+        check(lib().qcx_tune_set(k.encode(), int(v)), f"tune {k}")

@@ -1,0 +1,659 @@
+// qcx_api.hip -- the C ABI of libqcx.so (include/qcx.h) on top of the gfx950
+// kernels in qcx_kernels.h.  Host side of the drop-in boundary: argument checks,
+// launch geometry, the two gate schedules (Q:678-690, Q:712-737), MT19937 and
+// measurement bookkeeping.  HIP only -- nothing here computes on the CPU.
+#include "../../include/qcx.h"
+#include "qcx_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+using namespace qcx;
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+static thread_local char g_last_error[256] = "";
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            snprintf(g_last_error, sizeof g_last_error, "%s: %s", #expr, hipGetErrorString(e_)); \
+            return (e_ == hipErrorOutOfMemory) ? QCX_INSUFFICIENT_MEMORY : QCX_HIP_ERROR;      \
+        }                                                                                      \
+    } while (0)
+
+#define QCX_TRY(expr)                     \
+    do {                                  \
+        int s_ = (expr);                  \
+        if (s_ != QCX_NO_ERROR) return s_; \
+    } while (0)
+
+extern "C" const char *qcx_last_error(void) { return g_last_error; }
+
+extern "C" const char *qcx_version(void) { return "qcx 0.1.0 (gfx950)"; }
+
+extern "C" const char *qcx_status_string(int s)
+{
+    switch (s) {
+    case QCX_NO_ERROR: return "NO_ERROR";
+    case QCX_INSUFFICIENT_MEMORY: return "INSUFFICIENT_MEMORY";
+    case QCX_BAD_ARGUMENTS: return "BAD_ARGUMENTS";
+    case QCX_PERIOD_NOT_FOUND: return "PERIOD_NOT_FOUND";
+    case QCX_UNKNOWN_ERROR: return "UNKNOWN_ERROR";
+    case QCX_HIP_ERROR: return "HIP_ERROR";
+    case QCX_BAD_QUBIT: return "BAD_QUBIT";
+    case QCX_UNSUPPORTED: return "UNSUPPORTED";
+    default: return "?";
+    }
+}
+
+extern "C" int qcx_device_count(int *count)
+{
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *count = 0; snprintf(g_last_error, sizeof g_last_error, "hipGetDeviceCount: %s", hipGetErrorString(e)); return QCX_HIP_ERROR; }
+    *count = c;
+    return QCX_NO_ERROR;
+}
+
+extern "C" int qcx_set_device(int device) { HIP_TRY(hipSetDevice(device)); return QCX_NO_ERROR; }
+
+// ---------------------------------------------------------------------------
+// launch configuration (tunable at run time so one build can be swept on the GPU)
+// ---------------------------------------------------------------------------
+struct Tune {
+    long h_variant   = 0;      // 0: auto, 1: always pair form, 2: wave-tile form where it applies
+    long h_ppt       = 4;      // pairs per thread, pair form
+    long h_nt        = 0;      // nontemporal loads/stores
+    long h_grid_cap  = 0;      // 0: one tile per block (no cap)
+    long h_wave_r    = 4;      // registers per lane, wave-tile form (4 or 8)
+    long h_wave_maxq = 5;      // auto: use the wave-tile form for q <= this
+    long ph_apt      = 4;
+    long ph_grid_cap = 0;
+    long cam_grid_cap = 4096;
+};
+static Tune g_tune;
+
+extern "C" int qcx_tune_set(const char *key, long value)
+{
+#define K(name) if (!strcmp(key, #name)) { g_tune.name = value; return QCX_NO_ERROR; }
+    K(h_variant) K(h_ppt) K(h_nt) K(h_grid_cap) K(h_wave_r) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(cam_grid_cap)
+#undef K
+    return QCX_BAD_ARGUMENTS;
+}
+
+extern "C" long qcx_tune_get(const char *key)
+{
+#define K(name) if (!strcmp(key, #name)) return g_tune.name;
+    K(h_variant) K(h_ppt) K(h_nt) K(h_grid_cap) K(h_wave_r) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(cam_grid_cap)
+#undef K
+    return -1;
+}
+
+static inline unsigned grid_for(uint64_t work_items, uint64_t per_block, long cap)
+{
+    uint64_t g = (work_items + per_block - 1) / per_block;
+    if (g == 0) g = 1;
+    if (cap > 0 && g > (uint64_t)cap) g = (uint64_t)cap;
+    if (g > 0x7fffffffULL) g = 0x7fffffffULL;       // kernels grid-stride, so any cap is valid
+    return (unsigned)g;
+}
+
+// ---------------------------------------------------------------------------
+// per-device scratch for the shard-level entry points
+// ---------------------------------------------------------------------------
+struct Workspace {
+    double     *partials = nullptr;     // NORM_BLOCKS doubles + 1
+    MeasureOut *mout = nullptr;
+    MeasureOut *h_mout = nullptr;       // pinned
+    double     *h_scalar = nullptr;     // pinned
+    uint32_t   *tab = nullptr;          // camodc CSR table (off + srcs)
+    size_t      tab_cap = 0;
+};
+static const unsigned NORM_BLOCKS = 2048;
+static std::mutex g_ws_mutex;
+static Workspace g_ws[64];
+
+static int workspace(Workspace **out)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return QCX_HIP_ERROR;
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    Workspace &w = g_ws[dev];
+    if (!w.partials) {
+        HIP_TRY(hipMalloc(&w.partials, (NORM_BLOCKS + 1) * sizeof(double)));
+        HIP_TRY(hipMalloc(&w.mout, sizeof(MeasureOut)));
+        HIP_TRY(hipHostMalloc(&w.h_mout, sizeof(MeasureOut)));
+        HIP_TRY(hipHostMalloc(&w.h_scalar, sizeof(double)));
+    }
+    *out = &w;
+    return QCX_NO_ERROR;
+}
+
+// ---------------------------------------------------------------------------
+// shard-level launches
+// ---------------------------------------------------------------------------
+extern "C" int qcx_shard_reset(void *amp, unsigned n_local, int holds_index_one, void *stream)
+{
+    if (!amp || n_local > 40) return QCX_BAD_ARGUMENTS;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(amp, 0, (size_t)16 << n_local, st));
+    if (holds_index_one) {
+        if (n_local == 0) return QCX_BAD_ARGUMENTS;          // a 1-amplitude shard has no index 1
+        hipLaunchKernelGGL(k_set_one, dim3(1), dim3(64), 0, st, (amp_t *)amp, (uint64_t)1);
+        HIP_TRY(hipGetLastError());
+    }
+    return QCX_NO_ERROR;
+}
+
+extern "C" int qcx_shard_collapse(void *amp, unsigned n_local, int64_t local_index, void *stream)
+{
+    if (!amp || n_local > 40) return QCX_BAD_ARGUMENTS;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(amp, 0, (size_t)16 << n_local, st));
+    if (local_index >= 0) {
+        if ((uint64_t)local_index >= ((uint64_t)1 << n_local)) return QCX_BAD_ARGUMENTS;
+        hipLaunchKernelGGL(k_set_one, dim3(1), dim3(64), 0, st, (amp_t *)amp, (uint64_t)local_index);
+        HIP_TRY(hipGetLastError());
+    }
+    return QCX_NO_ERROR;
+}
+
+extern "C" int qcx_shard_fill_random(void *amp, unsigned n_local, uint64_t first_global, uint64_t seed, double scale, void *stream)
+{
+    if (!amp || n_local > 40) return QCX_BAD_ARGUMENTS;
+    const uint64_t count = (uint64_t)1 << n_local;
+    hipLaunchKernelGGL(k_fill_random, dim3(grid_for(count, 256 * 4, 0)), dim3(256), 0, (hipStream_t)stream,
+                       (amp_t *)amp, count, first_global, seed, scale);
+    HIP_TRY(hipGetLastError());
+    return QCX_NO_ERROR;
+}
+
+template <int PPT, bool NT>
+static void launch_h_pair(amp_t *a, unsigned q, uint64_t npairs, hipStream_t st)
+{
+    const unsigned grid = grid_for(npairs, 256 * PPT, g_tune.h_grid_cap);
+    hipLaunchKernelGGL((k_h_pair<PPT, NT, 256>), dim3(grid), dim3(256), 0, st, a, q, npairs);
+}
+
+template <int Q, int R, bool NT>
+static void launch_h_wave_q(amp_t *a, uint64_t namps, hipStream_t st)
+{
+    const uint64_t ntiles = namps / (64 * R);
+    const unsigned grid = grid_for(ntiles, 4 /* waves per 256-thread block */, g_tune.h_grid_cap);
+    hipLaunchKernelGGL((k_h_wave<Q, R, NT, 256>), dim3(grid), dim3(256), 0, st, a, ntiles);
+}
+
+template <int R, bool NT>
+static bool launch_h_wave(amp_t *a, unsigned q, uint64_t namps, hipStream_t st)
+{
+    switch (q) {
+    case 0: launch_h_wave_q<0, R, NT>(a, namps, st); return true;
+    case 1: launch_h_wave_q<1, R, NT>(a, namps, st); return true;
+    case 2: launch_h_wave_q<2, R, NT>(a, namps, st); return true;
+    case 3: launch_h_wave_q<3, R, NT>(a, namps, st); return true;
+    case 4: launch_h_wave_q<4, R, NT>(a, namps, st); return true;
+    case 5: launch_h_wave_q<5, R, NT>(a, namps, st); return true;
+    case 6: launch_h_wave_q<6, R, NT>(a, namps, st); return true;
+    case 7: launch_h_wave_q<7, R, NT>(a, namps, st); return true;
+    case 8: if constexpr (R >= 8) { launch_h_wave_q<8, R, NT>(a, namps, st); return true; } return false;
+    default: return false;
+    }
+}
+
+extern "C" int qcx_shard_hadamard(void *amp, unsigned n_local, unsigned q, void *stream)
+{
+    if (!amp || n_local == 0 || n_local > 40) return QCX_BAD_ARGUMENTS;
+    if (q >= n_local) return QCX_BAD_QUBIT;
+    hipStream_t st = (hipStream_t)stream;
+    amp_t *a = (amp_t *)amp;
+    const uint64_t namps = (uint64_t)1 << n_local, npairs = namps >> 1;
+    const bool nt = g_tune.h_nt != 0;
+
+    // wave-tile form: needs whole 64*R tiles and the partner inside the tile
+    const int R = (g_tune.h_wave_r >= 8) ? 8 : 4;
+    const unsigned tile_bits = (R == 8) ? 9 : 8;
+    bool want_wave = (g_tune.h_variant == 2) || (g_tune.h_variant == 0 && (long)q <= g_tune.h_wave_maxq);
+    if (want_wave && q < tile_bits && n_local >= tile_bits) {
+        bool ok;
+        if (R == 8) ok = nt ? launch_h_wave<8, true>(a, q, namps, st) : launch_h_wave<8, false>(a, q, namps, st);
+        else        ok = nt ? launch_h_wave<4, true>(a, q, namps, st) : launch_h_wave<4, false>(a, q, namps, st);
+        if (ok) { HIP_TRY(hipGetLastError()); return QCX_NO_ERROR; }
+    }
+    long ppt = g_tune.h_ppt;
+    while (ppt > 1 && npairs < (uint64_t)256 * (uint64_t)ppt) ppt >>= 1;
+    switch (ppt) {
+    case 8: nt ? launch_h_pair<8, true>(a, q, npairs, st) : launch_h_pair<8, false>(a, q, npairs, st); break;
+    case 4: nt ? launch_h_pair<4, true>(a, q, npairs, st) : launch_h_pair<4, false>(a, q, npairs, st); break;
+    case 2: nt ? launch_h_pair<2, true>(a, q, npairs, st) : launch_h_pair<2, false>(a, q, npairs, st); break;
+    default: nt ? launch_h_pair<1, true>(a, q, npairs, st) : launch_h_pair<1, false>(a, q, npairs, st); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return QCX_NO_ERROR;
+}
+
+template <int NB>
+static void launch_phase(amp_t *a, unsigned b0, unsigned b1, double c, double s, uint64_t count, hipStream_t st)
+{
+    long apt = g_tune.ph_apt;
+    while (apt > 1 && count < (uint64_t)256 * (uint64_t)apt) apt >>= 1;
+    if (apt >= 4) {
+        hipLaunchKernelGGL((k_phase<NB, 4, 256>), dim3(grid_for(count, 1024, g_tune.ph_grid_cap)), dim3(256), 0, st, a, b0, b1, c, s, count);
+    } else if (apt == 2) {
+        hipLaunchKernelGGL((k_phase<NB, 2, 256>), dim3(grid_for(count, 512, g_tune.ph_grid_cap)), dim3(256), 0, st, a, b0, b1, c, s, count);
+    } else {
+        hipLaunchKernelGGL((k_phase<NB, 1, 256>), dim3(grid_for(count, 256, g_tune.ph_grid_cap)), dim3(256), 0, st, a, b0, b1, c, s, count);
+    }
+}
+
+extern "C" int qcx_shard_phase(void *amp, unsigned n_local, uint64_t mask, double cos_t, double sin_t, void *stream)
+{
+    if (!amp || n_local > 40) return QCX_BAD_ARGUMENTS;
+    if (n_local < 64 && (mask >> n_local) != 0) return QCX_BAD_QUBIT;
+    const int nb = __builtin_popcountll(mask);
+    if (nb > 2) return QCX_BAD_ARGUMENTS;
+    hipStream_t st = (hipStream_t)stream;
+    amp_t *a = (amp_t *)amp;
+    unsigned b0 = 0, b1 = 0;
+    if (nb >= 1) b0 = (unsigned)__builtin_ctzll(mask);
+    if (nb == 2) b1 = 63u - (unsigned)__builtin_clzll(mask);
+    const uint64_t count = ((uint64_t)1 << n_local) >> nb;
+    if (nb == 0) launch_phase<0>(a, 0, 0, cos_t, sin_t, count, st);
+    else if (nb == 1) launch_phase<1>(a, b0, 0, cos_t, sin_t, count, st);
+    else launch_phase<2>(a, b0, b1, cos_t, sin_t, count, st);
+    HIP_TRY(hipGetLastError());
+    return QCX_NO_ERROR;
+}
+
+static unsigned gcd_u32(unsigned a, unsigned b) { while (b) { unsigned t = a % b; a = b; b = t; } return a; }
+
+// modular inverse of a mod m (gcd(a, m) == 1, m >= 1); 0 when m == 1
+static unsigned modinv_u32(unsigned a, unsigned m)
+{
+    if (m == 1) return 0;
+    long long t = 0, nt = 1, r = m, nr = a % m;
+    while (nr != 0) {
+        long long qd = r / nr;
+        long long tmp = t - qd * nt; t = nt; nt = tmp;
+        tmp = r - qd * nr; r = nr; nr = tmp;
+    }
+    if (t < 0) t += m;
+    return (unsigned)t;
+}
+
+extern "C" int qcx_shard_camodc(void *amp, unsigned n_local, unsigned M, unsigned C, unsigned A, int ctl, void *stream)
+{
+    if (!amp || n_local > 40 || C == 0 || M > n_local) return QCX_BAD_ARGUMENTS;
+    if (ctl >= (int)n_local) return QCX_BAD_QUBIT;
+    if (M > 12) return QCX_UNSUPPORTED;              // 2^M-block no longer fits the LDS tile
+    A %= C;
+    hipStream_t st = (hipStream_t)stream;
+    amp_t *a = (amp_t *)amp;
+
+    CamodcParams P;
+    P.M = M;
+    P.logT = (M < 11) ? 11 : M;                      // >= 2048 amplitudes (32 KiB) per tile
+    if (P.logT > n_local) P.logT = n_local;
+    if (P.logT < M) return QCX_BAD_ARGUMENTS;
+    P.ctl = ctl;
+    P.C = C;
+    const uint64_t blk = (uint64_t)1 << M;
+    const uint64_t all_tiles = (uint64_t)1 << (n_local - P.logT);
+    const size_t lds = (size_t)16 << P.logT;
+
+    // closed form is valid when the control is outside the M register, every residue fits the
+    // register (C <= 2^M) and the reference's 32-bit product A*f cannot wrap (Q:598-600, Q:639)
+    const uint64_t fmax = (C < blk ? C : blk) - 1;
+    const bool wraps = (uint64_t)(C - 1) * fmax > 0xffffffffULL;
+    const bool closed = (ctl < 0 || ctl >= (int)M) && C <= blk && !wraps;
+
+    if (closed) {
+        P.d = gcd_u32(A, C);            // gcd(0, C) = C
+        P.Cd = C / P.d;
+        P.inv = modinv_u32(A / P.d, P.Cd);
+        P.ntiles = (ctl >= (int)P.logT) ? all_tiles >> 1 : all_tiles;
+        const unsigned grid = grid_for(P.ntiles, 1, g_tune.cam_grid_cap);
+        hipLaunchKernelGGL((k_camodc<256>), dim3(grid), dim3(256), lds, st, a, P);
+        HIP_TRY(hipGetLastError());
+        return QCX_NO_ERROR;
+    }
+
+    // generic path: CSR of sources per destination built as Q:611-654 maps them
+    std::vector<uint32_t> cnt(blk + 1, 0), dst(blk);
+    for (uint64_t f = 0; f < blk; f++) {
+        uint32_t d = (uint32_t)f;
+        const bool on = (ctl >= 0 && ctl < (int)M) ? ((f >> ctl) & 1u) : true;
+        if (on && f < C) d = (uint32_t)(((uint32_t)(A * (uint32_t)f)) % C) & (uint32_t)(blk - 1);
+        dst[f] = d;
+        cnt[d + 1]++;
+    }
+    for (uint64_t g = 0; g < blk; g++) cnt[g + 1] += cnt[g];
+    std::vector<uint32_t> tab(blk + 1 + blk);
+    memcpy(tab.data(), cnt.data(), (blk + 1) * sizeof(uint32_t));
+    std::vector<uint32_t> fill(cnt.begin(), cnt.end() - 1);
+    for (uint64_t f = 0; f < blk; f++) tab[blk + 1 + fill[dst[f]]++] = (uint32_t)f;   // ascending f per destination
+
+    Workspace *w;
+    QCX_TRY(workspace(&w));
+    const size_t need = tab.size() * sizeof(uint32_t);
+    {
+        std::lock_guard<std::mutex> lock(g_ws_mutex);
+        if (w->tab_cap < need) {
+            if (w->tab) HIP_TRY(hipFree(w->tab));
+            w->tab = nullptr; w->tab_cap = 0;
+            HIP_TRY(hipMalloc(&w->tab, need));
+            w->tab_cap = need;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(st));                       // the previous table may still be in use
+    HIP_TRY(hipMemcpy(w->tab, tab.data(), need, hipMemcpyHostToDevice));
+    CamodcParams Pt = P;
+    Pt.d = 1; Pt.Cd = C; Pt.inv = 0;
+    if (ctl >= 0 && ctl < (int)M) Pt.ctl = -1;               // the table already encodes the control
+    Pt.ntiles = (Pt.ctl >= (int)P.logT) ? all_tiles >> 1 : all_tiles;
+    const unsigned grid = grid_for(Pt.ntiles, 1, g_tune.cam_grid_cap);
+    hipLaunchKernelGGL((k_camodc_table<256>), dim3(grid), dim3(256), lds, st, a, Pt, w->tab, w->tab + blk + 1);
+    HIP_TRY(hipGetLastError());
+    return QCX_NO_ERROR;
+}
+
+extern "C" int qcx_shard_norm2(const void *amp, unsigned n_local, double *out, void *stream)
+{
+    if (!amp || !out || n_local > 40) return QCX_BAD_ARGUMENTS;
+    Workspace *w;
+    QCX_TRY(workspace(&w));
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t count = (uint64_t)1 << n_local;
+    const unsigned grid = grid_for(count, 256 * 8, NORM_BLOCKS);
+    hipLaunchKernelGGL((k_norm_partial<256>), dim3(grid), dim3(256), 0, st, (const amp_t *)amp, count, w->partials);
+    hipLaunchKernelGGL(k_norm_final, dim3(1), dim3(64), 0, st, w->partials, grid, w->partials + NORM_BLOCKS);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(w->h_scalar, w->partials + NORM_BLOCKS, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *out = *w->h_scalar;
+    return QCX_NO_ERROR;
+}
+
+extern "C" int qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_t first_global,
+                                      uint64_t last_excluded, double cum_in, double r,
+                                      int *found, uint64_t *index, double *cum_out, void *stream)
+{
+    if (!amp || !found || !index || !cum_out || n_local > 40) return QCX_BAD_ARGUMENTS;
+    Workspace *w;
+    QCX_TRY(workspace(&w));
+    hipStream_t st = (hipStream_t)stream;
+    uint64_t count = (uint64_t)1 << n_local;
+    if (first_global >= last_excluded) count = 0;
+    else if (last_excluded - first_global < count) count = last_excluded - first_global;
+    if (count == 0) { *found = 0; *index = 0; *cum_out = cum_in; return QCX_NO_ERROR; }
+    hipLaunchKernelGGL(k_measure_scan, dim3(1), dim3(64), 0, st, (const amp_t *)amp, count, cum_in, r, w->mout);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(w->h_mout, w->mout, sizeof(MeasureOut), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *found = w->h_mout->found;
+    *index = first_global + w->h_mout->index;
+    *cum_out = w->h_mout->cum;
+    return QCX_NO_ERROR;
+}
+
+// ---------------------------------------------------------------------------
+// register (single-GPU handle): one in-place amplitude buffer in HBM
+// ---------------------------------------------------------------------------
+struct qcx_register {
+    int        L, M;
+    unsigned   n;
+    uint64_t   dim;
+    amp_t     *amp;
+    hipStream_t own_stream, stream;
+    hipEvent_t ev0, ev1;
+};
+
+extern "C" int qcx_register_create(int L, int M, qcx_register **out)
+{
+    if (!out) return QCX_BAD_ARGUMENTS;
+    *out = nullptr;
+    if (L < 0 || M < 0 || L + M < 1 || L + M > 36) return QCX_BAD_ARGUMENTS;
+    int ndev = 0;
+    QCX_TRY(qcx_device_count(&ndev));
+    if (ndev < 1) { snprintf(g_last_error, sizeof g_last_error, "no HIP device"); return QCX_HIP_ERROR; }
+    qcx_register *r = (qcx_register *)calloc(1, sizeof(qcx_register));
+    if (!r) return QCX_INSUFFICIENT_MEMORY;
+    r->L = L; r->M = M; r->n = (unsigned)(L + M); r->dim = (uint64_t)1 << r->n;
+    hipError_t e = hipMalloc(&r->amp, r->dim * sizeof(amp_t));
+    if (e != hipSuccess) { free(r); snprintf(g_last_error, sizeof g_last_error, "hipMalloc: %s", hipGetErrorString(e)); return QCX_INSUFFICIENT_MEMORY; }
+    if (hipStreamCreate(&r->own_stream) != hipSuccess || hipEventCreate(&r->ev0) != hipSuccess || hipEventCreate(&r->ev1) != hipSuccess) {
+        (void)hipFree(r->amp); free(r); return QCX_HIP_ERROR;
+    }
+    r->stream = r->own_stream;
+    // the reference's buffers start zeroed by calloc-like GSL allocs only after reset; be deterministic
+    if (hipMemsetAsync(r->amp, 0, r->dim * sizeof(amp_t), r->stream) != hipSuccess) { (void)hipFree(r->amp); free(r); return QCX_HIP_ERROR; }
+    *out = r;
+    return QCX_NO_ERROR;
+}
+
+extern "C" int qcx_register_destroy(qcx_register *r)
+{
+    if (!r) return QCX_NO_ERROR;
+    (void)hipStreamSynchronize(r->stream);
+    (void)hipEventDestroy(r->ev0); (void)hipEventDestroy(r->ev1);
+    (void)hipStreamDestroy(r->own_stream);
+    (void)hipFree(r->amp);
+    free(r);
+    return QCX_NO_ERROR;
+}
+
+extern "C" unsigned qcx_num_qubits(const qcx_register *r) { return r ? r->n : 0; }
+extern "C" unsigned long qcx_num_states(const qcx_register *r) { return r ? (unsigned long)r->dim : 0; }
+extern "C" int qcx_L_size(const qcx_register *r) { return r ? r->L : 0; }
+extern "C" int qcx_M_size(const qcx_register *r) { return r ? r->M : 0; }
+extern "C" void *qcx_device_pointer(qcx_register *r) { return r ? (void *)r->amp : nullptr; }
+
+extern "C" int qcx_register_set_stream(qcx_register *r, void *hip_stream)
+{
+    if (!r) return QCX_BAD_ARGUMENTS;
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    r->stream = hip_stream ? (hipStream_t)hip_stream : r->own_stream;
+    return QCX_NO_ERROR;
+}
+
+extern "C" int qcx_synchronize(qcx_register *r)
+{
+    if (!r) return QCX_BAD_ARGUMENTS;
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return QCX_NO_ERROR;
+}
+
+extern "C" int qcx_reset_register(qcx_register *r)
+{
+    if (!r) return QCX_BAD_ARGUMENTS;
+    return qcx_shard_reset(r->amp, r->n, 1, r->stream);
+}
+
+extern "C" int qcx_hadamard_gate(unsigned q, qcx_register *r)
+{
+    if (!r) return QCX_BAD_ARGUMENTS;
+    if (q >= r->n) return QCX_BAD_QUBIT;
+    return qcx_shard_hadamard(r->amp, r->n, q, r->stream);
+}
+
+extern "C" int qcx_c_phase_shift_gate(unsigned c, unsigned t, double theta, qcx_register *r)
+{
+    if (!r) return QCX_BAD_ARGUMENTS;
+    if (c >= r->n || t >= r->n || c == t) return QCX_BAD_QUBIT;
+    // gsl_complex_polar(1.0, theta) (Q:526): host libm, so the oracle sees the same two doubles
+    const double er = 1.0 * cos(theta), ei = 1.0 * sin(theta);
+    return qcx_shard_phase(r->amp, r->n, ((uint64_t)1 << c) | ((uint64_t)1 << t), er, ei, r->stream);
+}
+
+extern "C" int qcx_c_amodc_gate(unsigned C, unsigned long long atox, unsigned c, qcx_register *r)
+{
+    if (!r || C == 0) return QCX_BAD_ARGUMENTS;
+    if (c >= r->n) return QCX_BAD_QUBIT;
+    return qcx_shard_camodc(r->amp, r->n, (unsigned)r->M, C, (unsigned)(atox % C), (int)c, r->stream);
+}
+
+extern "C" int qcx_swap_states(qcx_register *r) { return r ? QCX_NO_ERROR : QCX_BAD_ARGUMENTS; }
+
+extern "C" int qcx_inverse_QFT(qcx_register *r)
+{
+    if (!r) return QCX_BAD_ARGUMENTS;
+    for (int l = r->L + r->M - 1; l >= r->M; l--) {
+        QCX_TRY(qcx_hadamard_gate((unsigned)l, r));
+        for (int k = l - 1; k >= r->M; k--) {
+            const double theta = M_PI / (double)((uint64_t)1 << (unsigned)(l - k));   // Q:686
+            QCX_TRY(qcx_c_phase_shift_gate((unsigned)l, (unsigned)k, theta, r));
+        }
+    }
+    return QCX_NO_ERROR;
+}
+
+// the reference's INT_POW (Q:158-159) as x86-64 gcc evaluates it: pow, +0.5, truncation to a
+// signed 64-bit integer (out of range gives 0x8000000000000000), low 32 bits kept
+extern "C" unsigned qcx_ref_int_pow(double base, double power)
+{
+    const double d = pow(base, power) + 0.5;
+    if (!(d > -9223372036854775808.0 && d < 9223372036854775808.0)) return 0u;
+    return (unsigned)(unsigned long long)(long long)d;
+}
+
+extern "C" int qcx_quantum_computation(unsigned C, unsigned a, int intpow_mode, qcx_register *r)
+{
+    if (!r || C == 0) return QCX_BAD_ARGUMENTS;
+    const unsigned lo = r->n - (unsigned)r->L;
+    for (unsigned l = lo; l < r->n; l++) QCX_TRY(qcx_hadamard_gate(l, r));
+    unsigned x = 1;                                   // Q:714
+    unsigned long long exact = a % C;                 // a^(2^k) mod C by repeated squaring
+    for (unsigned l = lo; l < r->n; l++) {
+        const unsigned long long atox = intpow_mode ? (unsigned long long)qcx_ref_int_pow((double)a, (double)x) : exact;
+        QCX_TRY(qcx_c_amodc_gate(C, atox, l, r));
+        x *= 2;                                       // Q:730
+        exact = (exact * exact) % C;
+    }
+    return qcx_inverse_QFT(r);
+}
+
+extern "C" int qcx_measure_state_r(qcx_register *r, double rnd, unsigned long *state_num)
+{
+    if (!r || !state_num) return QCX_BAD_ARGUMENTS;
+    int found = 0; uint64_t idx = 0; double cum = 0.0;
+    QCX_TRY(qcx_shard_measure_scan(r->amp, r->n, 0, r->dim - 1, 0.0, rnd, &found, &idx, &cum, r->stream));
+    if (!found) idx = r->dim - 1;                                           // Q:283 fall-through
+    QCX_TRY(qcx_shard_collapse(r->amp, r->n, (int64_t)idx, r->stream));     // Q:302-303
+    *state_num = (unsigned long)idx;
+    return QCX_NO_ERROR;
+}
+
+extern "C" int qcx_measure_state(qcx_register *r, qcx_rng *rng, unsigned long *state_num)
+{
+    if (!rng) return QCX_BAD_ARGUMENTS;
+    return qcx_measure_state_r(r, qcx_rng_uniform(rng), state_num);         // Q:281
+}
+
+extern "C" int qcx_state_read(qcx_register *r, unsigned long first, unsigned long count, double *out)
+{
+    if (!r || (!out && count)) return QCX_BAD_ARGUMENTS;
+    if ((uint64_t)first > r->dim || (uint64_t)count > r->dim - first) return QCX_BAD_ARGUMENTS;
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    if (count) HIP_TRY(hipMemcpy(out, r->amp + first, (size_t)count * sizeof(amp_t), hipMemcpyDeviceToHost));
+    return QCX_NO_ERROR;
+}
+
+extern "C" int qcx_state_write(qcx_register *r, unsigned long first, unsigned long count, const double *in)
+{
+    if (!r || (!in && count)) return QCX_BAD_ARGUMENTS;
+    if ((uint64_t)first > r->dim || (uint64_t)count > r->dim - first) return QCX_BAD_ARGUMENTS;
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    if (count) HIP_TRY(hipMemcpy(r->amp + first, in, (size_t)count * sizeof(amp_t), hipMemcpyHostToDevice));
+    return QCX_NO_ERROR;
+}
+
+extern "C" int qcx_norm2(qcx_register *r, double *out)
+{
+    if (!r || !out) return QCX_BAD_ARGUMENTS;
+    return qcx_shard_norm2(r->amp, r->n, out, r->stream);
+}
+
+extern "C" int qcx_state_fill_random(qcx_register *r, uint64_t seed)
+{
+    if (!r) return QCX_BAD_ARGUMENTS;
+    // U(-0.5, 0.5) components have variance 1/12: this scale makes the expected norm 1
+    return qcx_shard_fill_random(r->amp, r->n, 0, seed, sqrt(6.0 / (double)r->dim), r->stream);
+}
+
+extern "C" int qcx_timer_start(qcx_register *r)
+{
+    if (!r) return QCX_BAD_ARGUMENTS;
+    HIP_TRY(hipEventRecord(r->ev0, r->stream));
+    return QCX_NO_ERROR;
+}
+
+extern "C" int qcx_timer_stop(qcx_register *r, double *ms)
+{
+    if (!r || !ms) return QCX_BAD_ARGUMENTS;
+    HIP_TRY(hipEventRecord(r->ev1, r->stream));
+    HIP_TRY(hipEventSynchronize(r->ev1));
+    float f = 0.f;
+    HIP_TRY(hipEventElapsedTime(&f, r->ev0, r->ev1));
+    *ms = (double)f;
+    return QCX_NO_ERROR;
+}
+
+// ---------------------------------------------------------------------------
+// MT19937 with gsl_rng_mt19937 semantics (GSL 2.6 rng/mt.c: 2002 seeding, seed 0 -> 4357,
+// uniform = u32 / 2^32).  Restated from the published generator definition.
+// ---------------------------------------------------------------------------
+struct qcx_rng {
+    uint32_t s[624];
+    int pos;
+};
+
+extern "C" qcx_rng *qcx_rng_alloc(void)
+{
+    qcx_rng *g = (qcx_rng *)malloc(sizeof(qcx_rng));
+    if (g) qcx_rng_set(g, 0);
+    return g;
+}
+
+extern "C" void qcx_rng_free(qcx_rng *g) { free(g); }
+
+extern "C" void qcx_rng_set(qcx_rng *g, unsigned long seed)
+{
+    uint32_t v = (uint32_t)(seed & 0xffffffffUL);
+    if (v == 0) v = 4357u;
+    for (int i = 0; i < 624; i++) {
+        g->s[i] = v;
+        v = 1812433253u * (v ^ (v >> 30)) + (uint32_t)(i + 1);
+    }
+    g->pos = 624;
+}
+
+extern "C" unsigned long qcx_rng_get(qcx_rng *g)
+{
+    if (g->pos == 624) {
+        uint32_t *s = g->s;
+        auto twist = [](uint32_t u, uint32_t v) { uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu); return (y >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u); };
+        int k = 0;
+        for (; k < 624 - 397; k++) s[k] = s[k + 397] ^ twist(s[k], s[k + 1]);
+        for (; k < 623; k++)       s[k] = s[k + 397 - 624] ^ twist(s[k], s[k + 1]);
+        s[623] = s[396] ^ twist(s[623], s[0]);
+        g->pos = 0;
+    }
+    uint32_t y = g->s[g->pos++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return (unsigned long)y;
+}
+
+extern "C" double qcx_rng_uniform(qcx_rng *g) { return (double)qcx_rng_get(g) / 4294967296.0; }

@@ -1,0 +1,369 @@
+// qcx_kernels.h -- hand-written gfx950 (CDNA4) kernels for the gate-application
+// path of qc_shor.c.  HBM-bound streaming kernels on the in-place amplitude
+// vector; wave64 everywhere.  No matrix is built and no mat-vec is run: each
+// kernel computes, per amplitude, exactly the sums the reference's COO
+// mat-vec (Q:396-413) would have produced for that gate, in the same order
+// and with the same roundings (compile with -ffp-contract=off).
+//
+// Bit-exactness notes (proved against the oracle in tests/):
+//   reference output  = 0 + term0 (+ term1), term = (mr*cr)-(mi*ci) with mi = 0
+//   kernel output     = (t0 (+|-) t1) + 0.0
+// identical for every finite input, zero signs included: the only effect of
+// the reference's "0 +" and "- 0*x" is to turn a -0 result into +0, which the
+// trailing "+ 0.0" reproduces (it is not foldable under IEEE rules).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace qcx {
+
+typedef double amp_t __attribute__((ext_vector_type(2)));   // (re, im): one 16-B global access
+
+#define QCX_SQRT1_2 0.70710678118654752440   /* M_SQRT1_2, Q:210-213 */
+
+__device__ __forceinline__ uint64_t insert_zero(uint64_t p, unsigned b)
+{
+    const uint64_t low = ((uint64_t)1 << b) - 1;
+    return ((p & ~low) << 1) | (p & low);
+}
+
+template <bool NT> __device__ __forceinline__ amp_t ld(const amp_t *p)
+{
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+template <bool NT> __device__ __forceinline__ void st(amp_t *p, amp_t v)
+{
+    if (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+// one Hadamard butterfly: a = amplitude with target bit 0, b = with target bit 1
+__device__ __forceinline__ void h_butterfly(amp_t &a, amp_t &b)
+{
+    const double s = QCX_SQRT1_2;
+    const double t0r = s * a.x, t0i = s * a.y, t1r = s * b.x, t1i = s * b.y;
+    a.x = (t0r + t1r) + 0.0;  a.y = (t0i + t1i) + 0.0;
+    b.x = (t0r - t1r) + 0.0;  b.y = (t0i - t1i) + 0.0;
+}
+
+// ---------------------------------------------------------------------------
+// K1a  Hadamard, pair form, any target qubit.  Thread p owns the pair
+// (i0, i0 | 2^q) with i0 = p with a zero inserted at bit q.  For q >= 6 both
+// streams are 1-KiB-per-wave-instruction coalesced; below that the two loads of
+// a wave interleave inside one 2-KiB window.  PPT pairs per thread are loaded
+// before any is stored (2*PPT independent 16-B loads in flight per lane).
+// ---------------------------------------------------------------------------
+template <int PPT, bool NT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_h_pair(amp_t *__restrict__ amp, unsigned q, uint64_t npairs)
+{
+    const uint64_t low = ((uint64_t)1 << q) - 1, bit = (uint64_t)1 << q;
+    const uint64_t step = (uint64_t)gridDim.x * (BLOCK * PPT);
+    for (uint64_t base = (uint64_t)blockIdx.x * (BLOCK * PPT); base < npairs; base += step) {
+        amp_t a[PPT], b[PPT];
+        uint64_t i0[PPT];
+#pragma unroll
+        for (int k = 0; k < PPT; k++) {
+            const uint64_t p = base + (uint64_t)k * BLOCK + threadIdx.x;
+            i0[k] = ((p & ~low) << 1) | (p & low);
+            if (p < npairs) { a[k] = ld<NT>(amp + i0[k]); b[k] = ld<NT>(amp + i0[k] + bit); }
+        }
+#pragma unroll
+        for (int k = 0; k < PPT; k++) {
+            const uint64_t p = base + (uint64_t)k * BLOCK + threadIdx.x;
+            if (p < npairs) {
+                h_butterfly(a[k], b[k]);
+                st<NT>(amp + i0[k], a[k]);
+                st<NT>(amp + i0[k] + bit, b[k]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1b  Hadamard, wave-tile form for low target qubits (q < 6 + log2 R).
+// A wave owns 64*R consecutive amplitudes as R registers x 64 lanes, every
+// load/store a fully coalesced 1 KiB.  Partners sit in another lane (q < 6:
+// wavefront xor-shuffle butterfly) or in another register of the same lane.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ amp_t shfl_xor_amp(amp_t v, int lane_mask)
+{
+    amp_t r;
+    r.x = __shfl_xor(v.x, lane_mask, 64);
+    r.y = __shfl_xor(v.y, lane_mask, 64);
+    return r;
+}
+
+template <int Q, int R>
+__device__ __forceinline__ void h_wave_tile(amp_t (&r)[R], unsigned lane)
+{
+    const double s = QCX_SQRT1_2;
+    if constexpr (Q < 6) {
+        const bool upper = (lane >> Q) & 1u;
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            amp_t t; t.x = s * r[k].x; t.y = s * r[k].y;
+            const amp_t o = shfl_xor_amp(t, 1 << Q);
+            // lower lane: t + o ; upper lane: o - t   (o is the bit-0 partner's product)
+            r[k].x = (upper ? (o.x - t.x) : (t.x + o.x)) + 0.0;
+            r[k].y = (upper ? (o.y - t.y) : (t.y + o.y)) + 0.0;
+        }
+    } else {
+        constexpr int D = 1 << (Q - 6);
+#pragma unroll
+        for (int k = 0; k < R; k++)
+            if ((k & D) == 0) h_butterfly(r[k], r[k + D]);
+    }
+}
+
+template <int Q, int R, bool NT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_h_wave(amp_t *__restrict__ amp, uint64_t ntiles)
+{
+    // tile = 64*R amplitudes, one per wave per iteration
+    const unsigned lane = threadIdx.x & 63u;
+    const uint64_t wave = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * BLOCK) >> 6;
+    for (uint64_t t = wave; t < ntiles; t += nwaves) {
+        amp_t *base = amp + t * (64 * R) + lane;
+        amp_t r[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) r[k] = ld<NT>(base + k * 64);
+        h_wave_tile<Q, R>(r, lane);
+#pragma unroll
+        for (int k = 0; k < R; k++) st<NT>(base + k * 64, r[k]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2  controlled phase: multiply by (c + i s) every amplitude whose index has
+// all NB mask bits set (b0 < b1).  Only that 1/2^NB of the vector is touched.
+// ---------------------------------------------------------------------------
+template <int NB, int APT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_phase(amp_t *__restrict__ amp, unsigned b0, unsigned b1,
+                                                   double c, double s, uint64_t count)
+{
+    const uint64_t step = (uint64_t)gridDim.x * (BLOCK * APT);
+    for (uint64_t base = (uint64_t)blockIdx.x * (BLOCK * APT); base < count; base += step) {
+        amp_t v[APT];
+        uint64_t idx[APT];
+#pragma unroll
+        for (int k = 0; k < APT; k++) {
+            const uint64_t p = base + (uint64_t)k * BLOCK + threadIdx.x;
+            uint64_t i = p;
+            if (NB >= 1) i = insert_zero(i, b0) | ((uint64_t)1 << b0);
+            if (NB >= 2) i = insert_zero(i, b1) | ((uint64_t)1 << b1);
+            idx[k] = i;
+            if (p < count) v[k] = amp[i];
+        }
+#pragma unroll
+        for (int k = 0; k < APT; k++) {
+            const uint64_t p = base + (uint64_t)k * BLOCK + threadIdx.x;
+            if (p < count) {
+                amp_t o;
+                o.x = ((c * v[k].x) - (s * v[k].y)) + 0.0;      // Q:409
+                o.y = ((c * v[k].y) + (s * v[k].x)) + 0.0;      // Q:412
+                amp[idx[k]] = o;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3  controlled modular multiply on the low M bits (Q:595-660).  Pure data
+// movement: destination g (< C) of every 2^M-block with the control bit set
+// receives the sum, in ascending source order, of the amplitudes at the
+// sources f < C with (A*f) mod C == g.  With d = gcd(A, C) those are
+//     f = f0 + t*(C/d),  t = 0..d-1,  f0 = ((g/d) * inv) mod (C/d),  d | g
+// (inv = (A/d)^-1 mod C/d, computed on the host); for the usual coprime case
+// d = 1 and the gate is a permutation.  A tile of 2^logT >= 2^M amplitudes is
+// staged in LDS so the update is in place with coalesced global traffic; tiles
+// whose control bit is 0 are never touched.
+// ---------------------------------------------------------------------------
+struct CamodcParams {
+    unsigned M, logT;
+    int      ctl;        // local bit index, or -1: control lives in the rank id and is 1
+    unsigned C, d, Cd, inv;
+    uint64_t ntiles;     // tiles to process (control-set tiles only when ctl >= logT)
+};
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_camodc(amp_t *__restrict__ amp, CamodcParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qcx_lds_raw[];
+    amp_t *tile = reinterpret_cast<amp_t *>(qcx_lds_raw);
+    const unsigned T = 1u << P.logT, blkmask = (1u << P.M) - 1u;
+    for (uint64_t tt = blockIdx.x; tt < P.ntiles; tt += gridDim.x) {
+        uint64_t tsel = tt;
+        if (P.ctl >= (int)P.logT) tsel = insert_zero(tt, (unsigned)P.ctl - P.logT) | ((uint64_t)1 << ((unsigned)P.ctl - P.logT));
+        amp_t *g = amp + (tsel << P.logT);
+        for (unsigned e = threadIdx.x; e < T; e += BLOCK) tile[e] = g[e];
+        __syncthreads();
+        for (unsigned e = threadIdx.x; e < T; e += BLOCK) {
+            const unsigned f = e & blkmask;
+            bool on = true;
+            if (P.ctl >= 0 && P.ctl < (int)P.logT) on = (e >> P.ctl) & 1u;
+            if (!on || f >= P.C) continue;                     // identity rows (Q:611-613, Q:631-634)
+            amp_t acc; acc.x = 0.0; acc.y = 0.0;
+            if (f % P.d == 0) {
+                unsigned src = (unsigned)(((uint64_t)(f / P.d) * P.inv) % P.Cd);
+                const amp_t *blk = tile + (e - f);
+                for (unsigned t = 0; t < P.d; t++, src += P.Cd) { acc.x += blk[src].x; acc.y += blk[src].y; }
+            }
+            g[e] = acc;
+        }
+        __syncthreads();
+    }
+}
+
+// generic table form (C > 2^M, or 32-bit wrap in A*f): CSR of sources per
+// destination low-bits value, built on the host exactly as Q:619-647 maps them.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_camodc_table(amp_t *__restrict__ amp, CamodcParams P,
+                                                          const uint32_t *__restrict__ off,
+                                                          const uint32_t *__restrict__ srcs)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qcx_lds_raw[];
+    amp_t *tile = reinterpret_cast<amp_t *>(qcx_lds_raw);
+    const unsigned T = 1u << P.logT, blkmask = (1u << P.M) - 1u;
+    for (uint64_t tt = blockIdx.x; tt < P.ntiles; tt += gridDim.x) {
+        uint64_t tsel = tt;
+        if (P.ctl >= (int)P.logT) tsel = insert_zero(tt, (unsigned)P.ctl - P.logT) | ((uint64_t)1 << ((unsigned)P.ctl - P.logT));
+        amp_t *g = amp + (tsel << P.logT);
+        for (unsigned e = threadIdx.x; e < T; e += BLOCK) tile[e] = g[e];
+        __syncthreads();
+        for (unsigned e = threadIdx.x; e < T; e += BLOCK) {
+            const unsigned f = e & blkmask;
+            bool on = true;
+            if (P.ctl >= 0 && P.ctl < (int)P.logT) on = (e >> P.ctl) & 1u;
+            if (!on) continue;
+            // with the control inside the M register the source's own control bit decides
+            const amp_t *blk = tile + (e - f);
+            amp_t acc; acc.x = 0.0; acc.y = 0.0;
+            for (uint32_t k = off[f]; k < off[f + 1]; k++) { acc.x += blk[srcs[k]].x; acc.y += blk[srcs[k]].y; }
+            g[e] = acc;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K0 helpers
+// ---------------------------------------------------------------------------
+__global__ void k_set_one(amp_t *amp, uint64_t index)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { amp_t v; v.x = 1.0; v.y = 0.0; amp[index] = v; }
+}
+
+// synthetic input: counter-based pseudo-random amplitudes, component k of the whole vector is
+//   ((splitmix64(seed + k) >> 11) * 2^-53 - 0.5) * scale      (k = 2*index + {0: re, 1: im})
+// every operation exact or singly rounded, so the CPU twin in oracle/ gives the same bits and a
+// window of a 16-GiB state can be checked without ever holding it on the host.
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(256) void k_fill_random(amp_t *__restrict__ amp, uint64_t count, uint64_t first_global,
+                                                     uint64_t seed, double scale)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t k = 2 * (first_global + i);
+        amp_t v;
+        v.x = ((double)(splitmix64(seed + k) >> 11) * 0x1p-53 - 0.5) * scale;
+        v.y = ((double)(splitmix64(seed + k + 1) >> 11) * 0x1p-53 - 0.5) * scale;
+        amp[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K5  total probability.  Deterministic two-stage tree (fixed grid), not the
+// reference's sequential order (T:28-37) -- a check value, compared with a
+// tolerance.
+// ---------------------------------------------------------------------------
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_norm_partial(const amp_t *__restrict__ amp, uint64_t count, double *partial)
+{
+    __shared__ double red[BLOCK / 64];
+    double acc = 0.0;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < count; i += (uint64_t)gridDim.x * BLOCK) {
+        const amp_t v = amp[i];
+        acc += v.x * v.x + v.y * v.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < BLOCK / 64; w++) t += red[w];
+        partial[blockIdx.x] = t;
+    }
+}
+
+__global__ void k_norm_final(const double *partial, unsigned nparts, double *out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double t = 0.0;
+        for (unsigned i = 0; i < nparts; i++) t += partial[i];
+        *out = t;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K4  measurement scan, exact form: the reference's strictly sequential
+// cumulative sum (Q:283-292) carried by ONE wave.  Lanes fetch 64 amplitudes
+// at a time (coalesced) and the 64 additions are chained in index order; lane
+// k ends each round holding the running sum through element k, so the first
+// lane with cum >= r is the reference's answer bit for bit.
+// ---------------------------------------------------------------------------
+struct MeasureOut {
+    int      found;
+    uint64_t index;
+    double   cum;
+};
+
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    union { double d; int i[2]; } u; u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+    return u.d;
+}
+
+__global__ __launch_bounds__(64) void k_measure_scan(const amp_t *__restrict__ amp, uint64_t count,
+                                                     double cum_in, double r, MeasureOut *out)
+{
+    const unsigned lane = threadIdx.x;
+    double cum = cum_in;
+    amp_t nxt; nxt.x = 0.0; nxt.y = 0.0;
+    if (lane < count) nxt = amp[lane];
+    for (uint64_t base = 0; base < count; base += 64) {
+        const amp_t v = nxt;
+        const uint64_t ni = base + 64 + lane;
+        nxt.x = 0.0; nxt.y = 0.0;
+        if (ni < count) nxt = amp[ni];                       // prefetch the next round
+        const double p = v.x * v.x + v.y * v.y;              // gsl_complex_abs2 (Q:286); 0 past the end
+        double run = cum;
+#pragma unroll
+        for (int j = 0; j < 64; j++) {
+            const double pj = readlane_f64(p, j);
+            run = run + ((int)lane >= j ? pj : 0.0);         // + 0.0 leaves a non-negative sum unchanged
+        }
+        const bool hit = (base + lane < count) && (run >= r);
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+            const int first = __builtin_ctzll(m);
+            if ((int)lane == first) { out->found = 1; out->index = base + lane; out->cum = run; }
+            return;
+        }
+        cum = readlane_f64(run, 63);
+    }
+    if (lane == 0) { out->found = 0; out->index = 0; out->cum = cum; }
+}
+
+}  // namespace qcx

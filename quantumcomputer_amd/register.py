@@ -1,0 +1,181 @@
+"""Host-side mirror of the reference's gate/state interface over libqcx.so.
+
+Function names, argument order and qubit numbering follow qc_shor.c so that code
+(and tests) written against the reference read the same here:
+
+    reference (qc_shor.c)                       here
+    ------------------------------------------  -------------------------------------
+    Register + alloc/free (194-203, 1316-1333)  Register(L_size, M_size) / .close()
+    reset_register(reg)              318-324    reset_register(reg)
+    hadamard_gate(q, &reg, matrix)   442-484    hadamard_gate(q, reg, matrix=None)
+    c_phase_shift_gate(c, q, th, ..) 513-565    c_phase_shift_gate(c, q, theta, reg)
+    c_amodc_gate(C, atox, c, ..)     595-660    c_amodc_gate(C, atox, c, reg)
+    inverse_QFT(&reg, matrix)        678-690    inverse_QFT(reg)
+    quantum_computation(C, a, ..)    712-737    quantum_computation(C, a, reg)
+    measure_state(reg, rng)          272-306    measure_state(reg, rng)
+    swap_states(&reg)                242-249    swap_states(reg)   (no-op: in place)
+    gsl_rng mt19937                  1296-1299  Rng(seed)
+
+The `matrix` scratch argument of the reference is accepted and ignored: no gate
+matrix is ever built.  Everything executes in the HIP library; a missing library
+or GPU raises (see _lib.py).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+
+
+class Rng:
+    """gsl_rng_mt19937 equivalent (qc_shor.c:1296-1299)."""
+
+    def __init__(self, seed=0):
+        self._h = lib().qcx_rng_alloc()
+        if not self._h:
+            raise MemoryError("qcx_rng_alloc")
+        lib().qcx_rng_set(self._h, seed & 0xFFFFFFFF)
+
+    def set(self, seed):
+        lib().qcx_rng_set(self._h, seed & 0xFFFFFFFF)
+
+    def get(self):
+        return int(lib().qcx_rng_get(self._h))
+
+    def uniform(self):
+        return float(lib().qcx_rng_uniform(self._h))
+
+    def close(self):
+        if self._h:
+            lib().qcx_rng_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Register:
+    """The qubit register (qc_shor.c:194-203): L_size, M_size, num_qubits, num_states and the
+    state vector, which lives in HBM as 2^n interleaved (re, im) doubles, updated in place."""
+
+    def __init__(self, L_size, M_size):
+        h = C.c_void_p()
+        check(lib().qcx_register_create(int(L_size), int(M_size), C.byref(h)), "qcx_register_create")
+        self._h = h
+        self.L_size = int(L_size)
+        self.M_size = int(M_size)
+        self.num_qubits = int(lib().qcx_num_qubits(h))
+        self.num_states = int(lib().qcx_num_states(h))
+
+    # -- lifecycle -------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().qcx_register_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- state access (gsl_vector_complex_get/set uses; testing_and_debug.c:7-37) ------------
+    def read(self, first=0, count=None):
+        """Amplitudes [first, first+count) as a float64 array of 2*count (re, im) values."""
+        if count is None:
+            count = self.num_states - first
+        out = np.empty(2 * count, dtype=np.float64)
+        check(lib().qcx_state_read(self._h, first, count, out.ctypes.data_as(C.c_void_p)), "qcx_state_read")
+        return out
+
+    def write(self, amps, first=0):
+        a = np.ascontiguousarray(amps, dtype=np.float64)
+        if a.size % 2:
+            raise ValueError("amplitudes are (re, im) pairs")
+        check(lib().qcx_state_write(self._h, first, a.size // 2, a.ctypes.data_as(C.c_void_p)), "qcx_state_write")
+
+    def fill_random(self, seed):
+        """synthetic dense state generated on the device (include/qcx.h: qcx_state_fill_random)"""
+        check(lib().qcx_state_fill_random(self._h, int(seed)), "qcx_state_fill_random")
+
+    def norm2(self):
+        """Total probability (testing_and_debug.c:28-37), tree-summed on the GPU."""
+        out = C.c_double(0.0)
+        check(lib().qcx_norm2(self._h, C.byref(out)), "qcx_norm2")
+        return out.value
+
+    def synchronize(self):
+        check(lib().qcx_synchronize(self._h), "qcx_synchronize")
+
+    def set_stream(self, hip_stream_ptr):
+        check(lib().qcx_register_set_stream(self._h, C.c_void_p(hip_stream_ptr)), "qcx_register_set_stream")
+
+    def device_pointer(self):
+        return int(lib().qcx_device_pointer(self._h) or 0)
+
+    def timer_start(self):
+        check(lib().qcx_timer_start(self._h), "qcx_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_double(0.0)
+        check(lib().qcx_timer_stop(self._h, C.byref(ms)), "qcx_timer_stop")
+        return ms.value
+
+
+# ---- the reference's free functions ----------------------------------------------------------
+def reset_register(reg):
+    check(lib().qcx_reset_register(reg._h), "reset_register")
+
+
+def hadamard_gate(qubit_num, reg, matrix=None):
+    check(lib().qcx_hadamard_gate(qubit_num, reg._h), "hadamard_gate")
+
+
+def c_phase_shift_gate(c_qubit_num, qubit_num, theta, reg, matrix=None):
+    check(lib().qcx_c_phase_shift_gate(c_qubit_num, qubit_num, float(theta), reg._h), "c_phase_shift_gate")
+
+
+def c_amodc_gate(C_, atox, c_qubit_num, reg, matrix=None):
+    check(lib().qcx_c_amodc_gate(C_, int(atox), c_qubit_num, reg._h), "c_amodc_gate")
+
+
+def swap_states(reg):
+    check(lib().qcx_swap_states(reg._h), "swap_states")
+
+
+def inverse_QFT(reg, matrix=None):
+    check(lib().qcx_inverse_QFT(reg._h), "inverse_QFT")
+
+
+def quantum_computation(C_, a, reg, matrix=None, ref_intpow=False):
+    """ref_intpow=True reproduces the reference's 32-bit INT_POW(a, x) (qc_shor.c:158-159, 729)."""
+    check(lib().qcx_quantum_computation(C_, a, int(bool(ref_intpow)), reg._h), "quantum_computation")
+
+
+def measure_state(reg, rng):
+    """Collapse the register; returns the measured basis-state index (qc_shor.c:272-306).
+    `rng` is an Rng, or a float r in [0,1) to inject the uniform draw directly."""
+    out = C.c_ulong(0)
+    if isinstance(rng, Rng):
+        check(lib().qcx_measure_state(reg._h, rng._h, C.byref(out)), "measure_state")
+    else:
+        check(lib().qcx_measure_state_r(reg._h, float(rng), C.byref(out)), "measure_state")
+    return int(out.value)
+
+
+def read_omega(state_num, reg):
+    """x~/2^L with the L register read in reversed bit order (qc_shor.c:868-883)."""
+    x = 0
+    for p in range(reg.L_size):
+        x |= ((state_num >> (reg.L_size + reg.M_size - 1 - p)) & 1) << p
+    return x / float(1 << reg.L_size)

@@ -1,0 +1,189 @@
+"""GPU parity tests proper: every gate of the hot path through the C ABI (libqcx.so) against the
+CPU oracle on the same seeded inputs, BIT-EXACT (uint64 views of the doubles are compared, so even
+the sign of a zero has to agree)."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def assert_bits_equal(got, want, what=""):
+    g, w = bits(got), bits(want)
+    if not np.array_equal(g, w):
+        bad = np.nonzero(g != w)[0]
+        raise AssertionError(f"{what}: {bad.size}/{g.size} doubles differ; first at {bad[0]}: "
+                             f"got {got[bad[0]]!r} want {want[bad[0]]!r}")
+
+
+def sparse_random_state(ob, n, seed):
+    """random state with exact zeros and repeated magnitudes sprinkled in (cancellation -> +0 cases)"""
+    a = ob.random_state(n, seed)
+    rs = np.random.RandomState(seed)
+    v = a.reshape(-1, 2)
+    k = max(1, v.shape[0] // 4)
+    v[rs.randint(0, v.shape[0], k)] = 0.0
+    if v.shape[0] >= 4:
+        v[1] = v[0]; v[3] = -v[2]
+    return np.ascontiguousarray(a)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 7, 8, 9, 10, 11, 13, 16])
+def test_hadamard_every_qubit_bit_exact(qc, ob, n):
+    for seed, maker in ((7, ob.random_state), (11, lambda nn, ss: sparse_random_state(ob, nn, ss))):
+        for q in range(n):
+            a = maker(n, seed + q)
+            with qc.Register(n, 0) as reg:
+                reg.write(a)
+                qc.hadamard_gate(q, reg)
+                got = reg.read()
+            want = a.copy(); ob.hadamard(want, n, q)
+            assert_bits_equal(got, want, f"H n={n} q={q}")
+
+
+@pytest.mark.parametrize("variant", [dict(h_variant=1, h_ppt=1), dict(h_variant=1, h_ppt=8, h_nt=1),
+                                     dict(h_variant=2, h_wave_r=4), dict(h_variant=2, h_wave_r=8, h_nt=1),
+                                     dict(h_variant=1, h_ppt=4, h_grid_cap=3)])
+def test_hadamard_all_kernel_variants(qc, ob, variant):
+    """every launch form of K1 (pair form / wave-tile shuffle form, nontemporal or not, capped grid)"""
+    defaults = {k: qc.lib().qcx_tune_get(k.encode()) for k in ("h_variant", "h_ppt", "h_nt", "h_grid_cap", "h_wave_r")}
+    try:
+        qc.tune(**variant)
+        for n in (9, 12, 14):
+            for q in range(n):
+                a = ob.random_state(n, 100 + q)
+                with qc.Register(n, 0) as reg:
+                    reg.write(a); qc.hadamard_gate(q, reg); got = reg.read()
+                want = a.copy(); ob.hadamard(want, n, q)
+                assert_bits_equal(got, want, f"H {variant} n={n} q={q}")
+    finally:
+        qc.tune(**defaults)
+
+
+@pytest.mark.parametrize("n", [2, 3, 6, 10, 12, 15])
+def test_cphase_bit_exact(qc, ob, n):
+    rs = np.random.RandomState(n)
+    pairs = [(c, t) for c in range(n) for t in range(n) if c != t]
+    if len(pairs) > 40:
+        pairs = [pairs[i] for i in rs.choice(len(pairs), 40, replace=False)]
+    for k, (c, t) in enumerate(pairs):
+        theta = math.pi / (1 << (1 + k % 12)) if k % 3 else rs.uniform(-7, 7)
+        a = ob.random_state(n, 300 + k)
+        with qc.Register(n, 0) as reg:
+            reg.write(a); qc.c_phase_shift_gate(c, t, theta, reg); got = reg.read()
+        want = a.copy(); ob.cphase(want, n, c, t, theta)
+        assert_bits_equal(got, want, f"CPHASE n={n} c={c} t={t} theta={theta}")
+
+
+CAMODC_CASES = [
+    # (L, M, C, atox, ctl)
+    (3, 4, 15, 7, 4), (3, 4, 15, 7 ** 2, 5), (3, 4, 15, 4, 6),        # Shor N=15 ladder
+    (5, 5, 21, 2, 5), (5, 5, 21, 16, 7), (5, 5, 21, 2 ** 16, 9),      # Shor N=21
+    (4, 6, 33, 7, 8), (2, 10, 1000, 999, 11), (2, 12, 4093, 1234, 12), (1, 12, 4096, 4095, 12),
+    (3, 4, 15, 5, 4), (3, 4, 15, 3, 6), (3, 4, 15, 0, 5), (3, 4, 15, 15, 5),   # gcd(A, C) > 1: many-to-one sums
+    (4, 5, 21, 7, 6), (3, 6, 36, 6, 7),
+    (4, 3, 15, 7, 4), (4, 3, 21, 2, 5),                                # C > 2^M: only bits < M of f' kept
+    (3, 5, 21, 2, 2), (3, 5, 21, 10, 0), (3, 4, 15, 7, 3),             # control inside the M register
+    (12, 4, 15, 7, 15), (13, 5, 21, 4, 17), (9, 5, 21, 2, 10),         # control above / inside the LDS tile
+]
+
+
+@pytest.mark.parametrize("L,M,C,atox,ctl", CAMODC_CASES)
+def test_camodc_bit_exact(qc, ob, L, M, C, atox, ctl):
+    n = L + M
+    a = ob.random_state(n, 500 + ctl)
+    with qc.Register(L, M) as reg:
+        reg.write(a); qc.c_amodc_gate(C, atox, ctl, reg); got = reg.read()
+    want = a.copy(); ob.camodc(want, n, M, C, atox, ctl)
+    assert_bits_equal(got, want, f"C_AMODC L={L} M={M} C={C} atox={atox} ctl={ctl}")
+
+
+def test_reset_register(qc):
+    with qc.Register(5, 4) as reg:
+        reg.write(np.full(2 << 9, 0.25))
+        qc.reset_register(reg)
+        s = reg.read()
+    want = np.zeros(2 << 9); want[2] = 1.0
+    assert_bits_equal(s, want, "reset")
+
+
+@pytest.mark.parametrize("L,M,C,a", [(3, 4, 15, 7), (4, 4, 15, 7), (5, 5, 21, 2), (5, 5, 33, 7), (8, 4, 15, 7), (6, 6, 35, 2)])
+def test_shor_circuit_bit_exact(qc, ob, L, M, C, a):
+    n = L + M
+    with qc.Register(L, M) as reg:
+        qc.reset_register(reg)
+        qc.quantum_computation(C, a, reg)
+        got = reg.read()
+        total = reg.norm2()
+    want = np.zeros(2 << n); ob.reset(want, n); ob.quantum_computation(want, n, M, C, a)
+    assert_bits_equal(got, want, f"Shor circuit C={C} L={L} M={M} a={a}")
+    assert abs(total - 1.0) < 1e-13
+
+
+def test_shor_circuit_reference_intpow_mode(qc, ob):
+    """the reference's wrapped INT_POW (a=7, L=8: 7^128 overflows) reproduced on request"""
+    L, M, C, a = 8, 4, 15, 7
+    n = L + M
+    with qc.Register(L, M) as reg:
+        qc.reset_register(reg); qc.quantum_computation(C, a, reg, ref_intpow=True); got = reg.read()
+    want = np.zeros(2 << n); ob.reset(want, n); ob.quantum_computation(want, n, M, C, a, ref_intpow=True)
+    assert_bits_equal(got, want, "ref-intpow circuit")
+
+
+def test_iqft_schedule_full_register(qc, ob):
+    n = 12
+    a = ob.random_state(n, 77)
+    with qc.Register(n, 0) as reg:
+        reg.write(a); qc.inverse_QFT(reg); got = reg.read()
+    want = a.copy(); ob.iqft(want, n, 0)
+    assert_bits_equal(got, want, "IQFT schedule n=12")
+
+
+def test_measurement_histogram_matches_reference_seed(qc, ob):
+    """C=15 L=3 M=4 a=7, MT19937 seed 12345, 500 shots -> 123/113/127/137"""
+    L, M = 3, 4
+    rng = qc.Rng(12345)
+    hist = {}
+    with qc.Register(L, M) as reg:
+        for _ in range(500):
+            qc.reset_register(reg)
+            qc.quantum_computation(15, 7, reg)
+            idx = qc.measure_state(reg, rng)
+            w = qc.read_omega(idx, reg)
+            hist[w] = hist.get(w, 0) + 1
+            s = reg.read()
+            assert s[2 * idx] == 1.0 and np.count_nonzero(s) == 1
+    assert hist == {0.0: 123, 0.25: 113, 0.5: 127, 0.75: 137}
+
+
+@pytest.mark.parametrize("n", [1, 5, 6, 7, 11, 14])
+def test_measure_index_bit_exact_against_sequential_sum(qc, ob, n):
+    a = ob.random_state(n, 900 + n)
+    rs = np.random.RandomState(n)
+    cum = np.cumsum((a.reshape(-1, 2) ** 2).sum(axis=1))
+    rvals = [0.0, 1.0 - 2 ** -53, 0.999999, 0.5, float(cum[0]), float(cum[min(3, cum.size - 1)]),
+             float(np.nextafter(cum[cum.size // 2], 2.0))] + list(rs.uniform(0, 1, 12))
+    for r in rvals:
+        want_state = a.copy(); want = ob.measure(want_state, n, r)
+        with qc.Register(n, 0) as reg:
+            reg.write(a); got = qc.measure_state(reg, r); got_state = reg.read()
+        assert got == want, f"n={n} r={r!r}: got {got} want {want}"
+        assert_bits_equal(got_state, want_state, "collapsed state")
+
+
+def test_bad_arguments(qc):
+    from quantumcomputer_amd import QcxError
+    with qc.Register(3, 2) as reg:
+        with pytest.raises(QcxError):
+            qc.hadamard_gate(5, reg)
+        with pytest.raises(QcxError):
+            qc.c_phase_shift_gate(1, 1, 0.3, reg)
+        with pytest.raises(QcxError):
+            qc.c_amodc_gate(15, 7, 9, reg)
+    with pytest.raises(QcxError):
+        qc.Register(40, 40)

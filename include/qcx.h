@@ -99,6 +99,10 @@ int  qcx_state_fill_random(qcx_register *reg, uint64_t seed);
 /* ---- HIP-event timing on the register's stream (bench / roofline) ---------- */
 int  qcx_timer_start(qcx_register *reg);
 int  qcx_timer_stop(qcx_register *reg, double *milliseconds);    /* waits for the stop event */
+/* a pool of events: record between gates inside a timed region, read the differences afterwards */
+int  qcx_events_create(qcx_register *reg, unsigned count);
+int  qcx_event_record(qcx_register *reg, unsigned slot);
+int  qcx_event_elapsed(qcx_register *reg, unsigned from_slot, unsigned to_slot, double *milliseconds);
 
 /* ---- MT19937 with gsl_rng_mt19937 semantics (Q:1296-1299, Q:281) ----------- */
 qcx_rng      *qcx_rng_alloc(void);

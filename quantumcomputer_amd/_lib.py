@@ -55,6 +55,9 @@ SIGNATURES = {
     "qcx_shard_fill_random": (_i, [_p, _u, _u64, _u64, _d, _p]),
     "qcx_timer_start": (_i, [_p]),
     "qcx_timer_stop": (_i, [_p, C.POINTER(_d)]),
+    "qcx_events_create": (_i, [_p, _u]),
+    "qcx_event_record": (_i, [_p, _u]),
+    "qcx_event_elapsed": (_i, [_p, _u, _u, C.POINTER(_d)]),
     "qcx_rng_alloc": (_p, []),
     "qcx_rng_set": (None, [_p, _ul]),
     "qcx_rng_get": (_ul, [_p]),

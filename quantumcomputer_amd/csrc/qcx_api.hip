@@ -72,11 +72,16 @@ extern "C" int qcx_set_device(int device) { HIP_TRY(hipSetDevice(device)); retur
 // ---------------------------------------------------------------------------
 struct Tune {
     long h_variant   = 0;      // 0: auto, 1: always pair form, 2: wave-tile form where it applies
-    long h_ppt       = 4;      // pairs per thread, pair form
-    long h_nt        = 0;      // nontemporal loads/stores
+    long h_ppt       = 1;      // pairs per thread, pair form
+    long h_nt        = 3;      // nontemporal: bit 0 loads, bit 1 stores (pair form, q >= 3)
+    long h_wave_nt   = 3;      // same for the wave-tile form in auto mode
+    long h_wc        = 0;      // pair form: per-wave-contiguous load order
+    long h_block     = 64;     // pair form: threads per block (64/128/256/512)
+    long h_streams_log2 = 0;   // pair form: deal tiles as 2^k interleaved streams (3 = one per XCD)
     long h_grid_cap  = 0;      // 0: one tile per block (no cap)
-    long h_wave_r    = 4;      // registers per lane, wave-tile form (4 or 8)
-    long h_wave_maxq = 5;      // auto: use the wave-tile form for q <= this
+    long h_wave_r    = 4;      // registers per lane, wave-tile form (2, 4 or 8)
+    long h_wave_block = 256;   // wave-tile form: threads per block (64 or 256)
+    long h_wave_maxq = 7;      // auto: use the wave-tile form for q <= this
     long ph_apt      = 4;
     long ph_grid_cap = 0;
     long cam_grid_cap = 4096;
@@ -86,7 +91,7 @@ static Tune g_tune;
 extern "C" int qcx_tune_set(const char *key, long value)
 {
 #define K(name) if (!strcmp(key, #name)) { g_tune.name = value; return QCX_NO_ERROR; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_grid_cap) K(h_wave_r) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(cam_grid_cap)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(cam_grid_cap)
 #undef K
     return QCX_BAD_ARGUMENTS;
 }
@@ -94,7 +99,7 @@ extern "C" int qcx_tune_set(const char *key, long value)
 extern "C" long qcx_tune_get(const char *key)
 {
 #define K(name) if (!strcmp(key, #name)) return g_tune.name;
-    K(h_variant) K(h_ppt) K(h_nt) K(h_grid_cap) K(h_wave_r) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(cam_grid_cap)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(cam_grid_cap)
 #undef K
     return -1;
 }
@@ -179,36 +184,112 @@ extern "C" int qcx_shard_fill_random(void *amp, unsigned n_local, uint64_t first
     return QCX_NO_ERROR;
 }
 
-template <int PPT, bool NT>
+template <int PPT, bool NTL, bool NTS, bool WC, int BLOCK>
 static void launch_h_pair(amp_t *a, unsigned q, uint64_t npairs, hipStream_t st)
 {
-    const unsigned grid = grid_for(npairs, 256 * PPT, g_tune.h_grid_cap);
-    hipLaunchKernelGGL((k_h_pair<PPT, NT, 256>), dim3(grid), dim3(256), 0, st, a, q, npairs);
+    const unsigned grid = grid_for(npairs, BLOCK * PPT, g_tune.h_grid_cap);
+    // stream-interleaved tile order only for an uncapped power-of-two grid that divides evenly
+    unsigned glog = 0, slog = 0;
+    if ((grid & (grid - 1)) == 0 && (uint64_t)grid * (BLOCK * PPT) == npairs) {
+        glog = 31u - (unsigned)__builtin_clz(grid);
+        if (g_tune.h_streams_log2 > 0 && (unsigned)g_tune.h_streams_log2 <= glog) slog = (unsigned)g_tune.h_streams_log2;
+    }
+    hipLaunchKernelGGL((k_h_pair<PPT, NTL, NTS, WC, BLOCK>), dim3(grid), dim3(BLOCK), 0, st, a, q, npairs, glog, slog);
 }
 
-template <int Q, int R, bool NT>
+template <int PPT, int BLOCK>
+static void launch_h_pair_flags(amp_t *a, unsigned q, uint64_t npairs, hipStream_t st, long nt, bool wc)
+{
+    const int f = (int)(nt & 3) | (wc ? 4 : 0);
+    switch (f) {
+    case 0: launch_h_pair<PPT, false, false, false, BLOCK>(a, q, npairs, st); break;
+    case 3: launch_h_pair<PPT, true, true, false, BLOCK>(a, q, npairs, st); break;
+    case 4: launch_h_pair<PPT, false, false, true, BLOCK>(a, q, npairs, st); break;
+    case 7: launch_h_pair<PPT, true, true, true, BLOCK>(a, q, npairs, st); break;
+    case 1: case 5: launch_h_pair<PPT, true, false, false, BLOCK>(a, q, npairs, st); break;
+    default: launch_h_pair<PPT, false, true, false, BLOCK>(a, q, npairs, st); break;
+    }
+}
+
+template <int PPT>
+static void launch_h_pair_block(amp_t *a, unsigned q, uint64_t npairs, hipStream_t st, long nt, bool wc)
+{
+    switch (g_tune.h_block) {
+    case 64:  launch_h_pair_flags<PPT, 64>(a, q, npairs, st, nt, wc); break;
+    case 128: launch_h_pair_flags<PPT, 128>(a, q, npairs, st, nt, wc); break;
+    case 512: launch_h_pair_flags<PPT, 512>(a, q, npairs, st, nt, wc); break;
+    default:  launch_h_pair_flags<PPT, 256>(a, q, npairs, st, nt, wc); break;
+    }
+}
+
+static void stream_map(unsigned grid, uint64_t covered, uint64_t total, long want_slog, unsigned *glog, unsigned *slog)
+{
+    *glog = 0; *slog = 0;
+    if ((grid & (grid - 1)) == 0 && covered == total) {       // uncapped power-of-two grid that divides evenly
+        *glog = 31u - (unsigned)__builtin_clz(grid);
+        if (want_slog > 0 && (unsigned)want_slog <= *glog) *slog = (unsigned)want_slog;
+    }
+}
+
+template <int Q, int R, bool NTL, bool NTS>
 static void launch_h_wave_q(amp_t *a, uint64_t namps, hipStream_t st)
 {
     const uint64_t ntiles = namps / (64 * R);
-    const unsigned grid = grid_for(ntiles, 4 /* waves per 256-thread block */, g_tune.h_grid_cap);
-    hipLaunchKernelGGL((k_h_wave<Q, R, NT, 256>), dim3(grid), dim3(256), 0, st, a, ntiles);
+    unsigned glog, slog;
+    if (g_tune.h_wave_block == 64) {
+        const unsigned grid = grid_for(ntiles, 1, g_tune.h_grid_cap);
+        stream_map(grid, grid, ntiles, g_tune.h_streams_log2, &glog, &slog);
+        hipLaunchKernelGGL((k_h_wave<Q, R, NTL, NTS, 64>), dim3(grid), dim3(64), 0, st, a, ntiles, glog, slog);
+    } else {
+        const unsigned grid = grid_for(ntiles, 4 /* waves per 256-thread block */, g_tune.h_grid_cap);
+        stream_map(grid, (uint64_t)grid * 4, ntiles, g_tune.h_streams_log2, &glog, &slog);
+        hipLaunchKernelGGL((k_h_wave<Q, R, NTL, NTS, 256>), dim3(grid), dim3(256), 0, st, a, ntiles, glog, slog);
+    }
 }
 
-template <int R, bool NT>
+template <int R, bool NTL, bool NTS>
 static bool launch_h_wave(amp_t *a, unsigned q, uint64_t namps, hipStream_t st)
 {
     switch (q) {
-    case 0: launch_h_wave_q<0, R, NT>(a, namps, st); return true;
-    case 1: launch_h_wave_q<1, R, NT>(a, namps, st); return true;
-    case 2: launch_h_wave_q<2, R, NT>(a, namps, st); return true;
-    case 3: launch_h_wave_q<3, R, NT>(a, namps, st); return true;
-    case 4: launch_h_wave_q<4, R, NT>(a, namps, st); return true;
-    case 5: launch_h_wave_q<5, R, NT>(a, namps, st); return true;
-    case 6: launch_h_wave_q<6, R, NT>(a, namps, st); return true;
-    case 7: launch_h_wave_q<7, R, NT>(a, namps, st); return true;
-    case 8: if constexpr (R >= 8) { launch_h_wave_q<8, R, NT>(a, namps, st); return true; } return false;
+    case 0: launch_h_wave_q<0, R, NTL, NTS>(a, namps, st); return true;
+    case 1: launch_h_wave_q<1, R, NTL, NTS>(a, namps, st); return true;
+    case 2: launch_h_wave_q<2, R, NTL, NTS>(a, namps, st); return true;
+    case 3: launch_h_wave_q<3, R, NTL, NTS>(a, namps, st); return true;
+    case 4: launch_h_wave_q<4, R, NTL, NTS>(a, namps, st); return true;
+    case 5: launch_h_wave_q<5, R, NTL, NTS>(a, namps, st); return true;
+    case 6: launch_h_wave_q<6, R, NTL, NTS>(a, namps, st); return true;
+    case 7: if constexpr (R >= 4) { launch_h_wave_q<7, R, NTL, NTS>(a, namps, st); return true; } return false;
+    case 8: if constexpr (R >= 8) { launch_h_wave_q<8, R, NTL, NTS>(a, namps, st); return true; } return false;
     default: return false;
     }
+}
+
+template <int R>
+static bool launch_h_wave_flags(amp_t *a, unsigned q, uint64_t namps, hipStream_t st, long nt)
+{
+    if ((nt & 3) == 3) return launch_h_wave<R, true, true>(a, q, namps, st);
+    return launch_h_wave<R, false, false>(a, q, namps, st);
+}
+
+// Launch plan per target qubit, measured on MI355X (tools/tune_h.py, profiles/r01_tune_h_*.json).
+// What matters is the ABSOLUTE pair distance 2^q * 16 B (the same q behaves the same at n = 26, 28
+// and 30), i.e. how the two streams of a wave fall onto HBM channels and banks:
+//   - the smallest work item wins everywhere: one wave, 2 x 16 B per lane (2 KiB in flight per wave);
+//   - below q = 3 a pair shares a 128-B line, so the wave-tile (shuffle) form with whole-line
+//     nontemporal accesses is used; from q = 3 the pair form with nontemporal loads and stores;
+//   - dealing the tiles as 2^s interleaved streams (s = 1..3) moves the concurrently active windows
+//     apart; the best s depends on q (q = 20..23 are the hard distances, s = 3 and 2 pairs/thread).
+struct HPlan { int wave_form; int ppt; int block; int slog; };
+static HPlan h_plan(unsigned q)
+{
+    if (q <= 2)  return {1, 0, 256, 2};
+    if (q <= 6)  return {0, 1, 64, 2};
+    if (q <= 17) return {0, 1, 64, 1};
+    if (q <= 19) return {0, 1, 64, 0};
+    if (q == 20) return {0, 1, 64, 1};
+    if (q <= 23) return {0, 2, 64, 3};
+    if (q == 24 || q == 26 || q == 27) return {0, 1, 64, 1};
+    return {0, 1, 64, 0};
 }
 
 extern "C" int qcx_shard_hadamard(void *amp, unsigned n_local, unsigned q, void *stream)
@@ -218,28 +299,42 @@ extern "C" int qcx_shard_hadamard(void *amp, unsigned n_local, unsigned q, void 
     hipStream_t st = (hipStream_t)stream;
     amp_t *a = (amp_t *)amp;
     const uint64_t namps = (uint64_t)1 << n_local, npairs = namps >> 1;
-    const bool nt = g_tune.h_nt != 0;
 
+    Tune saved = g_tune;
+    if (g_tune.h_variant == 0) {                     // auto: the measured plan
+        const HPlan pl = h_plan(q);
+        g_tune.h_variant = pl.wave_form ? 2 : 1;
+        g_tune.h_wave_r = 2; g_tune.h_wave_block = pl.block;
+        g_tune.h_ppt = pl.ppt; g_tune.h_block = pl.block;
+        g_tune.h_streams_log2 = pl.slog; g_tune.h_nt = 3; g_tune.h_wc = 0; g_tune.h_grid_cap = 0;
+    }
+    int status = QCX_NO_ERROR;
+    bool launched = false;
     // wave-tile form: needs whole 64*R tiles and the partner inside the tile
-    const int R = (g_tune.h_wave_r >= 8) ? 8 : 4;
-    const unsigned tile_bits = (R == 8) ? 9 : 8;
-    bool want_wave = (g_tune.h_variant == 2) || (g_tune.h_variant == 0 && (long)q <= g_tune.h_wave_maxq);
-    if (want_wave && q < tile_bits && n_local >= tile_bits) {
-        bool ok;
-        if (R == 8) ok = nt ? launch_h_wave<8, true>(a, q, namps, st) : launch_h_wave<8, false>(a, q, namps, st);
-        else        ok = nt ? launch_h_wave<4, true>(a, q, namps, st) : launch_h_wave<4, false>(a, q, namps, st);
-        if (ok) { HIP_TRY(hipGetLastError()); return QCX_NO_ERROR; }
+    const int R = (g_tune.h_wave_r >= 8) ? 8 : (g_tune.h_wave_r >= 4 ? 4 : 2);
+    const unsigned tile_bits = (R == 8) ? 9 : (R == 4 ? 8 : 7);
+    if (g_tune.h_variant == 2 && q < tile_bits && n_local >= tile_bits + 2) {
+        launched = (R == 8) ? launch_h_wave_flags<8>(a, q, namps, st, g_tune.h_nt)
+                 : (R == 4) ? launch_h_wave_flags<4>(a, q, namps, st, g_tune.h_nt)
+                            : launch_h_wave_flags<2>(a, q, namps, st, g_tune.h_nt);
     }
-    long ppt = g_tune.h_ppt;
-    while (ppt > 1 && npairs < (uint64_t)256 * (uint64_t)ppt) ppt >>= 1;
-    switch (ppt) {
-    case 8: nt ? launch_h_pair<8, true>(a, q, npairs, st) : launch_h_pair<8, false>(a, q, npairs, st); break;
-    case 4: nt ? launch_h_pair<4, true>(a, q, npairs, st) : launch_h_pair<4, false>(a, q, npairs, st); break;
-    case 2: nt ? launch_h_pair<2, true>(a, q, npairs, st) : launch_h_pair<2, false>(a, q, npairs, st); break;
-    default: nt ? launch_h_pair<1, true>(a, q, npairs, st) : launch_h_pair<1, false>(a, q, npairs, st); break;
+    if (!launched) {
+        long ppt = g_tune.h_ppt;
+        while (ppt > 1 && npairs < (uint64_t)512 * (uint64_t)ppt) ppt >>= 1;
+        // nontemporal accesses only pay when a wave-instruction covers whole 128-B lines (q >= 3)
+        const long nt = (q >= 3) ? g_tune.h_nt : 0;
+        const bool wc = g_tune.h_wc != 0;
+        switch (ppt) {
+        case 8: launch_h_pair_block<8>(a, q, npairs, st, nt, wc); break;
+        case 4: launch_h_pair_block<4>(a, q, npairs, st, nt, wc); break;
+        case 2: launch_h_pair_block<2>(a, q, npairs, st, nt, wc); break;
+        default: launch_h_pair_block<1>(a, q, npairs, st, nt, wc); break;
+        }
     }
-    HIP_TRY(hipGetLastError());
-    return QCX_NO_ERROR;
+    g_tune = saved;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_last_error, sizeof g_last_error, "hadamard launch: %s", hipGetErrorString(e)); status = QCX_HIP_ERROR; }
+    return status;
 }
 
 template <int NB>
@@ -416,6 +511,8 @@ struct qcx_register {
     amp_t     *amp;
     hipStream_t own_stream, stream;
     hipEvent_t ev0, ev1;
+    hipEvent_t *events;
+    unsigned   n_events;
 };
 
 extern "C" int qcx_register_create(int L, int M, qcx_register **out)
@@ -446,6 +543,8 @@ extern "C" int qcx_register_destroy(qcx_register *r)
     if (!r) return QCX_NO_ERROR;
     (void)hipStreamSynchronize(r->stream);
     (void)hipEventDestroy(r->ev0); (void)hipEventDestroy(r->ev1);
+    for (unsigned i = 0; i < r->n_events; i++) (void)hipEventDestroy(r->events[i]);
+    free(r->events);
     (void)hipStreamDestroy(r->own_stream);
     (void)hipFree(r->amp);
     free(r);
@@ -588,6 +687,38 @@ extern "C" int qcx_state_fill_random(qcx_register *r, uint64_t seed)
     if (!r) return QCX_BAD_ARGUMENTS;
     // U(-0.5, 0.5) components have variance 1/12: this scale makes the expected norm 1
     return qcx_shard_fill_random(r->amp, r->n, 0, seed, sqrt(6.0 / (double)r->dim), r->stream);
+}
+
+// a pool of HIP events on the register's stream: record between gates inside a timed region,
+// read the differences afterwards (per-kernel durations for the roofline, bench.py)
+extern "C" int qcx_events_create(qcx_register *r, unsigned count)
+{
+    if (!r || count > 65536) return QCX_BAD_ARGUMENTS;
+    for (unsigned i = 0; i < r->n_events; i++) (void)hipEventDestroy(r->events[i]);
+    free(r->events);
+    r->events = nullptr; r->n_events = 0;
+    if (count == 0) return QCX_NO_ERROR;
+    r->events = (hipEvent_t *)calloc(count, sizeof(hipEvent_t));
+    if (!r->events) return QCX_INSUFFICIENT_MEMORY;
+    for (unsigned i = 0; i < count; i++) { HIP_TRY(hipEventCreate(&r->events[i])); r->n_events = i + 1; }
+    return QCX_NO_ERROR;
+}
+
+extern "C" int qcx_event_record(qcx_register *r, unsigned slot)
+{
+    if (!r || slot >= r->n_events) return QCX_BAD_ARGUMENTS;
+    HIP_TRY(hipEventRecord(r->events[slot], r->stream));
+    return QCX_NO_ERROR;
+}
+
+extern "C" int qcx_event_elapsed(qcx_register *r, unsigned from_slot, unsigned to_slot, double *ms)
+{
+    if (!r || !ms || from_slot >= r->n_events || to_slot >= r->n_events) return QCX_BAD_ARGUMENTS;
+    HIP_TRY(hipEventSynchronize(r->events[to_slot]));
+    float f = 0.f;
+    HIP_TRY(hipEventElapsedTime(&f, r->events[from_slot], r->events[to_slot]));
+    *ms = (double)f;
+    return QCX_NO_ERROR;
 }
 
 extern "C" int qcx_timer_start(qcx_register *r)

@@ -56,27 +56,37 @@ __device__ __forceinline__ void h_butterfly(amp_t &a, amp_t &b)
 // a wave interleave inside one 2-KiB window.  PPT pairs per thread are loaded
 // before any is stored (2*PPT independent 16-B loads in flight per lane).
 // ---------------------------------------------------------------------------
-template <int PPT, bool NT, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_h_pair(amp_t *__restrict__ amp, unsigned q, uint64_t npairs)
+template <int PPT, bool NTL, bool NTS, bool WC, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_h_pair(amp_t *__restrict__ amp, unsigned q, uint64_t npairs,
+                                                    unsigned glog, unsigned slog)
 {
     const uint64_t low = ((uint64_t)1 << q) - 1, bit = (uint64_t)1 << q;
     const uint64_t step = (uint64_t)gridDim.x * (BLOCK * PPT);
-    for (uint64_t base = (uint64_t)blockIdx.x * (BLOCK * PPT); base < npairs; base += step) {
+    // WC: a wave's PPT loads are consecutive 64-pair runs (per-wave contiguous); otherwise the
+    // block's waves interleave (k-th load of the block covers BLOCK consecutive pairs)
+    const unsigned toff = WC ? ((threadIdx.x >> 6) * (64 * PPT) + (threadIdx.x & 63u)) : threadIdx.x;
+    constexpr unsigned kstride = WC ? 64 : BLOCK;
+    // block -> tile map: with slog > 0 the 2^glog tiles are dealt as 2^slog interleaved streams, so
+    // blocks b, b + 2^slog, ... walk one contiguous region (slog = 3: one stream per XCD under the
+    // round-robin block placement; speed only, any placement is correct)
+    uint64_t tile0 = blockIdx.x;
+    if (slog) tile0 = ((uint64_t)(blockIdx.x & ((1u << slog) - 1u)) << (glog - slog)) | (blockIdx.x >> slog);
+    for (uint64_t base = tile0 * (BLOCK * PPT); base < npairs; base += step) {
         amp_t a[PPT], b[PPT];
         uint64_t i0[PPT];
 #pragma unroll
         for (int k = 0; k < PPT; k++) {
-            const uint64_t p = base + (uint64_t)k * BLOCK + threadIdx.x;
+            const uint64_t p = base + (uint64_t)k * kstride + toff;
             i0[k] = ((p & ~low) << 1) | (p & low);
-            if (p < npairs) { a[k] = ld<NT>(amp + i0[k]); b[k] = ld<NT>(amp + i0[k] + bit); }
+            if (p < npairs) { a[k] = ld<NTL>(amp + i0[k]); b[k] = ld<NTL>(amp + i0[k] + bit); }
         }
 #pragma unroll
         for (int k = 0; k < PPT; k++) {
-            const uint64_t p = base + (uint64_t)k * BLOCK + threadIdx.x;
+            const uint64_t p = base + (uint64_t)k * kstride + toff;
             if (p < npairs) {
                 h_butterfly(a[k], b[k]);
-                st<NT>(amp + i0[k], a[k]);
-                st<NT>(amp + i0[k] + bit, b[k]);
+                st<NTS>(amp + i0[k], a[k]);
+                st<NTS>(amp + i0[k] + bit, b[k]);
             }
         }
     }
@@ -118,21 +128,23 @@ __device__ __forceinline__ void h_wave_tile(amp_t (&r)[R], unsigned lane)
     }
 }
 
-template <int Q, int R, bool NT, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_h_wave(amp_t *__restrict__ amp, uint64_t ntiles)
+template <int Q, int R, bool NTL, bool NTS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_h_wave(amp_t *__restrict__ amp, uint64_t ntiles, unsigned glog, unsigned slog)
 {
-    // tile = 64*R amplitudes, one per wave per iteration
+    // tile = 64*R amplitudes, one per wave per iteration; slog: stream-interleaved block order as in k_h_pair
     const unsigned lane = threadIdx.x & 63u;
-    const uint64_t wave = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    uint64_t blk = blockIdx.x;
+    if (slog) blk = ((uint64_t)(blockIdx.x & ((1u << slog) - 1u)) << (glog - slog)) | (blockIdx.x >> slog);
+    const uint64_t wave = (blk * BLOCK + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * BLOCK) >> 6;
     for (uint64_t t = wave; t < ntiles; t += nwaves) {
         amp_t *base = amp + t * (64 * R) + lane;
         amp_t r[R];
 #pragma unroll
-        for (int k = 0; k < R; k++) r[k] = ld<NT>(base + k * 64);
+        for (int k = 0; k < R; k++) r[k] = ld<NTL>(base + k * 64);
         h_wave_tile<Q, R>(r, lane);
 #pragma unroll
-        for (int k = 0; k < R; k++) st<NT>(base + k * 64, r[k]);
+        for (int k = 0; k < R; k++) st<NTS>(base + k * 64, r[k]);
     }
 }
 

@@ -123,6 +123,17 @@ class Register:
     def device_pointer(self):
         return int(lib().qcx_device_pointer(self._h) or 0)
 
+    def events_create(self, count):
+        check(lib().qcx_events_create(self._h, count), "qcx_events_create")
+
+    def event_record(self, slot):
+        check(lib().qcx_event_record(self._h, slot), "qcx_event_record")
+
+    def event_elapsed(self, a, b):
+        ms = C.c_double(0.0)
+        check(lib().qcx_event_elapsed(self._h, a, b, C.byref(ms)), "qcx_event_elapsed")
+        return ms.value
+
     def timer_start(self):
         check(lib().qcx_timer_start(self._h), "qcx_timer_start")
 

@@ -46,12 +46,14 @@ def test_hadamard_every_qubit_bit_exact(qc, ob, n):
             assert_bits_equal(got, want, f"H n={n} q={q}")
 
 
-@pytest.mark.parametrize("variant", [dict(h_variant=1, h_ppt=1), dict(h_variant=1, h_ppt=8, h_nt=1),
-                                     dict(h_variant=2, h_wave_r=4), dict(h_variant=2, h_wave_r=8, h_nt=1),
-                                     dict(h_variant=1, h_ppt=4, h_grid_cap=3)])
+@pytest.mark.parametrize("variant", [
+    dict(h_variant=1, h_ppt=1, h_block=256, h_nt=0), dict(h_variant=1, h_ppt=8, h_nt=3, h_block=128, h_wc=1),
+    dict(h_variant=1, h_ppt=2, h_block=64, h_streams_log2=3), dict(h_variant=1, h_ppt=1, h_block=512, h_streams_log2=1),
+    dict(h_variant=2, h_wave_r=2, h_wave_block=256, h_streams_log2=2), dict(h_variant=2, h_wave_r=4, h_wave_block=64, h_nt=0),
+    dict(h_variant=2, h_wave_r=8, h_nt=3, h_streams_log2=1), dict(h_variant=1, h_ppt=4, h_grid_cap=3, h_block=256)])
 def test_hadamard_all_kernel_variants(qc, ob, variant):
     """every launch form of K1 (pair form / wave-tile shuffle form, nontemporal or not, capped grid)"""
-    defaults = {k: qc.lib().qcx_tune_get(k.encode()) for k in ("h_variant", "h_ppt", "h_nt", "h_grid_cap", "h_wave_r")}
+    defaults = {k: qc.lib().qcx_tune_get(k.encode()) for k in ("h_variant", "h_ppt", "h_nt", "h_grid_cap", "h_wave_r", "h_wave_block", "h_block", "h_streams_log2", "h_wc")}
     try:
         qc.tune(**variant)
         for n in (9, 12, 14):

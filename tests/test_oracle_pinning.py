@@ -1,0 +1,227 @@
+"""CPU: pin the oracle.  (1) against the reference's known-answer material committed in
+tests/golden/survey_appendix_c.json; (2) literal form (index-pair scan -> COO -> mat-vec, the
+reference's algorithm) == pairwise in-place form, bit for bit, on everything the literal form can
+reach; (3) MT19937 against published known answers and numpy's independent implementation."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "survey_appendix_c.json")))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def shor_state(ob, C, L, M, a, ref_intpow=False, literal=False):
+    n = L + M
+    if literal:
+        R = ob.LiteralRegister(L, M)
+        R.reset(); R.quantum_computation(C, a, ref_intpow)
+        s = R.state().copy(); R.close()
+        return s
+    s = np.zeros(2 << n); ob.reset(s, n); ob.quantum_computation(s, n, M, C, a, ref_intpow)
+    return s
+
+
+def xtilde_probs(s, L, M):
+    p = (s.reshape(-1, 2) ** 2).sum(axis=1)
+    out = {}
+    for idx in np.nonzero(p)[0]:
+        x = 0
+        for k in range(L):
+            x |= ((int(idx) >> (L + M - 1 - k)) & 1) << k
+        out[x] = out.get(x, 0.0) + float(p[idx])
+    return out
+
+
+def test_golden_shor15_final_state(ob):
+    g = GOLD["shor_15_L3_M4_a7"]
+    for literal in (True, False):
+        s = shor_state(ob, 15, 3, 4, 7, literal=literal)
+        v = s.reshape(-1, 2)
+        nz = np.nonzero(v.any(axis=1))[0]
+        assert len(nz) == g["nonzero_count"]
+        assert sorted(set(int(i) & 15 for i in nz)) == g["nonzero_low_values"]
+        assert sorted(set(int(i) >> 4 for i in nz)) == g["nonzero_L_values"]
+        for k, (re, im) in g["amplitudes"].items():
+            assert v[int(k), 0] == re and v[int(k), 1] == im, (k, v[int(k)])
+        mags = np.hypot(v[nz, 0], v[nz, 1])
+        assert np.all(mags == g["magnitude"])
+        assert ob.norm2(s, 7) == g["total_probability"]
+        pr = xtilde_probs(s, 3, 4)
+        assert {str(k): v for k, v in pr.items()} == g["x_tilde_probabilities"]
+
+
+def test_golden_shor15_L4(ob):
+    pr = xtilde_probs(shor_state(ob, 15, 4, 4, 7), 4, 4)
+    assert {str(k): v for k, v in pr.items()} == GOLD["shor_15_L4_M4_a7"]["x_tilde_probabilities"]
+
+
+def test_golden_shor21_probabilities(ob):
+    pr = xtilde_probs(shor_state(ob, 21, 5, 5, 2), 5, 5)
+    for k, want in GOLD["shor_21_L5_M5_a2"]["x_tilde_probabilities"].items():
+        assert pr[int(k)] == pytest.approx(want, rel=0, abs=2e-17), (k, pr[int(k)], want)
+
+
+def test_golden_seeded_histogram(ob):
+    """depends on the state bits, the sequential measurement sum and the GSL MT19937 stream at once"""
+    s = shor_state(ob, 15, 3, 4, 7)
+    rng = ob.Rng(12345)
+    hist = {}
+    for _ in range(500):
+        b = s.copy()
+        w = ob.read_omega(ob.measure(b, 7, rng.uniform()), 3, 4)
+        hist[str(w)] = hist.get(str(w), 0) + 1
+    assert hist == GOLD["histogram_15_L3_M4_a7_seed12345_500"]["omega_counts"]
+
+
+def test_golden_int_pow_wrap(ob):
+    for b, p, want in GOLD["int_pow"]["cases"]:
+        assert ob.ref_intpow(b, p) == want
+
+
+def test_golden_reference_overflow_behaviour(ob):
+    pr = xtilde_probs(shor_state(ob, 15, 5, 4, 7, ref_intpow=True), 5, 4)
+    for k, want in GOLD["overflow_15_L5_M4_a7"]["x_tilde_probabilities_approx"].items():
+        assert pr[int(k)] == pytest.approx(want, abs=5e-5)
+    # with exact modular powers the four-peak comb comes back
+    pr2 = xtilde_probs(shor_state(ob, 15, 5, 4, 7), 5, 4)
+    assert sorted(k for k, v in pr2.items() if v > 1e-3) == [0, 8, 16, 24]
+    s = shor_state(ob, 15, 8, 4, 7, ref_intpow=True)
+    assert ob.norm2(s, 12) == GOLD["refquirk_15_L8_M4_a7"]["total_probability"]
+
+
+def test_report_probability_conservation_and_table1(ob):
+    # Report sIV.A: |sum P - 1| <= 2.4e-15 while factoring 39 with 12 qubits
+    s = shor_state(ob, 39, 6, 6, 2)
+    # (the report does not state L, M or a for that run; same order of magnitude is what can be pinned)
+    assert abs(ob.norm2(s, 12) - 1.0) <= 4 * GOLD["report"]["max_total_probability_deviation_12_qubits"]
+    # Table I: omega uniform over {0, 1/4, 1/2, 3/4}
+    pr = xtilde_probs(shor_state(ob, 15, 3, 4, 7), 3, 4)
+    assert sorted(pr) == [0, 2, 4, 6] and all(abs(v - 0.25) < 1e-15 for v in pr.values())
+
+
+def test_cli_scenarios_period_and_factors(ob):
+    """the reference's documented runs (15 -> 5x3, 33 -> 11x3, 21 -> 3x7): every x~ the circuit can
+    emit with non-negligible probability leads, through continued fractions, to the stated period or
+    to a failure -- never to a wrong accepted period"""
+    for case in GOLD["cli_scenarios"]["cases"]:
+        C, L, M, a = case["C"], case["L"], case["M"], case["a"]
+        if L + M > 12:
+            L = 12 - M        # keep the CPU test small; the period does not depend on L
+        s = shor_state(ob, C, L, M, a)
+        pr = xtilde_probs(s, L, M)
+        good = 0.0
+        for x, p in pr.items():
+            if p < 1e-6:
+                continue
+            den = ob.cf_denominators(x / float(1 << L)) if x else []
+            found = None
+            for d in den:
+                for m in range(1, 11):
+                    if d and ob.modpow(a, m * d, C) == 1:
+                        found = m * d; break
+                if found:
+                    break
+            if found == case["period"]:
+                good += p
+            elif found is not None:
+                assert found % case["period"] == 0     # a multiple is still a period, never a non-period
+        assert good > 0.3
+        r = case["period"]
+        f = sorted([ob.gcd(ob.modpow(a, r // 2, C) + 1, C), ob.gcd(ob.modpow(a, r // 2, C) - 1, C)])
+        assert f == sorted(case["factors"])
+
+
+# ---- literal == pairwise -------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 8])
+def test_literal_equals_pairwise_hadamard(ob, n):
+    for q in range(n):
+        a = ob.random_state(n, 40 + q)
+        R = ob.LiteralRegister(n, 0); R.set_state(a); R.hadamard(q); lit = R.state().copy(); R.close()
+        R = ob.LiteralRegister(n, 0); R.set_state(a); R.spmv_hadamard(q); sp = R.state().copy(); R.close()
+        b = a.copy(); ob.hadamard(b, n, q)
+        assert np.array_equal(bits(lit), bits(b)) and np.array_equal(bits(sp), bits(b))
+
+
+@pytest.mark.parametrize("keep_zeros", [True, False])
+def test_literal_equals_pairwise_cphase(ob, keep_zeros):
+    """explicit zeros in the COO (a GSL-version detail) are numerically neutral"""
+    n = 6
+    for c in range(n):
+        for t in range(n):
+            if c == t:
+                continue
+            th = math.pi / (1 << (1 + (c + t) % 5))
+            a = ob.random_state(n, 60 + c * n + t)
+            R = ob.LiteralRegister(n, 0, keep_zeros); R.set_state(a); R.cphase(c, t, th); lit = R.state().copy(); R.close()
+            b = a.copy(); ob.cphase(b, n, c, t, th)
+            assert np.array_equal(bits(lit), bits(b))
+
+
+def test_literal_equals_pairwise_camodc(ob):
+    cases = [(3, 4, 15, 7, 4), (3, 4, 15, 49, 6), (5, 5, 21, 2, 7), (3, 4, 15, 5, 4), (3, 4, 15, 0, 5),
+             (3, 4, 15, 3, 6), (4, 3, 15, 7, 4), (4, 3, 21, 2, 5), (3, 5, 21, 2, 2), (3, 4, 15, 7, 3), (2, 6, 36, 6, 7)]
+    for L, M, C, atox, ctl in cases:
+        n = L + M
+        a = ob.random_state(n, 80 + ctl)
+        R = ob.LiteralRegister(L, M); R.set_state(a); R.camodc(C, atox, ctl); lit = R.state().copy(); R.close()
+        b = a.copy(); ob.camodc(b, n, M, C, atox, ctl)
+        assert np.array_equal(bits(lit), bits(b)), (L, M, C, atox, ctl)
+
+
+@pytest.mark.parametrize("C,L,M,a", [(15, 3, 4, 7), (15, 4, 4, 7), (21, 5, 5, 2), (33, 4, 6, 7)])
+def test_literal_equals_pairwise_full_circuit(ob, C, L, M, a):
+    assert np.array_equal(bits(shor_state(ob, C, L, M, a, literal=True)), bits(shor_state(ob, C, L, M, a)))
+
+
+def test_negative_zero_is_canonicalised_like_the_reference(ob):
+    n = 4
+    a = np.zeros(2 << n); a[::3] = -0.0; a[5] = 0.3; a[8] = -0.3
+    for q in range(n):
+        R = ob.LiteralRegister(n, 0); R.set_state(a); R.hadamard(q); lit = R.state().copy(); R.close()
+        b = a.copy(); ob.hadamard(b, n, q)
+        assert np.array_equal(bits(lit), bits(b))
+        assert not np.any(np.signbit(b) & (b == 0))
+
+
+def test_openmp_threads_do_not_change_bits(ob):
+    n = 14
+    a = ob.random_state(n, 5)
+    b1 = a.copy(); b8 = a.copy()
+    ob.quantum_computation(b1, n, 5, 21, 2, threads=1)
+    ob.quantum_computation(b8, n, 5, 21, 2, threads=4)
+    assert np.array_equal(bits(b1), bits(b8))
+
+
+# ---- MT19937 ---------------------------------------------------------------------------------
+def test_mt19937_known_answers(ob):
+    g = GOLD["mt19937"]
+    r = ob.Rng(g["seed"])
+    v = [r.get() for _ in range(10000)]
+    assert v[0] == g["first"] and v[-1] == g["ten_thousandth"]
+    assert ob.Rng(0).get() == ob.Rng(4357).get()
+
+
+def test_mt19937_matches_numpy_legacy_seeding(ob):
+    for seed in (1, 7, 12345, 4357, 2 ** 32 - 1):
+        bg = np.random.MT19937(); bg._legacy_seeding(seed)
+        r = ob.Rng(seed)
+        assert [int(x) for x in bg.random_raw(1500)] == [r.get() for _ in range(1500)]
+    r = ob.Rng(12345); bg = np.random.MT19937(); bg._legacy_seeding(12345)
+    assert r.uniform() == int(bg.random_raw(1)[0]) / 4294967296.0
+
+
+def test_measure_edges(ob):
+    n = 3
+    a = np.zeros(2 << n); a[2 * 5] = 1.0
+    assert ob.measure(a.copy(), n, 0.0) == 0            # r = 0: index 0 even though amp[0] = 0 (App. A#9)
+    assert ob.measure(a.copy(), n, 0.5) == 5
+    z = np.zeros(2 << n)
+    assert ob.measure(z, n, 0.5) == 7 and z[14] == 1.0   # never reached: falls through to the last index
+    hit, idx, cum = ob.measure_range(a[8:], 4, 4, 7, 0.0, 0.5)
+    assert hit and idx == 5 and cum == 1.0

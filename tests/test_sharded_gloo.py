@@ -1,0 +1,210 @@
+"""CPU: the multi-rank host logic of quantumcomputer_amd/sharded.py (which rank skips a gate, how a
+global target qubit is brought local by ONE all-to-all, how the measurement sum is handed from rank
+to rank) run with world_size 2 and 4 over gloo.  The local shard arithmetic is injected as an
+oracle-backed engine (tests may use the oracle as the checker; the product's only engine is HIP), and
+the gathered result has to equal the unsharded oracle bit for bit."""
+import math
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleEngine:
+    """shard-level engine interface of sharded.HipEngine on CPU tensors, backed by oracle/"""
+
+    def __init__(self):
+        from oracle import binding as ob
+        self.ob = ob
+
+    def reset(self, t, n_local, holds_one):
+        t.zero_()
+        if holds_one:
+            t[2] = 1.0
+
+    def fill_random(self, t, n_local, first_global, seed, scale):
+        import ctypes as C
+        a = t.numpy()
+        self.ob.lib().orc_fill_random(a.ctypes.data_as(C.POINTER(C.c_double)), first_global, 1 << n_local, seed, scale)
+
+    def hadamard(self, t, n_local, q):
+        self.ob.hadamard(t.numpy(), n_local, q)
+
+    def phase(self, t, n_local, mask, c, s):
+        v = t.numpy().reshape(-1, 2)
+        idx = np.arange(v.shape[0], dtype=np.int64)
+        sel = (idx & mask) == mask
+        re, im = v[sel, 0].copy(), v[sel, 1].copy()
+        v[sel, 0] = 0.0 + ((c * re) - (s * im))
+        v[sel, 1] = 0.0 + ((c * im) + (s * re))
+
+    def camodc(self, t, n_local, M, Cn, A, ctl_local):
+        if ctl_local >= 0:
+            self.ob.camodc(t.numpy(), n_local, M, Cn, A, ctl_local)
+            return
+        v = t.numpy().reshape(-1, 1 << M, 2)          # control is a rank bit that is 1: every block moves
+        new = np.zeros_like(v)
+        for f in range(1 << M):
+            d = ((A * f) % Cn) & ((1 << M) - 1) if f < Cn else f
+            new[:, d, :] += v[:, f, :]
+        v[...] = new
+
+    def norm2(self, t, n_local):
+        return self.ob.norm2(t.numpy(), n_local)
+
+    def measure_scan(self, t, n_local, first_global, last_excluded, cum_in, r):
+        return self.ob.measure_range(t.numpy(), first_global, 1 << n_local, last_excluded, cum_in, r)
+
+    def collapse(self, t, n_local, local_index):
+        t.zero_()
+        if local_index >= 0:
+            t[2 * local_index] = 1.0
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, scenario, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import binding as ob
+        from quantumcomputer_amd.sharded import ShardedRegister
+        out = scenario(rank, world, ob, lambda L, M: ShardedRegister(L, M, device="cpu", engine=OracleEngine()))
+        if rank == 0:
+            q.put(("ok", out))
+    except Exception as e:      # pragma: no cover
+        import traceback
+        q.put(("err", f"rank {rank}: {e}\n{traceback.format_exc()}"))
+    finally:
+        dist.destroy_process_group()
+
+
+def run(world, scenario):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, scenario, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    status, out = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+    assert status == "ok", out
+    return out
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+# ---- scenarios (module level: spawn pickles them by name) ----------------------------------------
+def sc_hadamard_sweep(rank, world, ob, make):
+    n = 9
+    reg = make(n, 0)
+    reg.fill_random(5)
+    want = ob.fill_random(n, 5)
+    for rep in range(2):                       # second sweep starts in the swapped layout
+        for qb in range(n):
+            reg.hadamard_gate(qb)
+            ob.hadamard(want, n, qb)
+    exchanges = reg.exchanges              # before gather() restores the identity layout
+    got = reg.gather()
+    return bool(np.array_equal(bits(got), bits(want))), exchanges
+
+
+def sc_shor(rank, world, ob, make):
+    L, M, Cn, a = 6, 4, 15, 7
+    n = L + M
+    reg = make(L, M)
+    reg.reset_register()
+    reg.quantum_computation(Cn, a)
+    want = np.zeros(2 << n); ob.reset(want, n); ob.quantum_computation(want, n, M, Cn, a)
+    nrm = reg.norm2()
+    got = reg.gather()
+    same = bool(np.array_equal(bits(got), bits(want)))
+    # seeded measurements: same index as the unsharded sequential scan, state collapses the same way
+    rng = ob.Rng(12345)
+    picks = []
+    for _ in range(6):
+        reg.reset_register(); reg.quantum_computation(Cn, a)
+        r = rng.uniform()
+        w = want.copy()
+        picks.append((reg.measure_state(r), ob.measure(w, n, r)))
+        same = same and bool(np.array_equal(bits(reg.gather()), bits(w)))
+    return same, picks, nrm, reg.exchanges
+
+
+def sc_mixed_gates_in_swapped_layout(rank, world, ob, make):
+    """controlled phases and modular multiplies whose control/target sit on global bits, issued
+    while the qubit map is swapped (right after a global Hadamard)"""
+    L, M, Cn = 6, 3, 7
+    n = L + M
+    reg = make(L, M)
+    reg.fill_random(11)
+    want = ob.fill_random(n, 11)
+    top = n - 1
+    prog = [("h", top), ("p", top, top - 1, 0.7), ("p", n - 4, top, math.pi / 8), ("c", 3, top), ("c", 5, top - 1),
+            ("h", 4), ("p", top - 2, 0, 1.1), ("h", top - 1), ("c", 2, 4), ("p", top, 1, -2.0), ("h", top - 3), ("c", 6, n - 4)]
+    for g in prog:
+        if g[0] == "h":
+            reg.hadamard_gate(g[1]); ob.hadamard(want, n, g[1])
+        elif g[0] == "p":
+            reg.c_phase_shift_gate(g[1], g[2], g[3]); ob.cphase(want, n, g[1], g[2], g[3])
+        else:
+            reg.c_amodc_gate(Cn, g[1], g[2]); ob.camodc(want, n, M, Cn, g[1], g[2])
+    return bool(np.array_equal(bits(reg.gather()), bits(want))), reg.exchanges
+
+
+def sc_measure_edges(rank, world, ob, make):
+    n = 8
+    reg = make(n, 0)
+    res = []
+    for r in (0.0, 0.3, 0.9999999, 1.0):
+        reg.fill_random(21)
+        want = ob.fill_random(n, 21)
+        res.append((reg.measure_state(r), ob.measure(want, n, r)))
+    reg.reset_register()                        # all weight on index 1: r beyond total probability -> last index
+    reg.engine.collapse(reg.shard, reg.n_local, -1)
+    res.append((reg.measure_state(0.5), (1 << n) - 1))
+    return res
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_hadamard_sweep(world):
+    same, exchanges = run(world, sc_hadamard_sweep)
+    assert same
+    assert exchanges == 3          # sweep 1: one all-to-all; sweep 2: back and forth
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_shor_circuit_and_measurement(world):
+    same, picks, nrm, exchanges = run(world, sc_shor)
+    assert same
+    assert all(g == w for g, w in picks), picks
+    assert abs(nrm - 1.0) < 1e-13
+
+
+def test_sharded_mixed_gates_world2():
+    same, exchanges = run(2, sc_mixed_gates_in_swapped_layout)
+    assert same and exchanges >= 2
+
+
+def test_sharded_mixed_gates_world4():
+    same, _ = run(4, sc_mixed_gates_in_swapped_layout)
+    assert same
+
+
+def test_sharded_measure_edges():
+    res = run(2, sc_measure_edges)
+    assert all(g == w for g, w in res), res

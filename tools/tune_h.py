@@ -14,21 +14,14 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import quantumcomputer_amd as qc  # noqa: E402
 
+def _v(variant, ppt=1, nt=3, cap=0, r=4, wc=0, blk=256, sl=0, wb=256):
+    return dict(h_variant=variant, h_ppt=ppt, h_nt=nt, h_grid_cap=cap, h_wave_r=r, h_wc=wc, h_block=blk,
+                h_streams_log2=sl, h_wave_block=wb)
+
+
 VARIANTS = {
-    "pair_p1": dict(h_variant=1, h_ppt=1, h_nt=0, h_grid_cap=0),
-    "pair_p2": dict(h_variant=1, h_ppt=2, h_nt=0, h_grid_cap=0),
-    "pair_p4": dict(h_variant=1, h_ppt=4, h_nt=0, h_grid_cap=0),
-    "pair_p8": dict(h_variant=1, h_ppt=8, h_nt=0, h_grid_cap=0),
-    "pair_p4_nt": dict(h_variant=1, h_ppt=4, h_nt=1, h_grid_cap=0),
-    "pair_p2_nt": dict(h_variant=1, h_ppt=2, h_nt=1, h_grid_cap=0),
-    "pair_p4_g2048": dict(h_variant=1, h_ppt=4, h_nt=0, h_grid_cap=2048),
-    "pair_p4_g4096": dict(h_variant=1, h_ppt=4, h_nt=0, h_grid_cap=4096),
-    "pair_p4_g8192": dict(h_variant=1, h_ppt=4, h_nt=0, h_grid_cap=8192),
-    "pair_p2_g4096": dict(h_variant=1, h_ppt=2, h_nt=0, h_grid_cap=4096),
-    "wave_r4": dict(h_variant=2, h_wave_r=4, h_nt=0, h_grid_cap=0, h_ppt=4),
-    "wave_r8": dict(h_variant=2, h_wave_r=8, h_nt=0, h_grid_cap=0, h_ppt=4),
-    "wave_r4_nt": dict(h_variant=2, h_wave_r=4, h_nt=1, h_grid_cap=0, h_ppt=4),
-    "wave_r4_g4096": dict(h_variant=2, h_wave_r=4, h_nt=0, h_grid_cap=4096, h_ppt=4),
+    "auto": dict(h_variant=0),
+    "p1_b64_s1": _v(1, blk=64, sl=1), "p1_b256_nt0": _v(1, blk=256, nt=0), "p4_b256_nt0": _v(1, ppt=4, blk=256, nt=0),
 }
 
 
@@ -54,7 +47,7 @@ def main():
             for rep in range(a.reps):
                 for k in names:
                     v = VARIANTS[k]
-                    if v["h_variant"] == 2 and q >= (9 if v.get("h_wave_r") == 8 else 8):
+                    if v["h_variant"] == 2 and q >= {8: 9, 4: 8, 2: 7}[v.get("h_wave_r", 4)]:
                         continue
                     qc.tune(**v)
                     reg.timer_start()

@@ -35,7 +35,12 @@ def cpu_baseline(n_sample, budget_s=20.0):
     """oracle (kind "port") timed on this box's host cores: H-sweep at n_sample qubits"""
     from oracle import binding as ob
     import numpy as np
-    cores = os.cpu_count() or 1
+    # threads = the CPUs this process may use, capped at the GPU box's per-GPU CPU share
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, int(os.environ.get("QCX_CPU_THREADS", "16"))))
     a = ob.fill_random(n_sample, 1)
     ob.hadamard(a, n_sample, 0, cores)                      # warm-up: page in, spin up the OpenMP team
     t0 = time.perf_counter()
@@ -57,7 +62,7 @@ def cpu_baseline(n_sample, budget_s=20.0):
             "sample": f"H on q=0..{gates - 1} of an n={n_sample} register ({gates} gates, {dt:.1f} s), oracle pairwise "
                       f"in-place form, OpenMP {cores} threads",
             "literal_reference_algorithm": {"value": float(1 << lit_n) / lit_dt, "unit": "amplitude-updates/s", "cores": 1,
-                                            "sample": f"one hadamard_gate at n={lit_n}: 4^n index-pair scan + COO mat-vec ({lit_dt:.2f} s)"}}
+                                            "sample": f"one hadamard_gate at n={lit_n}: 4^n index-pair scan + COO mat-vec ({lit_dt * 1e3:.1f} ms)"}}
 
 
 def load_traffic():

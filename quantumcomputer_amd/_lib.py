@@ -82,6 +82,28 @@ _EXTRA = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  The torch wheel bundles its own libamdhip64.so (same SONAME as
+    /opt/rocm's, different file); if libqcx.so pulled in the system copy first and torch its bundled
+    copy later, the process would hold two HSA runtimes and the second to initialise sees no device.
+    Loading torch's copy first (without importing torch) makes both resolve to that one file."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return                      # torch already loaded its runtime; libqcx.so resolves to it by SONAME
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def lib():
     """Load libqcx.so once; raise loudly if the HIP extension has not been built."""
     global _lib
@@ -90,6 +112,7 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `make -C quantumcomputer_amd/csrc` "
                 "(or __graft_entry__.build()); quantumcomputer_amd has no CPU fallback")
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in {**SIGNATURES, **_EXTRA}.items():
             fn = getattr(L, name)          # AttributeError here = header/library mismatch

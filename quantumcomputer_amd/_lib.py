@@ -77,6 +77,7 @@ _EXTRA = {
     "qcx_tune_set": (_i, [C.c_char_p, C.c_long]),
     "qcx_tune_get": (C.c_long, [C.c_char_p]),
     "qcx_ref_int_pow": (_u, [_d, _d]),
+    "qcx_measure_last_stats": (_i, [C.POINTER(_u), C.POINTER(_u)]),
 }
 
 _lib = None

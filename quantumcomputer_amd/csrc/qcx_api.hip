@@ -82,16 +82,21 @@ struct Tune {
     long h_wave_r    = 4;      // registers per lane, wave-tile form (2, 4 or 8)
     long h_wave_block = 256;   // wave-tile form: threads per block (64 or 256)
     long h_wave_maxq = 7;      // auto: use the wave-tile form for q <= this
-    long ph_apt      = 4;
-    long ph_grid_cap = 0;
+    long ph_apt      = 1;      // measured (tools/tune_phase.py): one amplitude per lane, one wave per block,
+    long ph_grid_cap = 0;      // nontemporal, 2 or 4 interleaved streams: 6.4-6.9 TB/s on the touched quarter
+    long ph_block    = 64;
+    long ph_nt       = 1;
+    long ph_streams_log2 = -1; // -1: auto (1 when the lowest mask bit >= 8, else 2)
     long cam_grid_cap = 4096;
+    long meas_parallel = 1;    // 0: always the single-wave sequential scan
+    long meas_min_log2 = 17;   // shards below 2^this amplitudes use the single-wave scan
 };
 static Tune g_tune;
 
 extern "C" int qcx_tune_set(const char *key, long value)
 {
 #define K(name) if (!strcmp(key, #name)) { g_tune.name = value; return QCX_NO_ERROR; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(cam_grid_cap)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2)
 #undef K
     return QCX_BAD_ARGUMENTS;
 }
@@ -99,7 +104,7 @@ extern "C" int qcx_tune_set(const char *key, long value)
 extern "C" long qcx_tune_get(const char *key)
 {
 #define K(name) if (!strcmp(key, #name)) return g_tune.name;
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(cam_grid_cap)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2)
 #undef K
     return -1;
 }
@@ -123,6 +128,10 @@ struct Workspace {
     double     *h_scalar = nullptr;     // pinned
     uint32_t   *tab = nullptr;          // camodc CSR table (off + srcs)
     size_t      tab_cap = 0;
+    double     *meas_sums = nullptr, *meas_prefix = nullptr;   // exact parallel measurement (K4b)
+    MeasBlock  *meas_blocks = nullptr;
+    unsigned    meas_cap = 0;
+    unsigned   *meas_stats = nullptr, *h_meas_stats = nullptr; // [slow-path blocks, blocks] of the last scan
 };
 static const unsigned NORM_BLOCKS = 2048;
 static std::mutex g_ws_mutex;
@@ -140,6 +149,9 @@ static int workspace(Workspace **out)
         HIP_TRY(hipMalloc(&w.mout, sizeof(MeasureOut)));
         HIP_TRY(hipHostMalloc(&w.h_mout, sizeof(MeasureOut)));
         HIP_TRY(hipHostMalloc(&w.h_scalar, sizeof(double)));
+        HIP_TRY(hipMalloc(&w.meas_stats, 2 * sizeof(unsigned)));
+        HIP_TRY(hipHostMalloc(&w.h_meas_stats, 2 * sizeof(unsigned)));
+        w.h_meas_stats[0] = w.h_meas_stats[1] = 0;
     }
     *out = &w;
     return QCX_NO_ERROR;
@@ -337,18 +349,34 @@ extern "C" int qcx_shard_hadamard(void *amp, unsigned n_local, unsigned q, void 
     return status;
 }
 
+template <int NB, int APT, bool NT, int BLOCK>
+static void launch_phase_cfg(amp_t *a, unsigned b0, unsigned b1, double c, double s, uint64_t count, hipStream_t st)
+{
+    const unsigned grid = grid_for(count, (uint64_t)BLOCK * APT, g_tune.ph_grid_cap);
+    unsigned glog, slog;
+    long want = g_tune.ph_streams_log2;
+    if (want < 0) want = (NB == 0 || b0 >= 8) ? 1 : 2;
+    stream_map(grid, (uint64_t)grid * BLOCK * APT, count, want, &glog, &slog);
+    hipLaunchKernelGGL((k_phase<NB, APT, NT, BLOCK>), dim3(grid), dim3(BLOCK), 0, st, a, b0, b1, c, s, count, glog, slog);
+}
+
+template <int NB, int APT, bool NT>
+static void launch_phase_blk(amp_t *a, unsigned b0, unsigned b1, double c, double s, uint64_t count, hipStream_t st)
+{
+    if (g_tune.ph_block == 64) launch_phase_cfg<NB, APT, NT, 64>(a, b0, b1, c, s, count, st);
+    else launch_phase_cfg<NB, APT, NT, 256>(a, b0, b1, c, s, count, st);
+}
+
 template <int NB>
 static void launch_phase(amp_t *a, unsigned b0, unsigned b1, double c, double s, uint64_t count, hipStream_t st)
 {
     long apt = g_tune.ph_apt;
     while (apt > 1 && count < (uint64_t)256 * (uint64_t)apt) apt >>= 1;
-    if (apt >= 4) {
-        hipLaunchKernelGGL((k_phase<NB, 4, 256>), dim3(grid_for(count, 1024, g_tune.ph_grid_cap)), dim3(256), 0, st, a, b0, b1, c, s, count);
-    } else if (apt == 2) {
-        hipLaunchKernelGGL((k_phase<NB, 2, 256>), dim3(grid_for(count, 512, g_tune.ph_grid_cap)), dim3(256), 0, st, a, b0, b1, c, s, count);
-    } else {
-        hipLaunchKernelGGL((k_phase<NB, 1, 256>), dim3(grid_for(count, 256, g_tune.ph_grid_cap)), dim3(256), 0, st, a, b0, b1, c, s, count);
-    }
+    // nontemporal only when the touched runs are whole 128-B lines (lowest mask bit >= 3, or no mask)
+    const bool nt = g_tune.ph_nt != 0 && (NB == 0 || b0 >= 3);
+    if (apt >= 4)      { if (nt) launch_phase_blk<NB, 4, true>(a, b0, b1, c, s, count, st); else launch_phase_blk<NB, 4, false>(a, b0, b1, c, s, count, st); }
+    else if (apt == 2) { if (nt) launch_phase_blk<NB, 2, true>(a, b0, b1, c, s, count, st); else launch_phase_blk<NB, 2, false>(a, b0, b1, c, s, count, st); }
+    else               { if (nt) launch_phase_blk<NB, 1, true>(a, b0, b1, c, s, count, st); else launch_phase_blk<NB, 1, false>(a, b0, b1, c, s, count, st); }
 }
 
 extern "C" int qcx_shard_phase(void *amp, unsigned n_local, uint64_t mask, double cos_t, double sin_t, void *stream)
@@ -491,13 +519,49 @@ extern "C" int qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_
     if (first_global >= last_excluded) count = 0;
     else if (last_excluded - first_global < count) count = last_excluded - first_global;
     if (count == 0) { *found = 0; *index = 0; *cum_out = cum_in; return QCX_NO_ERROR; }
-    hipLaunchKernelGGL(k_measure_scan, dim3(1), dim3(64), 0, st, (const amp_t *)amp, count, cum_in, r, w->mout);
+    const bool parallel = g_tune.meas_parallel != 0 && count >= ((uint64_t)1 << g_tune.meas_min_log2);
+    if (!parallel) {
+        // small shards: the strictly sequential single-wave scan
+        hipLaunchKernelGGL(k_measure_scan, dim3(1), dim3(64), 0, st, (const amp_t *)amp, count, cum_in, r, w->mout);
+    } else {
+        // exact parallel form (qcx_kernels.h, K4b): block binade guesses -> integer block increments -> chain
+        const uint64_t nb64 = (count + MEAS_BLOCK - 1) >> MEAS_BLOCK_LOG;
+        if (nb64 > 0x7fffffffULL) return QCX_UNSUPPORTED;
+        const unsigned nblocks = (unsigned)nb64;
+        {
+            std::lock_guard<std::mutex> lock(g_ws_mutex);
+            if (w->meas_cap < nblocks) {
+                if (w->meas_sums) { HIP_TRY(hipFree(w->meas_sums)); HIP_TRY(hipFree(w->meas_prefix)); HIP_TRY(hipFree(w->meas_blocks)); }
+                w->meas_sums = w->meas_prefix = nullptr; w->meas_blocks = nullptr; w->meas_cap = 0;
+                HIP_TRY(hipMalloc(&w->meas_sums, (size_t)nblocks * sizeof(double)));
+                HIP_TRY(hipMalloc(&w->meas_prefix, (size_t)nblocks * sizeof(double)));
+                HIP_TRY(hipMalloc(&w->meas_blocks, (size_t)nblocks * sizeof(MeasBlock)));
+                w->meas_cap = nblocks;
+            }
+        }
+        hipLaunchKernelGGL((k_meas_blocksum<256>), dim3(nblocks), dim3(256), 0, st, (const amp_t *)amp, count, w->meas_sums);
+        hipLaunchKernelGGL(k_meas_prefix, dim3(1), dim3(1024), 0, st, w->meas_sums, nblocks, cum_in, w->meas_prefix);
+        hipLaunchKernelGGL((k_meas_composite<256>), dim3(nblocks), dim3(256), 0, st, (const amp_t *)amp, count, w->meas_prefix, w->meas_blocks);
+        hipLaunchKernelGGL(k_meas_chain, dim3(1), dim3(64), 0, st, (const amp_t *)amp, count, w->meas_blocks, nblocks,
+                           cum_in, r, w->mout, w->meas_stats);
+    }
     HIP_TRY(hipGetLastError());
+    if (parallel) HIP_TRY(hipMemcpyAsync(w->h_meas_stats, w->meas_stats, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(w->h_mout, w->mout, sizeof(MeasureOut), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     *found = w->h_mout->found;
     *index = first_global + w->h_mout->index;
     *cum_out = w->h_mout->cum;
+    return QCX_NO_ERROR;
+}
+
+// diagnostics of the last parallel measurement scan on the current device: blocks redone sequentially / blocks
+extern "C" int qcx_measure_last_stats(unsigned *slow_blocks, unsigned *blocks)
+{
+    Workspace *w;
+    QCX_TRY(workspace(&w));
+    if (slow_blocks) *slow_blocks = w->h_meas_stats[0];
+    if (blocks) *blocks = w->h_meas_stats[1];
     return QCX_NO_ERROR;
 }
 

@@ -152,12 +152,14 @@ __global__ __launch_bounds__(BLOCK) void k_h_wave(amp_t *__restrict__ amp, uint6
 // K2  controlled phase: multiply by (c + i s) every amplitude whose index has
 // all NB mask bits set (b0 < b1).  Only that 1/2^NB of the vector is touched.
 // ---------------------------------------------------------------------------
-template <int NB, int APT, int BLOCK>
+template <int NB, int APT, bool NT, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_phase(amp_t *__restrict__ amp, unsigned b0, unsigned b1,
-                                                   double c, double s, uint64_t count)
+                                                   double c, double s, uint64_t count, unsigned glog, unsigned slog)
 {
     const uint64_t step = (uint64_t)gridDim.x * (BLOCK * APT);
-    for (uint64_t base = (uint64_t)blockIdx.x * (BLOCK * APT); base < count; base += step) {
+    uint64_t tile0 = blockIdx.x;              // stream-interleaved tile order as in k_h_pair
+    if (slog) tile0 = ((uint64_t)(blockIdx.x & ((1u << slog) - 1u)) << (glog - slog)) | (blockIdx.x >> slog);
+    for (uint64_t base = tile0 * (BLOCK * APT); base < count; base += step) {
         amp_t v[APT];
         uint64_t idx[APT];
 #pragma unroll
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(BLOCK) void k_phase(amp_t *__restrict__ amp, unsign
             if (NB >= 1) i = insert_zero(i, b0) | ((uint64_t)1 << b0);
             if (NB >= 2) i = insert_zero(i, b1) | ((uint64_t)1 << b1);
             idx[k] = i;
-            if (p < count) v[k] = amp[i];
+            if (p < count) v[k] = ld<NT>(amp + i);
         }
 #pragma unroll
         for (int k = 0; k < APT; k++) {
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(BLOCK) void k_phase(amp_t *__restrict__ amp, unsign
                 amp_t o;
                 o.x = ((c * v[k].x) - (s * v[k].y)) + 0.0;      // Q:409
                 o.y = ((c * v[k].y) + (s * v[k].x)) + 0.0;      // Q:412
-                amp[idx[k]] = o;
+                st<NT>(amp + idx[k], o);
             }
         }
     }
@@ -376,6 +378,205 @@ __global__ __launch_bounds__(64) void k_measure_scan(const amp_t *__restrict__ a
         cum = readlane_f64(run, 63);
     }
     if (lane == 0) { out->found = 0; out->index = 0; out->cum = cum; }
+}
+
+// ---------------------------------------------------------------------------
+// K4b  measurement scan, exact AND parallel.
+//
+// The reference's cumulative sum cum_i = fl(cum_{i-1} + p_i) is order dependent, so a parallel
+// prefix sum does not give the same decisions.  But while the running sum stays inside one binade
+// [2^e, 2^(e+1)) it is an integer K (53 bits) times the fixed ulp u = 2^(e-52), and adding p >= 0
+// rounds to   K + floor(p/u) + [frac(p/u) > 1/2]        (a tie, frac == 1/2, rounds to even).
+// So for a block of MEAS_BLOCK amplitudes with no tie and no element >= 2^e, the sequential sum
+// over the block is exactly K + S with S = sum_i (floor(p_i/u) + [frac > 1/2]) -- an ORDINARY
+// integer sum -- provided K + S < 2^53 (no binade crossing).  Pipeline:
+//   1. k_meas_blocksum / k_meas_prefix : approximate (tree) block sums and their exclusive prefix,
+//      only used to guess the binade e_b in which each block starts;
+//   2. k_meas_composite                 : per block, S under that binade, plus flags
+//      (all-zero, tie seen, element too large, binade unknown);
+//   3. k_meas_chain (one wave)          : walks the blocks in order with the EXACT running sum;
+//      a block whose guess holds costs a few integer operations, any other block (binade crossing,
+//      wrong guess, tie, start of the sum, the block in which cum reaches r) is redone with the
+//      strictly sequential wave scan of k_measure_scan.  The result is the reference's index,
+//      bit for bit, for every input; only the speed depends on the data.
+// ---------------------------------------------------------------------------
+constexpr int MEAS_BLOCK_LOG = 13;
+constexpr unsigned MEAS_BLOCK = 1u << MEAS_BLOCK_LOG;          // amplitudes per block
+enum : uint32_t { MEAS_ALLZERO = 1u << 16, MEAS_TIE = 1u << 17, MEAS_BIG = 1u << 18, MEAS_EUNK = 1u << 19 };
+
+struct MeasBlock {
+    uint64_t S;        // integer increment of the block in units of the assumed ulp (saturated)
+    uint32_t meta;     // low 11 bits: assumed biased exponent of the running sum at block start; flags above
+    uint32_t pad;
+};
+
+__device__ __forceinline__ double prob_of(amp_t v) { return v.x * v.x + v.y * v.y; }    // gsl_complex_abs2
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_meas_blocksum(const amp_t *__restrict__ amp, uint64_t count, double *sums)
+{
+    __shared__ double red[BLOCK / 64];
+    const uint64_t base = (uint64_t)blockIdx.x << MEAS_BLOCK_LOG;
+    double acc = 0.0;
+#pragma unroll 4
+    for (unsigned j = threadIdx.x; j < MEAS_BLOCK; j += BLOCK) {
+        const uint64_t i = base + j;
+        if (i < count) acc += prob_of(__builtin_nontemporal_load(amp + i));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < BLOCK / 64; w++) t += red[w];
+        sums[blockIdx.x] = t;
+    }
+}
+
+// exclusive prefix of the block sums starting from `base` (one workgroup of 1024 threads)
+__global__ __launch_bounds__(1024) void k_meas_prefix(const double *__restrict__ sums, unsigned nblocks, double base, double *prefix)
+{
+    __shared__ double part[1024];
+    const unsigned per = (nblocks + 1023u) / 1024u;
+    const unsigned lo = threadIdx.x * per, hi = min(lo + per, nblocks);
+    double t = 0.0;
+    for (unsigned b = lo; b < hi; b++) t += sums[b];
+    part[threadIdx.x] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double run = base;
+        for (unsigned k = 0; k < 1024; k++) { const double v = part[k]; part[k] = run; run += v; }
+    }
+    __syncthreads();
+    double run = part[threadIdx.x];
+    for (unsigned b = lo; b < hi; b++) { prefix[b] = run; run += sums[b]; }
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_meas_composite(const amp_t *__restrict__ amp, uint64_t count,
+                                                            const double *__restrict__ prefix, MeasBlock *out)
+{
+    __shared__ uint64_t redS[BLOCK / 64];
+    __shared__ uint32_t redF[BLOCK / 64];
+    const uint64_t base = (uint64_t)blockIdx.x << MEAS_BLOCK_LOG;
+    const uint64_t pbits = (uint64_t)__double_as_longlong(prefix[blockIdx.x]);
+    const int e = (int)((pbits >> 52) & 0x7ff);                  // biased exponent of the assumed start value
+    uint64_t S = 0;
+    uint32_t flags = (e == 0 || e == 0x7ff) ? (uint32_t)MEAS_EUNK : 0u;
+    bool nonzero = false;
+    const uint64_t SAT = (uint64_t)1 << 54;
+#pragma unroll 4
+    for (unsigned j = threadIdx.x; j < MEAS_BLOCK; j += BLOCK) {
+        const uint64_t i = base + j;
+        if (i >= count) continue;
+        const uint64_t b = (uint64_t)__double_as_longlong(prob_of(__builtin_nontemporal_load(amp + i)));
+        if (b == 0) continue;                                    // p = +0 (p is never negative)
+        nonzero = true;
+        int ep = (int)((b >> 52) & 0x7ff);
+        uint64_t mp = b & 0xfffffffffffffULL;
+        if (ep == 0) ep = 1; else mp |= (uint64_t)1 << 52;       // subnormal: no implicit bit
+        const int sh = e - ep;                                   // p/u = mp * 2^-sh
+        uint64_t inc;
+        if (sh <= 0) { flags |= MEAS_BIG; inc = SAT; }
+        else if (sh >= 54) inc = 0;
+        else if (sh == 53) { inc = (mp == ((uint64_t)1 << 52)) ? 0 : 1; if (mp == ((uint64_t)1 << 52)) flags |= MEAS_TIE; }
+        else {
+            const uint64_t rem = mp & (((uint64_t)1 << sh) - 1), half = (uint64_t)1 << (sh - 1);
+            inc = (mp >> sh) + (rem > half ? 1 : 0);
+            if (rem == half) flags |= MEAS_TIE;
+        }
+        S += inc;
+        if (S > SAT) S = SAT;
+    }
+    const unsigned long long any_nz = __ballot(nonzero);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        S += (uint64_t)__shfl_down((unsigned long long)S, o, 64);
+        flags |= (uint32_t)__shfl_down((int)flags, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { redS[threadIdx.x >> 6] = S; redF[threadIdx.x >> 6] = flags | (any_nz ? 0x80000000u : 0u); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0; uint32_t f = 0;
+        for (int w = 0; w < BLOCK / 64; w++) { t += redS[w]; f |= redF[w]; }
+        if (!(f & 0x80000000u)) f |= MEAS_ALLZERO;
+        MeasBlock mb; mb.S = t; mb.meta = (uint32_t)e | (f & 0x7fff0000u); mb.pad = 0;
+        out[blockIdx.x] = mb;
+    }
+}
+
+// exact sequential scan of amplitudes [first, first+len) continuing from cum (whole wave, uniform
+// result): returns true and sets *hit_index when the running sum reaches r
+__device__ __forceinline__ bool wave_exact_scan(const amp_t *__restrict__ amp, uint64_t first, uint64_t len,
+                                                double &cum, double r, uint64_t *hit_index, double *hit_cum)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    for (uint64_t base = 0; base < len; base += 64) {
+        double p = 0.0;
+        if (base + lane < len) p = prob_of(amp[first + base + lane]);
+        double run = cum;
+#pragma unroll
+        for (int j = 0; j < 64; j++) {
+            const double pj = readlane_f64(p, j);
+            run = run + ((int)lane >= j ? pj : 0.0);
+        }
+        const bool hit = (base + lane < len) && (run >= r);
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+            const int firstl = __builtin_ctzll(m);
+            *hit_index = first + base + (uint64_t)firstl;
+            *hit_cum = readlane_f64(run, firstl);
+            return true;
+        }
+        cum = readlane_f64(run, 63);
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(64) void k_meas_chain(const amp_t *__restrict__ amp, uint64_t count,
+                                                   const MeasBlock *__restrict__ blocks, unsigned nblocks,
+                                                   double cum_in, double r, MeasureOut *out, unsigned *stats)
+{
+    const unsigned lane = threadIdx.x;
+    double cum = cum_in;
+    unsigned slow = 0;
+    // r already reached before the first addition (r <= 0, Q:289 with cum_0 >= cum_in): the first
+    // examined element is the answer -- let the sequential scan of block 0 report it
+    const bool force = (cum_in >= r);
+    for (unsigned b0 = 0; b0 < nblocks; b0 += 64) {
+        MeasBlock mine; mine.S = 0; mine.meta = MEAS_ALLZERO; mine.pad = 0;
+        if (b0 + lane < nblocks) mine = blocks[b0 + lane];
+        const unsigned lim = min(64u, nblocks - b0);
+        for (unsigned j = 0; j < lim; j++) {
+            const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)mine.meta, j);
+            if ((meta & MEAS_ALLZERO) && !force) continue;
+            const uint64_t S = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(mine.S >> 32), j) << 32) |
+                               (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(mine.S & 0xffffffffu), j);
+            const uint64_t cb = (uint64_t)__double_as_longlong(cum);
+            const int ec = (int)((cb >> 52) & 0x7ff);
+            bool fast = false;
+            if (!force && !(meta & (MEAS_ALLZERO | MEAS_TIE | MEAS_BIG | MEAS_EUNK)) && ec != 0 && ec == (int)(meta & 0x7ff)) {
+                const uint64_t K = (cb & 0xfffffffffffffULL) | ((uint64_t)1 << 52);
+                const uint64_t Kn = K + S;
+                if (Kn < ((uint64_t)1 << 53)) {
+                    const double cn = __longlong_as_double((long long)(((uint64_t)ec << 52) | (Kn & 0xfffffffffffffULL)));
+                    if (!(cn >= r)) { cum = cn; fast = true; }
+                }
+            }
+            if (!fast) {
+                slow++;
+                const uint64_t first = (uint64_t)(b0 + j) << MEAS_BLOCK_LOG;
+                const uint64_t len = min((uint64_t)MEAS_BLOCK, count - first);
+                uint64_t hi = 0; double hc = 0.0;
+                if (wave_exact_scan(amp, first, len, cum, r, &hi, &hc)) {
+                    if (lane == 0) { out->found = 1; out->index = hi; out->cum = hc; if (stats) { stats[0] = slow; stats[1] = nblocks; } }
+                    return;
+                }
+            }
+        }
+    }
+    if (lane == 0) { out->found = 0; out->index = 0; out->cum = cum; if (stats) { stats[0] = slow; stats[1] = nblocks; } }
 }
 
 }  // namespace qcx

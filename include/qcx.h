@@ -83,6 +83,14 @@ int  qcx_inverse_QFT(qcx_register *reg);                                        
  * reference's 32-bit INT_POW(a, x) including its wrap (Q:158-159, Q:729) */
 int  qcx_quantum_computation(unsigned C, unsigned a, int intpow_mode, qcx_register *reg); /* Q:712-737 */
 
+/* ---- gate fusion (no reference counterpart) ------------
+ * enable = 1: gate calls are queued and executed as fused passes (one HBM round trip applies many
+ * gates to LDS-resident tiles).  Results are bit-identical to the per-gate kernels.  Every call that
+ * observes the state flushes the queue; qcx_flush does so explicitly. */
+int  qcx_set_fusion(qcx_register *reg, int enable);
+int  qcx_flush(qcx_register *reg);
+int  qcx_fusion_stats(qcx_register *reg, unsigned long *passes_launched, unsigned long *gates_fused);
+
 /* ---- measurement: Q:272-306 ----------------------------------------------- */
 int  qcx_measure_state(qcx_register *reg, qcx_rng *rng, unsigned long *state_num);
 int  qcx_measure_state_r(qcx_register *reg, double r, unsigned long *state_num);   /* r supplied */

@@ -45,6 +45,9 @@ SIGNATURES = {
     "qcx_swap_states": (_i, [_p]),
     "qcx_inverse_QFT": (_i, [_p]),
     "qcx_quantum_computation": (_i, [_u, _u, _i, _p]),
+    "qcx_set_fusion": (_i, [_p, _i]),
+    "qcx_flush": (_i, [_p]),
+    "qcx_fusion_stats": (_i, [_p, C.POINTER(_ul), C.POINTER(_ul)]),
     "qcx_measure_state": (_i, [_p, _p, C.POINTER(_ul)]),
     "qcx_measure_state_r": (_i, [_p, _d, C.POINTER(_ul)]),
     "qcx_state_read": (_i, [_p, _ul, _ul, _p]),

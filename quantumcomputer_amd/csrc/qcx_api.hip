@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -88,6 +89,13 @@ struct Tune {
     long ph_nt       = 1;
     long ph_streams_log2 = -1; // -1: auto (1 when the lowest mask bit >= 8, else 2)
     long cam_grid_cap = 4096;
+    long fuse_T      = 11;     // fused passes: tile = 2^T amplitudes in LDS (8..12)
+    long fuse_c      = 4;      // fused passes: contiguous low bits of a tile (runs of 16 * 2^c bytes)
+    long fuse_grid_cap = 0;
+    long fuse_pipe   = 1;      // fused passes: persistent double-buffered form (fill of tile i+1 under tile i)
+    long fuse_pipe_grid = 512; // workgroups of the persistent form
+    long fuse_ldsdma = 1;      // fused passes: fill the tile with global_load_lds (LDS-DMA)
+    long fuse_max_queue = 4096;
     long meas_parallel = 1;    // 0: always the single-wave sequential scan
     long meas_min_log2 = 17;   // shards below 2^this amplitudes use the single-wave scan
 };
@@ -96,7 +104,7 @@ static Tune g_tune;
 extern "C" int qcx_tune_set(const char *key, long value)
 {
 #define K(name) if (!strcmp(key, #name)) { g_tune.name = value; return QCX_NO_ERROR; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_pipe) K(fuse_pipe_grid)
 #undef K
     return QCX_BAD_ARGUMENTS;
 }
@@ -104,7 +112,7 @@ extern "C" int qcx_tune_set(const char *key, long value)
 extern "C" long qcx_tune_get(const char *key)
 {
 #define K(name) if (!strcmp(key, #name)) return g_tune.name;
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_pipe) K(fuse_pipe_grid)
 #undef K
     return -1;
 }
@@ -577,7 +585,13 @@ struct qcx_register {
     hipEvent_t ev0, ev1;
     hipEvent_t *events;
     unsigned   n_events;
+    int        fusion;          // 1: gate calls are queued and executed as fused passes (qcx_fuse.inc.h)
+    struct GateQueue *queue;
 };
+
+#include "qcx_fuse.inc.h"
+
+#define FLUSH(r) QCX_TRY(fuse_flush(r))
 
 extern "C" int qcx_register_create(int L, int M, qcx_register **out)
 {
@@ -605,7 +619,9 @@ extern "C" int qcx_register_create(int L, int M, qcx_register **out)
 extern "C" int qcx_register_destroy(qcx_register *r)
 {
     if (!r) return QCX_NO_ERROR;
+    (void)fuse_flush(r);
     (void)hipStreamSynchronize(r->stream);
+    queue_free(r->queue);
     (void)hipEventDestroy(r->ev0); (void)hipEventDestroy(r->ev1);
     for (unsigned i = 0; i < r->n_events; i++) (void)hipEventDestroy(r->events[i]);
     free(r->events);
@@ -619,11 +635,37 @@ extern "C" unsigned qcx_num_qubits(const qcx_register *r) { return r ? r->n : 0;
 extern "C" unsigned long qcx_num_states(const qcx_register *r) { return r ? (unsigned long)r->dim : 0; }
 extern "C" int qcx_L_size(const qcx_register *r) { return r ? r->L : 0; }
 extern "C" int qcx_M_size(const qcx_register *r) { return r ? r->M : 0; }
-extern "C" void *qcx_device_pointer(qcx_register *r) { return r ? (void *)r->amp : nullptr; }
+extern "C" void *qcx_device_pointer(qcx_register *r) { if (r) (void)fuse_flush(r); return r ? (void *)r->amp : nullptr; }
+
+// gate fusion: 1 = queue gates and run them as fused LDS-tile passes; results are
+// bit-identical to the per-gate kernels.  Observing calls (read, norm, measure, synchronize, timers) flush.
+extern "C" int qcx_set_fusion(qcx_register *r, int enable)
+{
+    if (!r) return QCX_BAD_ARGUMENTS;
+    FLUSH(r);
+    r->fusion = enable ? 1 : 0;
+    return QCX_NO_ERROR;
+}
+
+extern "C" int qcx_flush(qcx_register *r)
+{
+    if (!r) return QCX_BAD_ARGUMENTS;
+    FLUSH(r);
+    return QCX_NO_ERROR;
+}
+
+extern "C" int qcx_fusion_stats(qcx_register *r, unsigned long *passes, unsigned long *gates)
+{
+    if (!r) return QCX_BAD_ARGUMENTS;
+    if (passes) *passes = r->queue ? r->queue->passes_launched : 0;
+    if (gates) *gates = r->queue ? r->queue->gates_fused : 0;
+    return QCX_NO_ERROR;
+}
 
 extern "C" int qcx_register_set_stream(qcx_register *r, void *hip_stream)
 {
     if (!r) return QCX_BAD_ARGUMENTS;
+    FLUSH(r);
     HIP_TRY(hipStreamSynchronize(r->stream));
     r->stream = hip_stream ? (hipStream_t)hip_stream : r->own_stream;
     return QCX_NO_ERROR;
@@ -632,6 +674,7 @@ extern "C" int qcx_register_set_stream(qcx_register *r, void *hip_stream)
 extern "C" int qcx_synchronize(qcx_register *r)
 {
     if (!r) return QCX_BAD_ARGUMENTS;
+    FLUSH(r);
     HIP_TRY(hipStreamSynchronize(r->stream));
     return QCX_NO_ERROR;
 }
@@ -639,6 +682,7 @@ extern "C" int qcx_synchronize(qcx_register *r)
 extern "C" int qcx_reset_register(qcx_register *r)
 {
     if (!r) return QCX_BAD_ARGUMENTS;
+    if (r->queue) r->queue->gates.clear();         // pending gates act on a state that is being overwritten
     return qcx_shard_reset(r->amp, r->n, 1, r->stream);
 }
 
@@ -646,6 +690,7 @@ extern "C" int qcx_hadamard_gate(unsigned q, qcx_register *r)
 {
     if (!r) return QCX_BAD_ARGUMENTS;
     if (q >= r->n) return QCX_BAD_QUBIT;
+    if (r->fusion) { QGate g; memset(&g, 0, sizeof g); g.type = FUSE_H; g.q = q; return fuse_push(r, g); }
     return qcx_shard_hadamard(r->amp, r->n, q, r->stream);
 }
 
@@ -655,6 +700,11 @@ extern "C" int qcx_c_phase_shift_gate(unsigned c, unsigned t, double theta, qcx_
     if (c >= r->n || t >= r->n || c == t) return QCX_BAD_QUBIT;
     // gsl_complex_polar(1.0, theta) (Q:526): host libm, so the oracle sees the same two doubles
     const double er = 1.0 * cos(theta), ei = 1.0 * sin(theta);
+    if (r->fusion) {
+        QGate g; memset(&g, 0, sizeof g);
+        g.type = FUSE_PHASE; g.mask = ((uint64_t)1 << c) | ((uint64_t)1 << t); g.c = er; g.s = ei;
+        return fuse_push(r, g);
+    }
     return qcx_shard_phase(r->amp, r->n, ((uint64_t)1 << c) | ((uint64_t)1 << t), er, ei, r->stream);
 }
 
@@ -662,6 +712,13 @@ extern "C" int qcx_c_amodc_gate(unsigned C, unsigned long long atox, unsigned c,
 {
     if (!r || C == 0) return QCX_BAD_ARGUMENTS;
     if (c >= r->n) return QCX_BAD_QUBIT;
+    if (r->fusion) {
+        if ((unsigned)r->M > 12) return QCX_UNSUPPORTED;
+        QGate g; memset(&g, 0, sizeof g);
+        g.q = c; g.C = C; g.A = (unsigned)(atox % C);
+        g.type = camodc_closed_form(r->n, (unsigned)r->M, C, g.A, c) ? (uint32_t)FUSE_CAMODC : 99u;
+        return fuse_push(r, g);
+    }
     return qcx_shard_camodc(r->amp, r->n, (unsigned)r->M, C, (unsigned)(atox % C), (int)c, r->stream);
 }
 
@@ -708,6 +765,7 @@ extern "C" int qcx_quantum_computation(unsigned C, unsigned a, int intpow_mode, 
 extern "C" int qcx_measure_state_r(qcx_register *r, double rnd, unsigned long *state_num)
 {
     if (!r || !state_num) return QCX_BAD_ARGUMENTS;
+    FLUSH(r);
     int found = 0; uint64_t idx = 0; double cum = 0.0;
     QCX_TRY(qcx_shard_measure_scan(r->amp, r->n, 0, r->dim - 1, 0.0, rnd, &found, &idx, &cum, r->stream));
     if (!found) idx = r->dim - 1;                                           // Q:283 fall-through
@@ -726,6 +784,7 @@ extern "C" int qcx_state_read(qcx_register *r, unsigned long first, unsigned lon
 {
     if (!r || (!out && count)) return QCX_BAD_ARGUMENTS;
     if ((uint64_t)first > r->dim || (uint64_t)count > r->dim - first) return QCX_BAD_ARGUMENTS;
+    FLUSH(r);
     HIP_TRY(hipStreamSynchronize(r->stream));
     if (count) HIP_TRY(hipMemcpy(out, r->amp + first, (size_t)count * sizeof(amp_t), hipMemcpyDeviceToHost));
     return QCX_NO_ERROR;
@@ -735,6 +794,7 @@ extern "C" int qcx_state_write(qcx_register *r, unsigned long first, unsigned lo
 {
     if (!r || (!in && count)) return QCX_BAD_ARGUMENTS;
     if ((uint64_t)first > r->dim || (uint64_t)count > r->dim - first) return QCX_BAD_ARGUMENTS;
+    FLUSH(r);
     HIP_TRY(hipStreamSynchronize(r->stream));
     if (count) HIP_TRY(hipMemcpy(r->amp + first, in, (size_t)count * sizeof(amp_t), hipMemcpyHostToDevice));
     return QCX_NO_ERROR;
@@ -743,12 +803,14 @@ extern "C" int qcx_state_write(qcx_register *r, unsigned long first, unsigned lo
 extern "C" int qcx_norm2(qcx_register *r, double *out)
 {
     if (!r || !out) return QCX_BAD_ARGUMENTS;
+    FLUSH(r);
     return qcx_shard_norm2(r->amp, r->n, out, r->stream);
 }
 
 extern "C" int qcx_state_fill_random(qcx_register *r, uint64_t seed)
 {
     if (!r) return QCX_BAD_ARGUMENTS;
+    if (r->queue) r->queue->gates.clear();
     // U(-0.5, 0.5) components have variance 1/12: this scale makes the expected norm 1
     return qcx_shard_fill_random(r->amp, r->n, 0, seed, sqrt(6.0 / (double)r->dim), r->stream);
 }
@@ -771,6 +833,7 @@ extern "C" int qcx_events_create(qcx_register *r, unsigned count)
 extern "C" int qcx_event_record(qcx_register *r, unsigned slot)
 {
     if (!r || slot >= r->n_events) return QCX_BAD_ARGUMENTS;
+    FLUSH(r);
     HIP_TRY(hipEventRecord(r->events[slot], r->stream));
     return QCX_NO_ERROR;
 }
@@ -788,6 +851,7 @@ extern "C" int qcx_event_elapsed(qcx_register *r, unsigned from_slot, unsigned t
 extern "C" int qcx_timer_start(qcx_register *r)
 {
     if (!r) return QCX_BAD_ARGUMENTS;
+    FLUSH(r);
     HIP_TRY(hipEventRecord(r->ev0, r->stream));
     return QCX_NO_ERROR;
 }
@@ -795,6 +859,7 @@ extern "C" int qcx_timer_start(qcx_register *r)
 extern "C" int qcx_timer_stop(qcx_register *r, double *ms)
 {
     if (!r || !ms) return QCX_BAD_ARGUMENTS;
+    FLUSH(r);
     HIP_TRY(hipEventRecord(r->ev1, r->stream));
     HIP_TRY(hipEventSynchronize(r->ev1));
     float f = 0.f;

@@ -1,0 +1,204 @@
+// qcx_fuse.inc.h -- lazy gate queue and pass scheduler for the fused tile kernel (k_fused).
+// Included into qcx_api.hip (single translation unit) after struct qcx_register.
+//
+// With fusion enabled (qcx_set_fusion) the gate entry points only append to a queue.  Anything that
+// observes the state (read, norm, measure, synchronize, timers) flushes it: the queue is cut greedily
+// into PASSES, each one launch of k_fused over tiles of 2^T amplitudes = the c lowest index bits plus
+// up to T - c "hot" higher bits.  A gate joins the current pass if the bits it needs inside the tile
+// (the target of an H; the M register of a modular multiply) still fit; controlled phases are
+// diagonal and always join.  Gates keep their issue order inside a pass, and each performs the same
+// arithmetic as its stand-alone kernel, so fused and unfused results are bit-identical.
+
+struct QGate {
+    uint32_t type;            // FUSE_H / FUSE_PHASE / FUSE_CAMODC, or 99 = C_AMODC that must run stand-alone
+    unsigned q;               // H: target.  CAMODC: control qubit
+    uint64_t mask;            // PHASE: control|target mask
+    double   c, s;            // PHASE
+    unsigned C, A;            // CAMODC
+};
+
+struct GateQueue {
+    std::vector<QGate> gates;
+    FuseOp  *d_ops = nullptr;       // device copy of the ops of the passes in flight
+    size_t   d_cap = 0;
+    FuseOp  *h_ops = nullptr;       // pinned staging
+    size_t   h_cap = 0;
+    unsigned long passes_launched = 0, gates_fused = 0;
+};
+
+static void queue_free(GateQueue *gq)
+{
+    if (!gq) return;
+    if (gq->d_ops) (void)hipFree(gq->d_ops);
+    if (gq->h_ops) (void)hipHostFree(gq->h_ops);
+    delete gq;
+}
+
+static bool camodc_closed_form(unsigned n, unsigned M, unsigned C, unsigned A, unsigned ctl)
+{
+    (void)A;
+    if (M > n || ctl < M || C == 0) return false;
+    const uint64_t blk = (uint64_t)1 << M;
+    if (C > blk) return false;
+    return (uint64_t)(C - 1) * (uint64_t)(C - 1) <= 0xffffffffULL;
+}
+
+struct PassPlan {
+    std::vector<unsigned> hbits;    // hot bits >= c, kept sorted
+    size_t first, last;             // gate range [first, last)
+};
+
+static int fuse_flush(qcx_register *r)
+{
+    GateQueue *gq = r->queue;
+    if (!gq || gq->gates.empty()) return QCX_NO_ERROR;
+    const unsigned n = r->n;
+    unsigned T = (unsigned)g_tune.fuse_T, c = (unsigned)g_tune.fuse_c;
+    if (T > 12) T = 12;
+    if (T < 1) T = 1;
+    if (T > n) T = n;
+    if (c > T) c = T;
+    const unsigned budget = T - c;
+
+    std::vector<QGate> gates;
+    gates.swap(gq->gates);                       // the queue is empty from here on (re-entrancy safe)
+
+    size_t i = 0;
+    while (i < gates.size()) {
+        if (gates[i].type == 99) {
+            // stand-alone launch (table-form modular multiply)
+            const QGate &g = gates[i];
+            int s = QCX_NO_ERROR;
+            if (g.type == FUSE_H) s = qcx_shard_hadamard(r->amp, n, g.q, r->stream);
+            else if (g.type == FUSE_PHASE) s = qcx_shard_phase(r->amp, n, g.mask, g.c, g.s, r->stream);
+            else s = qcx_shard_camodc(r->amp, n, (unsigned)r->M, g.C, g.A, (int)g.q, r->stream);
+            if (s != QCX_NO_ERROR) return s;
+            i++;
+            continue;
+        }
+        // ---- grow one pass ------------------------------------------------------------------
+        PassPlan pl;
+        pl.first = i;
+        auto need_of = [&](const QGate &g, std::vector<unsigned> &need) {
+            need.clear();
+            if (g.type == FUSE_H) { if (g.q >= c) need.push_back(g.q); }
+            else if (g.type == FUSE_CAMODC) { for (unsigned b = c; b < (unsigned)r->M; b++) need.push_back(b); }
+        };
+        std::vector<unsigned> need;
+        while (i < gates.size() && gates[i].type != 99) {
+            need_of(gates[i], need);
+            std::vector<unsigned> merged = pl.hbits;
+            for (unsigned b : need) if (std::find(merged.begin(), merged.end(), b) == merged.end()) merged.push_back(b);
+            if (merged.size() > budget) break;
+            pl.hbits.swap(merged);
+            i++;
+        }
+        pl.last = i;
+        if (pl.last == pl.first) {               // a single gate that does not fit the tile budget: stand-alone
+            const QGate &g = gates[i];
+            int s = (g.type == FUSE_H) ? qcx_shard_hadamard(r->amp, n, g.q, r->stream)
+                                       : qcx_shard_camodc(r->amp, n, (unsigned)r->M, g.C, g.A, (int)g.q, r->stream);
+            if (s != QCX_NO_ERROR) return s;
+            i++;
+            continue;
+        }
+        // one gate alone gains nothing from staging: use its tuned stand-alone kernel
+        if (pl.last - pl.first == 1) {
+            const QGate &g = gates[pl.first];
+            int s;
+            if (g.type == FUSE_H) s = qcx_shard_hadamard(r->amp, n, g.q, r->stream);
+            else if (g.type == FUSE_PHASE) s = qcx_shard_phase(r->amp, n, g.mask, g.c, g.s, r->stream);
+            else s = qcx_shard_camodc(r->amp, n, (unsigned)r->M, g.C, g.A, (int)g.q, r->stream);
+            if (s != QCX_NO_ERROR) return s;
+            continue;
+        }
+        // pad the tile with the lowest free bits (longer contiguous runs) up to T bits
+        std::sort(pl.hbits.begin(), pl.hbits.end());
+        for (unsigned b = c; pl.hbits.size() < budget && b < n; b++)
+            if (std::find(pl.hbits.begin(), pl.hbits.end(), b) == pl.hbits.end()) pl.hbits.push_back(b);
+        std::sort(pl.hbits.begin(), pl.hbits.end());
+
+        FusePass P;
+        memset(&P, 0, sizeof P);
+        P.c = c; P.nh = (uint32_t)pl.hbits.size(); P.T = c + P.nh;
+        for (unsigned j = 0; j < P.nh; j++) P.hbit[j] = (uint8_t)pl.hbits[j];
+        P.nops = (uint32_t)(pl.last - pl.first);
+
+        const size_t nops = pl.last - pl.first;
+        if (gq->h_cap < nops) {
+            if (gq->h_ops) HIP_TRY(hipHostFree(gq->h_ops));
+            gq->h_ops = nullptr; gq->h_cap = 0;
+            HIP_TRY(hipHostMalloc(&gq->h_ops, nops * sizeof(FuseOp)));
+            gq->h_cap = nops;
+        }
+        if (gq->d_cap < nops) {
+            HIP_TRY(hipStreamSynchronize(r->stream));
+            if (gq->d_ops) HIP_TRY(hipFree(gq->d_ops));
+            gq->d_ops = nullptr; gq->d_cap = 0;
+            HIP_TRY(hipMalloc(&gq->d_ops, nops * sizeof(FuseOp)));
+            gq->d_cap = nops;
+        }
+        // the previous pass may still be reading d_ops/h_ops: passes are rare and long, a stream sync is cheap
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        for (size_t k = 0; k < nops; k++) {
+            const QGate &g = gates[pl.first + k];
+            FuseOp &o = gq->h_ops[k];
+            memset(&o, 0, sizeof o);
+            o.type = g.type;
+            if (g.type == FUSE_H) {
+                o.a = g.q;
+                if (g.q >= c) o.a = c + (unsigned)(std::find(pl.hbits.begin(), pl.hbits.end(), g.q) - pl.hbits.begin());
+            } else if (g.type == FUSE_PHASE) {
+                // split the control|target mask into tile-local bits (vector test) and outside bits (scalar test)
+                uint32_t mloc = 0; uint64_t mext = 0;
+                for (unsigned b = 0; b < n; b++) {
+                    if (!((g.mask >> b) & 1)) continue;
+                    if (b < c) mloc |= 1u << b;
+                    else {
+                        auto it = std::find(pl.hbits.begin(), pl.hbits.end(), b);
+                        if (it != pl.hbits.end()) mloc |= 1u << (c + (unsigned)(it - pl.hbits.begin()));
+                        else mext |= (uint64_t)1 << b;
+                    }
+                }
+                o.a = mloc; o.mask = mext; o.c = g.c; o.s = g.s;
+            } else {
+                o.a = (unsigned)r->M;
+                o.mask = (uint64_t)1 << g.q;
+                FuseCamExtra X;
+                X.C = g.C; X.d = gcd_u32(g.A, g.C); X.Cd = g.C / X.d; X.inv = modinv_u32(g.A / X.d, X.Cd);
+                memcpy(&o.c, &X, sizeof X);
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(gq->d_ops, gq->h_ops, nops * sizeof(FuseOp), hipMemcpyHostToDevice, r->stream));
+        const uint64_t ntiles = (uint64_t)1 << (n - P.T);
+        const unsigned grid = grid_for(ntiles, 1, g_tune.fuse_grid_cap);
+        const size_t lds = (size_t)16 << P.T;
+        // 4 amplitudes per thread (all loads of a tile in flight at once, few registers): block = 2^T / 4
+#define QCX_FUSE_LAUNCH(B, TTv) do { \
+            if (g_tune.fuse_pipe && ntiles >= 4096) { \
+                const unsigned pg = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)g_tune.fuse_pipe_grid); \
+                hipLaunchKernelGGL((k_fused_pipe<B, TTv>), dim3(pg), dim3(B), 2 * lds, r->stream, r->amp, n, P, gq->d_ops, ntiles); \
+            } else if (g_tune.fuse_ldsdma) hipLaunchKernelGGL((k_fused<B, TTv, true>), dim3(grid), dim3(B), lds, r->stream, r->amp, n, P, gq->d_ops, ntiles); \
+            else hipLaunchKernelGGL((k_fused<B, TTv, false>), dim3(grid), dim3(B), lds, r->stream, r->amp, n, P, gq->d_ops, ntiles); } while (0)
+        switch (P.T) {
+        case 12: QCX_FUSE_LAUNCH(1024, 12); break;
+        case 11: QCX_FUSE_LAUNCH(512, 11); break;
+        case 10: QCX_FUSE_LAUNCH(256, 10); break;
+        case 9:  QCX_FUSE_LAUNCH(256, 9); break;
+        default: hipLaunchKernelGGL((k_fused<256, 0, false>), dim3(grid), dim3(256), lds, r->stream, r->amp, n, P, gq->d_ops, ntiles); break;
+        }
+#undef QCX_FUSE_LAUNCH
+        HIP_TRY(hipGetLastError());
+        gq->passes_launched++;
+        gq->gates_fused += nops;
+    }
+    return QCX_NO_ERROR;
+}
+
+static int fuse_push(qcx_register *r, const QGate &g)
+{
+    if (!r->queue) r->queue = new GateQueue();
+    r->queue->gates.push_back(g);
+    if (r->queue->gates.size() >= (size_t)g_tune.fuse_max_queue) return fuse_flush(r);
+    return QCX_NO_ERROR;
+}

@@ -579,4 +579,262 @@ __global__ __launch_bounds__(64) void k_meas_chain(const amp_t *__restrict__ amp
     if (lane == 0) { out->found = 0; out->index = 0; out->cum = cum; if (stats) { stats[0] = slow; stats[1] = nblocks; } }
 }
 
+// ---------------------------------------------------------------------------
+// K6  fused multi-gate pass.  A workgroup stages a TILE of 2^T amplitudes in
+// LDS -- the c lowest index bits (contiguous runs of 2^c amplitudes = 16*2^c bytes) plus nh = T - c
+// arbitrary higher bits hbit[0..nh) -- applies a whole list of gates to it and writes it back: one
+// HBM round trip for the lot.  Every gate performs exactly the arithmetic of its stand-alone
+// kernel, in the order the gates were issued, so results are bit-identical to the unfused path:
+//   H on a tile bit           butterfly between LDS slots (same t0 +/- t1 + 0.0 form)
+//   controlled phase          any control/target: a bit outside the tile is a per-tile constant;
+//                             runs of consecutive phases are applied per amplitude in registers
+//   controlled modular mult.  when the M register is inside the tile (closed form of k_camodc)
+// ---------------------------------------------------------------------------
+enum : uint32_t { FUSE_H = 0, FUSE_PHASE = 1, FUSE_CAMODC = 2 };
+
+struct FuseOp {                 // 32 bytes
+    uint32_t type;
+    uint32_t a;                 // H: tile-local bit;  CAMODC: M
+    uint64_t mask;              // PHASE: global index bits that must all be 1
+    double   c, s;              // PHASE: cos, sin.   CAMODC: reinterpreted below
+};
+struct FuseCamExtra {           // overlays c, s of a CAMODC op (16 bytes)
+    uint32_t C, d, Cd, inv;
+};
+struct FusePass {
+    uint32_t nops, T, c, nh;
+    int32_t  cam_ctl_local[4];  // unused padding / future
+    uint8_t  hbit[16];          // global bit carried by tile-local bit c + j, ascending
+};
+
+// the gate list applied to one LDS-resident tile (shared by the plain and the pipelined pass kernels)
+template <int BLOCK, int TT, unsigned EPT>
+__device__ __forceinline__ void fuse_apply_ops(amp_t *tile, const FusePass &P, const FuseOp *__restrict__ ops,
+                                               uint64_t base, uint64_t off_t, const uint64_t (&off_k)[EPT],
+                                               unsigned tsize, unsigned ept)
+{
+    unsigned i = 0;
+    while (i < P.nops) {
+        const uint32_t type = ops[i].type;
+        if (type == FUSE_H) {
+            const unsigned j = ops[i].a;
+#pragma unroll
+            for (unsigned k = 0; k < (EPT + 1) / 2; k++) {
+                const unsigned p = k * BLOCK + threadIdx.x;
+                if (p < tsize / 2) {
+                    const unsigned i0 = (unsigned)insert_zero(p, j), i1 = i0 | (1u << j);
+                    amp_t a = tile[i0], b = tile[i1];
+                    h_butterfly(a, b);
+                    tile[i0] = a; tile[i1] = b;
+                }
+            }
+            __syncthreads();
+            i++;
+        } else if (type == FUSE_PHASE) {
+            // a run of consecutive diagonal gates: the thread's amplitudes stay in registers for the whole run.
+            // mask (global bits outside the tile) is a per-tile constant -> scalar skip; a = mask of tile-local bits
+            unsigned gend = i + 1;
+            while (gend < P.nops && ops[gend].type == FUSE_PHASE) gend++;
+            amp_t v[EPT];
+#pragma unroll
+            for (unsigned k = 0; k < EPT; k++) {
+                const unsigned e = k * BLOCK + threadIdx.x;
+                if (k < ept && e < tsize) v[k] = tile[e];
+            }
+            for (unsigned o = i; o < gend; o++) {
+                const uint64_t mext = ops[o].mask;                      // wave-uniform: scalar loads
+                if ((base & mext) != mext) continue;
+                const uint32_t mloc = ops[o].a;
+                const double cc = ops[o].c, ss = ops[o].s;
+#pragma unroll
+                for (unsigned k = 0; k < EPT; k++) {
+                    const unsigned e = k * BLOCK + threadIdx.x;
+                    if (k < ept && e < tsize && (e & mloc) == mloc) {
+                        amp_t w;
+                        w.x = ((cc * v[k].x) - (ss * v[k].y)) + 0.0;
+                        w.y = ((cc * v[k].y) + (ss * v[k].x)) + 0.0;
+                        v[k] = w;
+                    }
+                }
+            }
+#pragma unroll
+            for (unsigned k = 0; k < EPT; k++) {
+                const unsigned e = k * BLOCK + threadIdx.x;
+                if (k < ept && e < tsize) tile[e] = v[k];
+            }
+            __syncthreads();
+            i = gend;
+        } else {    // FUSE_CAMODC: mask = control bit as a global-index mask
+            const unsigned M = ops[i].a;
+            const FuseCamExtra X = *reinterpret_cast<const FuseCamExtra *>(&ops[i].c);
+            const uint64_t cm = ops[i].mask;
+            const unsigned blkmask = (1u << M) - 1u;
+            // the elements of a thread are gathered before anything is overwritten
+            amp_t acc[EPT];
+            bool wr[EPT];
+#pragma unroll
+            for (unsigned k = 0; k < EPT; k++) {
+                wr[k] = false;
+                const unsigned e = k * BLOCK + threadIdx.x;
+                if (k < ept && e < tsize) {
+                    const uint64_t gi = base | off_t | off_k[k];
+                    const unsigned f = e & blkmask;
+                    if ((gi & cm) == cm && f < X.C) {
+                        amp_t s2; s2.x = 0.0; s2.y = 0.0;
+                        if (f % X.d == 0) {
+                            unsigned src = (unsigned)(((uint64_t)(f / X.d) * X.inv) % X.Cd);
+                            const amp_t *blk = tile + (e - f);
+                            for (unsigned q = 0; q < X.d; q++, src += X.Cd) { s2.x += blk[src].x; s2.y += blk[src].y; }
+                        }
+                        acc[k] = s2; wr[k] = true;
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (unsigned k = 0; k < EPT; k++)
+                if (wr[k]) tile[k * BLOCK + threadIdx.x] = acc[k];
+            __syncthreads();
+            i++;
+        }
+    }
+
+}
+
+template <int BLOCK, int TT, bool LDSDMA>   // TT = tile bits when known at compile time (loops unroll, loads batch); 0 = generic
+__global__ __launch_bounds__(BLOCK) void k_fused(amp_t *__restrict__ amp, unsigned n, FusePass P,
+                                                   const FuseOp *__restrict__ ops, uint64_t ntiles)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qcx_lds_raw[];
+    amp_t *tile = reinterpret_cast<amp_t *>(qcx_lds_raw);
+    const unsigned T = TT ? (unsigned)TT : P.T, c = P.c, nh = P.nh;
+    const unsigned tsize = 1u << T;
+    constexpr unsigned EPT = TT ? ((1u << TT) + BLOCK - 1) / BLOCK : 16;      // elements per thread (<= 16)
+    const unsigned ept = TT ? EPT : (tsize + BLOCK - 1) / BLOCK;
+    const unsigned lowmask = (1u << c) - 1u;
+
+    // global offset of a tile-local element index: linear in its bits, so split thread part / k part
+    auto scatter = [&](unsigned e) -> uint64_t {
+        uint64_t off = e & lowmask;
+        for (unsigned j = 0; j < nh; j++) off |= (uint64_t)((e >> (c + j)) & 1u) << P.hbit[j];
+        return off;
+    };
+    const uint64_t off_t = scatter(threadIdx.x);
+    uint64_t off_k[EPT];
+#pragma unroll
+    for (unsigned k = 0; k < EPT; k++) off_k[k] = scatter(k * BLOCK);
+
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        uint64_t base = t << c;
+        for (unsigned j = 0; j < nh; j++) base = insert_zero(base, P.hbit[j]);
+        amp_t *g = amp + (base | off_t);
+
+        if constexpr (TT != 0 && LDSDMA) {
+            // LDS-DMA: every wave instruction moves 64 x 16 B straight from HBM into 1 KiB of the tile
+            // (lane l lands at base + 16 l); no staging registers, all loads of the tile in flight at once
+            const unsigned wbase = (threadIdx.x >> 6) * 64;
+#pragma unroll
+            for (unsigned k = 0; k < EPT; k++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + off_k[k]),
+                                                 (__attribute__((address_space(3))) void *)(tile + k * BLOCK + wbase), 16, 0, 2);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {   // all loads of the tile in flight before the first LDS write
+            amp_t v[EPT];
+#pragma unroll
+            for (unsigned k = 0; k < EPT; k++)
+                if (k < ept && k * BLOCK + threadIdx.x < tsize) v[k] = __builtin_nontemporal_load(g + off_k[k]);
+#pragma unroll
+            for (unsigned k = 0; k < EPT; k++)
+                if (k < ept && k * BLOCK + threadIdx.x < tsize) tile[k * BLOCK + threadIdx.x] = v[k];
+        }
+        __syncthreads();
+
+        fuse_apply_ops<BLOCK, TT, EPT>(tile, P, ops, base, off_t, off_k, tsize, ept);
+
+        {
+            amp_t v[EPT];
+#pragma unroll
+            for (unsigned k = 0; k < EPT; k++)
+                if (k < ept && k * BLOCK + threadIdx.x < tsize) v[k] = tile[k * BLOCK + threadIdx.x];
+#pragma unroll
+            for (unsigned k = 0; k < EPT; k++)
+                if (k < ept && k * BLOCK + threadIdx.x < tsize) __builtin_nontemporal_store(v[k], g + off_k[k]);
+        }
+        __syncthreads();
+    }
+}
+
+// Pipelined form of the fused pass: a persistent workgroup walks its tiles with two LDS buffers; the
+// LDS-DMA fill of tile i+1 is in flight while tile i is being processed and stored.  vmcnt counts
+// stores as well, so the wait before using a buffer is "all but the EPT youngest" (the stores of the
+// previous tile, issued after the fill).
+template <int BLOCK, int TT>
+__global__ __launch_bounds__(BLOCK, 4) void k_fused_pipe(amp_t *__restrict__ amp, unsigned n, FusePass P,
+                                                        const FuseOp *__restrict__ ops, uint64_t ntiles)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qcx_lds_raw[];
+    amp_t *buf0 = reinterpret_cast<amp_t *>(qcx_lds_raw);
+    constexpr unsigned tsize = 1u << TT;
+    constexpr unsigned EPT = tsize / BLOCK;
+    static_assert(EPT >= 1 && EPT <= 8, "tile / block geometry");
+    const unsigned c = P.c, nh = P.nh;
+    const unsigned lowmask = (1u << c) - 1u;
+    auto scatter = [&](unsigned e) -> uint64_t {
+        uint64_t off = e & lowmask;
+        for (unsigned j = 0; j < nh; j++) off |= (uint64_t)((e >> (c + j)) & 1u) << P.hbit[j];
+        return off;
+    };
+    auto tile_base = [&](uint64_t t) -> uint64_t {
+        uint64_t base = t << c;
+        for (unsigned j = 0; j < nh; j++) base = insert_zero(base, P.hbit[j]);
+        return base;
+    };
+    const uint64_t off_t = scatter(threadIdx.x);
+    uint64_t off_k[EPT];
+#pragma unroll
+    for (unsigned k = 0; k < EPT; k++) off_k[k] = scatter(k * BLOCK);
+    const unsigned wbase = (threadIdx.x >> 6) * 64;
+
+    auto fill = [&](amp_t *dst, uint64_t base) {
+        const amp_t *g = amp + (base | off_t);
+#pragma unroll
+        for (unsigned k = 0; k < EPT; k++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + off_k[k]),
+                                             (__attribute__((address_space(3))) void *)(dst + k * BLOCK + wbase), 16, 0, 2);
+    };
+
+    uint64_t t = blockIdx.x;
+    if (t >= ntiles) return;
+    unsigned cur = 0;
+    fill(buf0, tile_base(t));
+    bool stores_pending = false;
+    for (; t < ntiles; t += gridDim.x) {
+        amp_t *tile = buf0 + cur * tsize;
+        const uint64_t base = tile_base(t);
+        // the fill of this tile is older than the stores of the previous one
+        if (stores_pending) { if constexpr (EPT == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                              else if constexpr (EPT == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                              else if constexpr (EPT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                              else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                       // fill visible to all waves; all waves done reading the other buffer
+        const uint64_t tn = t + gridDim.x;
+        if (tn < ntiles) fill(buf0 + (cur ^ 1) * tsize, tile_base(tn));
+
+        fuse_apply_ops<BLOCK, TT, EPT>(tile, P, ops, base, off_t, off_k, tsize, EPT);
+
+        amp_t *g = amp + (base | off_t);
+        amp_t v[EPT];
+#pragma unroll
+        for (unsigned k = 0; k < EPT; k++) v[k] = tile[k * BLOCK + threadIdx.x];
+        if (tn < ntiles) {
+            // keep the fill of the next tile OLDER than these stores in the vmcnt order: it already is
+        }
+#pragma unroll
+        for (unsigned k = 0; k < EPT; k++) __builtin_nontemporal_store(v[k], g + off_k[k]);
+        stores_pending = true;
+        cur ^= 1;
+    }
+}
+
 }  // namespace qcx

@@ -114,6 +114,18 @@ class Register:
         check(lib().qcx_norm2(self._h, C.byref(out)), "qcx_norm2")
         return out.value
 
+    def set_fusion(self, enable=True):
+        """queue gates and run them as fused LDS-tile passes (bit-identical results)"""
+        check(lib().qcx_set_fusion(self._h, int(bool(enable))), "qcx_set_fusion")
+
+    def flush(self):
+        check(lib().qcx_flush(self._h), "qcx_flush")
+
+    def fusion_stats(self):
+        p, g = C.c_ulong(0), C.c_ulong(0)
+        check(lib().qcx_fusion_stats(self._h, C.byref(p), C.byref(g)), "qcx_fusion_stats")
+        return p.value, g.value
+
     def synchronize(self):
         check(lib().qcx_synchronize(self._h), "qcx_synchronize")
 

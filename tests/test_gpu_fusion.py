@@ -1,0 +1,149 @@
+"""GPU: the gate queue + fused LDS-tile passes give the SAME BITS as the per-gate kernels and the
+oracle: random gate programs, whole Shor circuits, the IQFT ladder, every tile geometry."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+@pytest.fixture()
+def tune_guard(qc):
+    keys = ("fuse_T", "fuse_c", "fuse_grid_cap", "fuse_max_queue")
+    old = {k: qc.lib().qcx_tune_get(k.encode()) for k in keys}
+    yield
+    qc.tune(**old)
+
+
+def random_program(rs, n, M, Cn, length):
+    prog = []
+    for _ in range(length):
+        k = rs.randint(0, 10)
+        if k < 4:
+            prog.append(("h", int(rs.randint(0, n))))
+        elif k < 9 or M == 0:
+            c, t = rs.choice(n, 2, replace=False)
+            prog.append(("p", int(c), int(t), float(rs.uniform(-3, 3)) if k % 2 else math.pi / (1 << int(rs.randint(1, 12)))))
+        else:
+            prog.append(("c", int(rs.randint(1, 4 * Cn)), int(rs.randint(M, n))))
+    return prog
+
+
+def run_both(qc, ob, L, M, Cn, prog, seed, fusion=True):
+    n = L + M
+    want = ob.random_state(n, seed)
+    with qc.Register(L, M) as reg:
+        reg.write(want)
+        reg.set_fusion(fusion)
+        for g in prog:
+            if g[0] == "h":
+                qc.hadamard_gate(g[1], reg); ob.hadamard(want, n, g[1])
+            elif g[0] == "p":
+                qc.c_phase_shift_gate(g[1], g[2], g[3], reg); ob.cphase(want, n, g[1], g[2], g[3])
+            else:
+                qc.c_amodc_gate(Cn, g[1], g[2], reg); ob.camodc(want, n, M, Cn, g[1], g[2])
+        got = reg.read()
+        stats = reg.fusion_stats()
+    return got, want, stats
+
+
+@pytest.mark.parametrize("L,M,Cn", [(3, 2, 3), (5, 4, 15), (9, 4, 15), (10, 5, 21), (13, 5, 21), (12, 0, 1), (10, 10, 1000)])
+def test_random_programs_fused_bit_exact(qc, ob, L, M, Cn):
+    rs = np.random.RandomState(L * 31 + M)
+    for trial in range(3):
+        prog = random_program(rs, L + M, M, Cn, 60)
+        got, want, stats = run_both(qc, ob, L, M, Cn, prog, 70 + trial)
+        assert np.array_equal(bits(got), bits(want)), f"L={L} M={M} trial {trial}"
+    if L + M >= 8:
+        assert stats[0] > 0 and stats[1] >= stats[0]
+
+
+@pytest.mark.parametrize("T,c", [(8, 2), (9, 4), (10, 6), (11, 3), (12, 4), (12, 6), (12, 0), (10, 10)])
+def test_every_tile_geometry(qc, ob, tune_guard, T, c):
+    qc.tune(fuse_T=T, fuse_c=c)
+    rs = np.random.RandomState(T * 16 + c)
+    L, M, Cn = 11, 5, 21
+    prog = random_program(rs, L + M, M, Cn, 80)
+    got, want, _ = run_both(qc, ob, L, M, Cn, prog, 5)
+    assert np.array_equal(bits(got), bits(want))
+    qc.tune(fuse_grid_cap=3)                       # grid-stride over tiles
+    got, want, _ = run_both(qc, ob, L, M, Cn, prog, 6)
+    assert np.array_equal(bits(got), bits(want))
+
+
+@pytest.mark.parametrize("L,M,C,a", [(3, 4, 15, 7), (8, 4, 15, 7), (9, 5, 21, 2), (6, 6, 35, 2), (14, 5, 21, 2)])
+def test_shor_circuit_fused(qc, ob, L, M, C, a):
+    n = L + M
+    with qc.Register(L, M) as reg:
+        reg.set_fusion(True)
+        qc.reset_register(reg)
+        qc.quantum_computation(C, a, reg)
+        got = reg.read()
+        passes, gates = reg.fusion_stats()
+    want = np.zeros(2 << n); ob.reset(want, n); ob.quantum_computation(want, n, M, C, a, threads=8)
+    assert np.array_equal(bits(got), bits(want))
+    if n >= 8:
+        assert gates == 3 * L + L * (L - 1) // 2 or passes > 0
+        assert passes < gates / 3
+
+
+def test_iqft_and_sweep_fused(qc, ob):
+    n = 16
+    a = ob.random_state(n, 3)
+    with qc.Register(n, 0) as reg:
+        reg.write(a); reg.set_fusion(True)
+        qc.inverse_QFT(reg)
+        for q in range(n):
+            qc.hadamard_gate(q, reg)
+        got = reg.read()
+    want = a.copy(); ob.iqft(want, n, 0, threads=8)
+    for q in range(n):
+        ob.hadamard(want, n, q, 8)
+    assert np.array_equal(bits(got), bits(want))
+
+
+def test_queue_semantics(qc, ob):
+    """reads flush; reset drops pending gates; measurement sees the fused state; toggling fusion flushes"""
+    n = 10
+    a = ob.random_state(n, 8)
+    with qc.Register(n, 0) as reg:
+        reg.write(a); reg.set_fusion(True)
+        qc.hadamard_gate(3, reg); qc.hadamard_gate(9, reg)
+        w = a.copy(); ob.hadamard(w, n, 3); ob.hadamard(w, n, 9)
+        assert np.array_equal(bits(reg.read(5, 100)), bits(w[10:210]))
+        qc.hadamard_gate(1, reg)
+        qc.reset_register(reg)                      # the queued H(1) must not touch the fresh state
+        s = reg.read(); z = np.zeros(2 << n); z[2] = 1.0
+        assert np.array_equal(bits(s), bits(z))
+        reg.write(a)
+        qc.hadamard_gate(0, reg); qc.c_phase_shift_gate(9, 2, 0.4, reg)
+        w = a.copy(); ob.hadamard(w, n, 0); ob.cphase(w, n, 9, 2, 0.4)
+        r = 0.37
+        assert qc.measure_state(reg, r) == ob.measure(w, n, r)
+        reg.write(a)
+        qc.hadamard_gate(5, reg)
+        reg.set_fusion(False)                       # flushes
+        qc.hadamard_gate(6, reg)
+        w = a.copy(); ob.hadamard(w, n, 5); ob.hadamard(w, n, 6)
+        assert np.array_equal(bits(reg.read()), bits(w))
+
+
+def test_fullsize_fused_sweep_matches_unfused_windows(qc):
+    """n = 28: the fused sweep and the per-gate sweep leave identical bits (spot windows)"""
+    n = 28
+    with qc.Register(n, 0) as r1, qc.Register(n, 0) as r2:
+        r1.fill_random(2); r2.fill_random(2)
+        r2.set_fusion(True)
+        for q in range(n):
+            qc.hadamard_gate(q, r1); qc.hadamard_gate(q, r2)
+        for k in range(n - 2, n - 12, -1):
+            th = math.pi / (1 << (n - 1 - k))
+            qc.c_phase_shift_gate(n - 1, k, th, r1); qc.c_phase_shift_gate(n - 1, k, th, r2)
+        for s in (0, 12345 << 13, (1 << n) - (1 << 13), 1 << 27):
+            assert np.array_equal(bits(r1.read(s, 1 << 13)), bits(r2.read(s, 1 << 13)))
+        assert r2.fusion_stats()[0] <= 6

@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n-local", type=int, default=30, help="qubits per GPU shard (30 = 16 GiB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path (ShardedRegister) even at world size 1")
     ap.add_argument("--cpu-n", type=int, default=26)
     args = ap.parse_args()
 
@@ -103,7 +105,7 @@ def main():
     gates_per_step = n
     dim = float(1 << n)
 
-    if args.gpus == 1:
+    if args.gpus == 1 and not args.force_sharded:
         reg = qc.Register(n, 0)
         reg.fill_random(1)
         nev = args.steps * (gates_per_step + 1)
@@ -128,6 +130,24 @@ def main():
 
         per_q_ms = [[reg.event_elapsed(s * (n + 1) + q, s * (n + 1) + q + 1) for s in range(args.steps)] for q in range(n)]
         norm = reg.norm2()
+
+        # reported separately: the same sweep with gate fusion on -- the 30 gate calls are queued
+        # and run as a few fused LDS-tile passes, bit-identical results; bytes are counted once per pass
+        fused = None
+        if not args.no_fused:
+            reg.set_fusion(True)
+            sweep(); reg.synchronize()
+            p0 = reg.fusion_stats()[0]
+            tf0 = time.perf_counter()
+            for s in range(args.steps):
+                sweep()
+            reg.synchronize()
+            tf = time.perf_counter() - tf0
+            passes = (reg.fusion_stats()[0] - p0) / args.steps
+            fused = {"value": args.steps * gates_per_step * dim / tf, "unit": "amplitude-updates/s", "ms_per_step": tf / args.steps * 1e3,
+                     "hbm_passes_per_sweep": passes, "hbm_gbs_per_pass": passes * 32.0 * dim / (tf / args.steps) / 1e9,
+                     "note": "qcx_set_fusion(1): same 30 hadamard_gate calls, executed as fused passes over LDS tiles"}
+            reg.set_fusion(False)
         reg.close()
         exchanges = 0
     else:
@@ -136,30 +156,37 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         reg = ShardedRegister(n, 0)
         reg.fill_random(1)
-        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(n + 1)] for _ in range(args.steps)]
 
-        def sweep(evs=None):
+        def sweep():
             for q in range(n):
-                if evs is not None:
-                    evs[q].record()
-                reg.hadamard_gate(q)
-            if evs is not None:
-                evs[n].record()
+                reg.hadamard_gate(q)          # queued; executed on flush with look-ahead eviction
 
         for _ in range(args.warmup):
             sweep()
-        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        reg.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        ex0 = reg.exchanges
+        reg.profile = []
         t0 = time.perf_counter()
         for s in range(args.steps):
-            sweep(ev[s])
-        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            sweep()
+        reg.synchronize(); dist.barrier(); torch.cuda.synchronize()
         dt_local = time.perf_counter() - t0
         t = torch.tensor([dt_local], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        per_q_ms = [[ev[s][q].elapsed_time(ev[s][q + 1]) for s in range(args.steps)] for q in range(n)]
+        prof, reg.profile = reg.profile, None
+        # per physical target position: durations of the Hadamard launches that did not carry an exchange
+        per_q_ms = [[] for _ in range(n)]
+        exch_ms = []
+        for kind, pq, e0, e1, exchanged in prof:
+            ms = e0.elapsed_time(e1)
+            if exchanged:
+                exch_ms.append(ms)
+            elif kind == "h":
+                per_q_ms[pq].append(ms)
         norm = reg.norm2()
-        exchanges = reg.exchanges
+        exchanges = reg.exchanges - ex0
+        fused = None
 
     if rank == 0:
         bytes_per_launch = 32.0 * float(1 << args.n_local)           # 16 B read + 16 B written per amplitude, per GPU
@@ -167,6 +194,7 @@ def main():
         # on N > 1 the event interval of a global qubit also holds the all-to-all, so those are left out
         dom = [q for q in range(3, args.n_local)]
         dom_ms = [x for q in dom for x in per_q_ms[q]]
+        per_q_ms = [v if v else [float("nan")] for v in per_q_ms]
         avg_ms = sum(dom_ms) / len(dom_ms)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         per_q_gbs = [round(bytes_per_launch / (min(per_q_ms[q]) * 1e-3) / 1e9, 1) for q in range(n)]
@@ -183,13 +211,15 @@ def main():
                                    f"one launch per gate through libqcx.so, complex128 state of {16 * dim / 2**30:.0f} GiB in HBM",
                        "qubits": n, "gates_per_step": gates_per_step, "shard_qubits": args.n_local,
                        "parallelism": "1 GPU" if args.gpus == 1 else f"state sharded by top {k} qubits over {args.gpus} ranks, "
-                                      f"all-to-all qubit remap for global targets ({exchanges} exchanges in {args.warmup + args.steps} sweeps)"},
+                                      f"all-to-all qubit remap for global targets ({exchanges} exchanges in the {args.steps} timed sweeps"
+                                      + (f", mean {sum(exch_ms) / len(exch_ms):.1f} ms per exchange+gate)" if args.gpus > 1 and exch_ms else ")")},
             "hbm_gbs_sweep_average": args.steps * gates_per_step * bytes_per_launch * args.gpus / dt / 1e9,
             "roofline": {"bound": "hbm", "kernel": "qcx::k_h_pair (Hadamard, pair form, target qubit >= 3)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
                          "launches_timed": len(dom_ms), "traffic": load_traffic()},
             "per_qubit_gbs": per_q_gbs,
+            "fused_sweep": fused if args.gpus == 1 else None,
             "total_probability_after": norm,
         }
         if not args.no_cpu_baseline and args.gpus == 1:

@@ -135,6 +135,10 @@ int  qcx_shard_phase(void *amp, unsigned n_local, uint64_t mask_local, double co
 /* ctl_local < 0: the control is a global bit whose value on this rank is 1 */
 int  qcx_shard_camodc(void *amp, unsigned n_local, unsigned M, unsigned C, unsigned A,
                       int ctl_local, void *stream);
+/* dst[j] = src[j with index bits pos_a[m] <-> pos_b[m] exchanged, m < npairs <= 8]; out of place.
+ * The pack pass of the sharded qubit remap (brings the bits to be traded with the rank id to the top). */
+int  qcx_shard_swap_bits(const void *src, void *dst, unsigned n_local, unsigned npairs,
+                         const unsigned *pos_a, const unsigned *pos_b, void *stream);
 int  qcx_shard_norm2(const void *amp, unsigned n_local, double *out, void *stream);
 /* sequential cumulative scan of |amp|^2 over this shard continuing from cum_in
  * (global index of local 0 = first_global; indices >= last_excluded are not

@@ -70,6 +70,7 @@ SIGNATURES = {
     "qcx_shard_hadamard": (_i, [_p, _u, _u, _p]),
     "qcx_shard_phase": (_i, [_p, _u, _u64, _d, _d, _p]),
     "qcx_shard_camodc": (_i, [_p, _u, _u, _u, _u, _i, _p]),
+    "qcx_shard_swap_bits": (_i, [_p, _p, _u, _u, C.POINTER(_u), C.POINTER(_u), _p]),
     "qcx_shard_norm2": (_i, [_p, _u, C.POINTER(_d), _p]),
     "qcx_shard_measure_scan": (_i, [_p, _u, _u64, _u64, _d, _d, C.POINTER(_i), C.POINTER(_u64), C.POINTER(_d), _p]),
     "qcx_shard_collapse": (_i, [_p, _u, _i64, _p]),

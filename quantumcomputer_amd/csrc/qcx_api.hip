@@ -498,6 +498,24 @@ extern "C" int qcx_shard_camodc(void *amp, unsigned n_local, unsigned M, unsigne
     return QCX_NO_ERROR;
 }
 
+extern "C" int qcx_shard_swap_bits(const void *src, void *dst, unsigned n_local, unsigned npairs,
+                                   const unsigned *pos_a, const unsigned *pos_b, void *stream)
+{
+    if (!src || !dst || src == dst || n_local > 40 || npairs > 8 || (npairs && (!pos_a || !pos_b))) return QCX_BAD_ARGUMENTS;
+    SwapBits S;
+    memset(&S, 0, sizeof S);
+    S.npairs = npairs;
+    for (unsigned m = 0; m < npairs; m++) {
+        if (pos_a[m] >= n_local || pos_b[m] >= n_local || pos_a[m] == pos_b[m]) return QCX_BAD_QUBIT;
+        S.a[m] = pos_a[m]; S.b[m] = pos_b[m];
+    }
+    const uint64_t count = (uint64_t)1 << n_local;
+    hipLaunchKernelGGL((k_swap_bits<256>), dim3(grid_for(count, 256, 0)), dim3(256), 0, (hipStream_t)stream,
+                       (const amp_t *)src, (amp_t *)dst, count, S);
+    HIP_TRY(hipGetLastError());
+    return QCX_NO_ERROR;
+}
+
 extern "C" int qcx_shard_norm2(const void *amp, unsigned n_local, double *out, void *stream)
 {
     if (!amp || !out || n_local > 40) return QCX_BAD_ARGUMENTS;

@@ -837,4 +837,24 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fused_pipe(amp_t *__restrict__ amp
     }
 }
 
+// ---------------------------------------------------------------------------
+// X1  local index-bit permutation (pack pass of the sharded qubit remap): dst[j] = src[j with the bit
+// pairs (a_m, b_m) exchanged].  Out of place, coalesced stores, gathered loads (runs of 2^min(a, b)).
+// ---------------------------------------------------------------------------
+struct SwapBits { unsigned npairs; unsigned a[8]; unsigned b[8]; };
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_swap_bits(const amp_t *__restrict__ src, amp_t *__restrict__ dst,
+                                                       uint64_t count, SwapBits S)
+{
+    for (uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; j < count; j += (uint64_t)gridDim.x * BLOCK) {
+        uint64_t i = j;
+        for (unsigned m = 0; m < S.npairs; m++) {
+            const uint64_t x = ((i >> S.a[m]) ^ (i >> S.b[m])) & 1u;      // exchange bits a and b
+            i ^= (x << S.a[m]) | (x << S.b[m]);
+        }
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + j);
+    }
+}
+
 }  // namespace qcx

@@ -202,3 +202,27 @@ def read_omega(state_num, reg):
     for p in range(reg.L_size):
         x |= ((state_num >> (reg.L_size + reg.M_size - 1 - p)) & 1) << p
     return x / float(1 << reg.L_size)
+
+
+def display_state(reg, file=None, limit=None):
+    """testing_and_debug.c:7-26: one line per basis state with non-zero amplitude, qubits MSB first,
+    followed by |amplitude| with two decimals.  Reads the whole state to the host (debug tool)."""
+    import sys
+    out = file or sys.stdout
+    v = reg.read().reshape(-1, 2)
+    mag = np.hypot(v[:, 0], v[:, 1])
+    shown = 0
+    for i in np.nonzero(mag)[0]:
+        print("|" + format(int(i), "0%db" % reg.num_qubits) + "> %.2f" % mag[i], file=out)
+        shown += 1
+        if limit is not None and shown >= limit:
+            break
+    return shown
+
+
+def check_normalisation(reg, file=None):
+    """testing_and_debug.c:28-37: prints the total probability with 16 decimals and returns it"""
+    import sys
+    total = reg.norm2()
+    print("Total Probability: %.16f" % total, file=file or sys.stdout)
+    return total

@@ -1,27 +1,37 @@
 """State vector sharded over the GPUs of one node, one process per GPU (torch.distributed; the
 "nccl" backend is RCCL over xGMI on ROCm).
 
-Layout: rank r of W = 2^k holds the 2^(n-k) amplitudes whose top k index bits are r.
-  * H on a local qubit, every controlled phase (diagonal) and the controlled modular multiply
-    (permutes only the low M bits) need NO communication: a global control bit is a per-rank
-    constant -- ranks where it is 0 skip the gate.
-  * H on a global qubit is the one exchange step.  Instead of pairwise half-shard swaps (one xGMI
-    link each) the k rank bits are exchanged with the top k local bits in ONE all-to-all, which
-    drives all 7 links of every GPU at once; the logical->physical qubit map records the swap and
-    later gates are translated through it.  Measurement and read-back restore the identity map.
+Layout: rank r of W = 2^k holds the 2^(n-k) amplitudes whose top k PHYSICAL index bits
+are r.  A logical->physical qubit permutation is kept on the host.
+  * H on a qubit that is physically local, every controlled phase (diagonal) and the controlled
+    modular multiply (permutes only the low M bits, which never move) need NO communication: a
+    control that sits in the rank id is a per-rank constant -- ranks where it is 0 skip the gate.
+  * H on a qubit that is physically global is the one exchange step.  Instead of pairwise half-shard
+    swaps (each rides ONE xGMI link) all k rank bits are traded at once for k local bits with ONE
+    all-to-all, which drives all 7 links of every GPU together:
+        pack   (local, qcx_shard_swap_bits): bring the k local bits to be given up to the top k
+               local positions -- out of place, so it doubles as the send-buffer fill;
+        trade  (all_to_all_single): chunk c of rank r <-> chunk r of rank c.
+    Gates are queued (like the single-GPU fusion queue) and executed on flush, so the choice of WHICH
+    local qubits to give up can look ahead: the k candidates whose next use as an H target lies
+    furthest in the future are evicted (Belady).  A cyclic H sweep then costs one exchange per sweep,
+    the Shor circuit two in total.
+  * measurement, norm and read-back flush the queue; measurement and read-back also restore the
+    identity layout.
 
 All arithmetic runs in libqcx.so through the shard-level C ABI (`HipEngine`); torch only owns the
-device buffers, the stream and the collective.  The engine is injectable so that the host logic
-(who skips, which bits, which chunks) can be exercised on CPU with the gloo backend in tests.
+device buffers, the stream and the collective.  The engine is injectable so that the host logic can be
+exercised on CPU with the gloo backend in tests.
 """
 import ctypes as C
 import math
 
-import numpy as np
 import torch
 import torch.distributed as dist
 
 from ._lib import check, lib
+
+MIN_EVICT_POS = 6          # never trade away index bits below this: runs of the pack pass stay >= 1 KiB
 
 
 class HipEngine:
@@ -56,6 +66,12 @@ class HipEngine:
     def camodc(self, t, n_local, M, Cn, A, ctl_local):
         check(lib().qcx_shard_camodc(self._p(t), n_local, M, Cn, A, ctl_local, self._s()), "qcx_shard_camodc")
 
+    def swap_bits(self, src, dst, n_local, pos_a, pos_b):
+        m = len(pos_a)
+        a = (C.c_uint * max(m, 1))(*pos_a)
+        b = (C.c_uint * max(m, 1))(*pos_b)
+        check(lib().qcx_shard_swap_bits(self._p(src), self._p(dst), n_local, m, a, b, self._s()), "qcx_shard_swap_bits")
+
     def norm2(self, t, n_local):
         out = C.c_double(0.0)
         check(lib().qcx_shard_norm2(self._p(t), n_local, C.byref(out), self._s()), "qcx_shard_norm2")
@@ -72,9 +88,9 @@ class HipEngine:
 
 
 class ShardedRegister:
-    """Register (qc_shor.c:194-203) sharded by its top log2(world) qubits."""
+    """Register (qc_shor.c:194-203) sharded by its top log2(world) physical index bits."""
 
-    def __init__(self, L_size, M_size, device=None, group=None, engine=None):
+    def __init__(self, L_size, M_size, device=None, group=None, engine=None, max_queue=8192):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -83,19 +99,25 @@ class ShardedRegister:
             raise ValueError("world size must be a power of two")
         self.k = k
         self.L_size, self.M_size = int(L_size), int(M_size)
-        self.num_qubits = self.L_size + self.M_size
-        self.num_states = 1 << self.num_qubits
-        self.n_local = self.num_qubits - k
-        if self.n_local < max(2 * k, 1) or self.M_size > self.n_local - k:
-            raise ValueError("register too small for this many ranks (need n - k >= 2k and M <= n - 2k)")
+        self.num_qubits = n = self.L_size + self.M_size
+        self.num_states = 1 << n
+        self.n_local = n - k
+        self.min_evict = max(MIN_EVICT_POS if self.n_local - 2 * k >= MIN_EVICT_POS else 0, self.M_size)
+        if self.n_local < 1 or (k and self.n_local - self.min_evict < 2 * k):
+            raise ValueError("register too small for this many ranks (need n_local - max(M, 6) >= 2 log2(world))")
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = torch.device(device)
         self.engine = engine if engine is not None else HipEngine(self.device)
         self.bufs = [torch.zeros(2 << self.n_local, dtype=torch.float64, device=self.device) for _ in range(2 if k else 1)]
         self.cur = 0
-        self.swapped = False          # True: rank bits and top-k local bits are exchanged
-        self.exchanges = 0            # all-to-alls performed (statistics)
+        self.perm = list(range(n))        # logical qubit -> physical index bit
+        self.inv = list(range(n))         # physical index bit -> logical qubit
+        self.queue = []
+        self.max_queue = max_queue
+        self.exchanges = 0                # all-to-alls performed
+        self.pack_passes = 0              # local pack passes performed
+        self.profile = None               # set to [] to collect (gate, ms, exchanged) per executed gate (cuda only)
 
     # -- layout -------------------------------------------------------------------------------
     @property
@@ -103,70 +125,175 @@ class ShardedRegister:
         return self.bufs[self.cur]
 
     def phys(self, q):
-        """physical bit position of logical qubit q"""
-        if self.swapped and self.k:
-            if self.n_local - self.k <= q < self.n_local:
-                return q + self.k
-            if q >= self.n_local:
-                return q - self.k
-        return q
+        return self.perm[q]
 
     def _rank_bit(self, pq):
         return (self.rank >> (pq - self.n_local)) & 1
 
-    def _toggle(self):
-        """swap the k rank bits with the top k local bits: one all-to-all of equal chunks
-        (chunk c of rank r <-> chunk r of rank c), result lands in the other buffer"""
-        if not self.k:
-            return
+    def _set_phys(self, logical, pos):
+        self.perm[logical] = pos
+        self.inv[pos] = logical
+
+    def _apply_local_swaps(self, swaps):
+        """swaps = index-bit transpositions (a, b) in APPLICATION order (data at index i moves to the index
+        with bits a and b exchanged).  One out-of-place pass per 8 transpositions."""
+        for lo in range(0, len(swaps), 8):
+            part = swaps[lo:lo + 8]
+            src, dst = self.bufs[self.cur], self.bufs[self.cur ^ 1]
+            # dst[j] = src[s_1(s_2(...s_m(j)))]: the kernel applies its list to the index in array order
+            rev = list(reversed(part))
+            self.engine.swap_bits(src, dst, self.n_local, [x[0] for x in rev], [x[1] for x in rev])
+            self.cur ^= 1
+            self.pack_passes += 1
+            for a, b in part:
+                la, lb = self.inv[a], self.inv[b]
+                self._set_phys(la, b); self._set_phys(lb, a)
+
+    def _trade(self, give):
+        """exchange the k rank bits with k local positions: the qubit at local position give[j] ends up in
+        rank bit j, the qubit of rank bit j at local position n_local - k + j.
+          pack  : transpositions bringing give[j] to top slot j (out of place = the send buffer fill)
+          trade : one all_to_all_single of equal chunks (chunk c of rank r <-> chunk r of rank c)"""
+        k, nl = self.k, self.n_local
+        pos = list(give)
+        swaps = []
+        for j in range(k):
+            t, p = nl - k + j, pos[j]
+            if p != t:
+                swaps.append((p, t))
+                for jj in range(j + 1, k):
+                    if pos[jj] == t:
+                        pos[jj] = p
+        self._apply_local_swaps(swaps)
         src, dst = self.bufs[self.cur], self.bufs[self.cur ^ 1]
         dist.all_to_all_single(dst, src, group=self.group)
         self.cur ^= 1
-        self.swapped = not self.swapped
         self.exchanges += 1
+        for j in range(k):
+            lt, lr = self.inv[nl - k + j], self.inv[nl + j]
+            self._set_phys(lt, nl + j); self._set_phys(lr, nl - k + j)
+
+    def _next_use(self, logical, start):
+        """index in the queue of the next H on `logical` at or after `start` (len(queue) + 1 = never)"""
+        for i in range(start, len(self.queue)):
+            g = self.queue[i]
+            if g[0] == "h" and g[1] == logical:
+                return i
+        return len(self.queue) + 1
+
+    def _make_local(self, q, at):
+        """bring logical qubit q (and with it every qubit of the rank id) to local positions, giving up the
+        k local qubits whose next use as an H target lies furthest ahead in the queue (Belady)"""
+        nl, k = self.n_local, self.k
+        cand = list(range(self.min_evict, nl))
+        cand.sort(key=lambda p: (-self._next_use(self.inv[p], at), -p))
+        self._trade(sorted(cand[:k]))
+        assert self.perm[q] < nl
 
     def _identity(self):
-        if self.swapped:
-            self._toggle()
+        """restore logical == physical (the order measurement and read-back need)"""
+        self.flush()
+        n, nl, k = self.num_qubits, self.n_local, self.k
+        if self.perm == list(range(n)):
+            return
+        G = list(range(nl, n))
+        if k and any(self.perm[g] != g for g in G):
+            if any(self.perm[g] >= nl for g in G):
+                # some rightful rank-id qubits sit in the rank id but in the wrong slot / beside strangers:
+                # one trade brings the whole rank id local (giving up positions that hold none of G)
+                cand = [p for p in range(nl - 1, self.min_evict - 1, -1) if self.inv[p] not in G][:k]
+                self._trade(cand)
+            self._trade([self.perm[nl + j] for j in range(k)])         # rank bit j <- logical qubit nl + j
+        swaps = []
+        perm = list(self.perm)
+        inv = list(self.inv)
+        for q in range(nl):
+            a = perm[q]
+            if a != q:
+                swaps.append((a, q))
+                other = inv[q]
+                perm[q], perm[other] = q, a
+                inv[q], inv[a] = q, other
+        self._apply_local_swaps(swaps)
+        assert self.perm == list(range(n)), self.perm
+
+    # -- queue ----------------------------------------------------------------------------------
+    def _push(self, g):
+        self.queue.append(g)
+        if len(self.queue) >= self.max_queue:
+            self.flush()
+
+    def flush(self):
+        if not self.queue:
+            return
+        queue, i = self.queue, 0
+        nl = self.n_local
+        while i < len(queue):
+            g = queue[i]
+            ev0 = None
+            if self.profile is not None and self.device.type == "cuda":
+                ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True); ev0.record()
+            exchanged = False
+            if g[0] == "h":
+                if self.perm[g[1]] >= nl:
+                    self._make_local(g[1], i)
+                    exchanged = True
+                self.engine.hadamard(self.shard, nl, self.perm[g[1]])
+            elif g[0] == "p":
+                mask, skip = 0, False
+                for pq in (self.perm[g[1]], self.perm[g[2]]):
+                    if pq >= nl:
+                        skip = skip or not self._rank_bit(pq)      # this rank's amplitudes all have the bit at 0
+                    else:
+                        mask |= 1 << pq
+                if not skip:
+                    self.engine.phase(self.shard, nl, mask, g[3], g[4])
+            else:
+                pc = self.perm[g[3]]
+                if pc >= nl:
+                    if self._rank_bit(pc):
+                        self.engine.camodc(self.shard, nl, self.M_size, g[1], g[2], -1)
+                else:
+                    self.engine.camodc(self.shard, nl, self.M_size, g[1], g[2], pc)
+            if ev0 is not None:
+                ev1.record()
+                self.profile.append((g[0], self.perm[g[1]] if g[0] == "h" else -1, ev0, ev1, exchanged))
+            i += 1
+        self.queue = []
+
+    def synchronize(self):
+        self.flush()
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
 
     # -- gates ----------------------------------------------------------------------------------
     def reset_register(self):
-        self.swapped = False
+        self.queue = []                                   # pending gates act on a state that is being overwritten
+        n = self.num_qubits
+        self.perm, self.inv = list(range(n)), list(range(n))
         self.engine.reset(self.shard, self.n_local, self.rank == 0)
 
     def fill_random(self, seed):
-        self.swapped = False
+        self.queue = []
+        n = self.num_qubits
+        self.perm, self.inv = list(range(n)), list(range(n))
         self.engine.fill_random(self.shard, self.n_local, self.rank << self.n_local, int(seed),
                                 math.sqrt(6.0 / float(self.num_states)))
 
     def hadamard_gate(self, q):
         if not 0 <= q < self.num_qubits:
             raise ValueError("bad qubit")
-        if self.phys(q) >= self.n_local:
-            self._toggle()
-        self.engine.hadamard(self.shard, self.n_local, self.phys(q))
+        self._push(("h", q))
 
     def c_phase_shift_gate(self, c, t, theta):
         if c == t or not (0 <= c < self.num_qubits and 0 <= t < self.num_qubits):
             raise ValueError("bad qubit")
-        mask = 0
-        for pq in (self.phys(c), self.phys(t)):
-            if pq >= self.n_local:
-                if not self._rank_bit(pq):
-                    return                        # this rank's amplitudes all have the bit at 0
-            else:
-                mask |= 1 << pq
-        self.engine.phase(self.shard, self.n_local, mask, 1.0 * math.cos(theta), 1.0 * math.sin(theta))
+        self._push(("p", c, t, 1.0 * math.cos(theta), 1.0 * math.sin(theta)))
 
     def c_amodc_gate(self, Cn, atox, ctl):
         if not 0 <= ctl < self.num_qubits:
             raise ValueError("bad qubit")
-        pc = self.phys(ctl)
-        if pc >= self.n_local:
-            if not self._rank_bit(pc):
-                return
-            pc = -1
-        self.engine.camodc(self.shard, self.n_local, self.M_size, Cn, int(atox % Cn), pc)
+        self._push(("c", int(Cn), int(atox % Cn), ctl))
 
     def inverse_QFT(self):                               # qc_shor.c:678-690
         for l in range(self.L_size + self.M_size - 1, self.M_size - 1, -1):
@@ -186,6 +313,7 @@ class ShardedRegister:
 
     # -- measurement, reductions, read-back ---------------------------------------------------------
     def norm2(self):
+        self.flush()
         t = torch.tensor([self.engine.norm2(self.shard, self.n_local)], dtype=torch.float64, device=self.device)
         dist.all_reduce(t, group=self.group)
         return float(t.item())
@@ -196,7 +324,7 @@ class ShardedRegister:
         self._identity()
         last_excluded = self.num_states - 1
         msg = torch.zeros(3, dtype=torch.float64, device=self.device)
-        cum, found, idx = 0.0, False, last_excluded
+        cum, idx = 0.0, last_excluded
         for rk in range(self.world):
             if self.rank == rk:
                 f, i, cum_out = self.engine.measure_scan(self.shard, self.n_local, rk << self.n_local, last_excluded, cum, float(r))
@@ -205,7 +333,7 @@ class ShardedRegister:
             m = msg.tolist()
             cum = m[2]
             if m[0] != 0.0:
-                found, idx = True, int(m[1])
+                idx = int(m[1])
                 break
         owner = idx >> self.n_local
         self.engine.collapse(self.shard, self.n_local, idx & ((1 << self.n_local) - 1) if owner == self.rank else -1)

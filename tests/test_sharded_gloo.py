@@ -55,6 +55,14 @@ class OracleEngine:
             new[:, d, :] += v[:, f, :]
         v[...] = new
 
+    def swap_bits(self, src, dst, n_local, pos_a, pos_b):
+        j = np.arange(1 << n_local, dtype=np.int64)
+        i = j.copy()
+        for a, b in zip(pos_a, pos_b):                 # applied to the index in array order, like the kernel
+            x = ((i >> a) ^ (i >> b)) & 1
+            i ^= (x << a) | (x << b)
+        dst.numpy().reshape(-1, 2)[...] = src.numpy().reshape(-1, 2)[i]
+
     def norm2(self, t, n_local):
         return self.ob.norm2(t.numpy(), n_local)
 
@@ -114,10 +122,11 @@ def sc_hadamard_sweep(rank, world, ob, make):
     reg = make(n, 0)
     reg.fill_random(5)
     want = ob.fill_random(n, 5)
-    for rep in range(2):                       # second sweep starts in the swapped layout
+    for rep in range(2):                       # second sweep starts in a permuted layout
         for qb in range(n):
             reg.hadamard_gate(qb)
             ob.hadamard(want, n, qb)
+    reg.flush()
     exchanges = reg.exchanges              # before gather() restores the identity layout
     got = reg.gather()
     return bool(np.array_equal(bits(got), bits(want))), exchanges
@@ -174,7 +183,7 @@ def sc_measure_edges(rank, world, ob, make):
         reg.fill_random(21)
         want = ob.fill_random(n, 21)
         res.append((reg.measure_state(r), ob.measure(want, n, r)))
-    reg.reset_register()                        # all weight on index 1: r beyond total probability -> last index
+    reg.reset_register()                        # all-zero state: r beyond total probability -> last index
     reg.engine.collapse(reg.shard, reg.n_local, -1)
     res.append((reg.measure_state(0.5), (1 << n) - 1))
     return res
@@ -184,7 +193,7 @@ def sc_measure_edges(rank, world, ob, make):
 def test_sharded_hadamard_sweep(world):
     same, exchanges = run(world, sc_hadamard_sweep)
     assert same
-    assert exchanges == 3          # sweep 1: one all-to-all; sweep 2: back and forth
+    assert exchanges == 2          # look-ahead eviction: ONE all-to-all per sweep
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -208,3 +217,34 @@ def test_sharded_mixed_gates_world4():
 def test_sharded_measure_edges():
     res = run(2, sc_measure_edges)
     assert all(g == w for g, w in res), res
+
+
+def sc_world8(rank, world, ob, make):
+    """8 ranks (k = 3): two H sweeps, then a Shor circuit with seeded measurements"""
+    n = 12
+    reg = make(n, 0)
+    reg.fill_random(31)
+    want = ob.fill_random(n, 31)
+    for rep in range(2):
+        for qb in range(n):
+            reg.hadamard_gate(qb); ob.hadamard(want, n, qb)
+    reg.flush()
+    ex = reg.exchanges
+    ok = bool(np.array_equal(bits(reg.gather()), bits(want)))
+    L, M, Cn, a = 9, 4, 15, 7
+    reg2 = make(L, M)
+    reg2.reset_register(); reg2.quantum_computation(Cn, a)
+    w2 = np.zeros(2 << (L + M)); ob.reset(w2, L + M); ob.quantum_computation(w2, L + M, M, Cn, a)
+    reg2.flush()
+    ex2 = reg2.exchanges
+    ok = ok and bool(np.array_equal(bits(reg2.gather()), bits(w2)))
+    r = 0.6180339887
+    ok = ok and reg2.measure_state(r) == ob.measure(w2, L + M, r)
+    return ok, ex, ex2
+
+
+def test_sharded_world8():
+    ok, ex, ex2 = run(8, sc_world8)
+    assert ok
+    assert ex == 2             # one exchange per sweep
+    assert ex2 <= 3            # whole Shor circuit: the top qubits are traded in once and out once

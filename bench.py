@@ -174,15 +174,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         prof, reg.profile = reg.profile, None
-        # per physical target position: durations of the Hadamard launches that did not carry an exchange
+        # Hadamard launches by physical target position; a launch on a slice moves 32 * 2^bits bytes
         per_q_ms = [[] for _ in range(n)]
-        exch_ms = []
-        for kind, pq, e0, e1, exchanged in prof:
+        h_bytes, h_ms = 0.0, 0.0
+        for kind, pq, e0, e1, bits_ in prof:
+            if kind != "h":
+                continue
             ms = e0.elapsed_time(e1)
-            if exchanged:
-                exch_ms.append(ms)
-            elif kind == "h":
-                per_q_ms[pq].append(ms)
+            h_bytes += 32.0 * float(1 << bits_); h_ms += ms
+            per_q_ms[pq].append(ms * float(1 << (args.n_local - bits_)))      # scaled to a whole-shard launch
+        exch_ms = []
+        overlapped = reg.overlapped_gates
         norm = reg.norm2()
         exchanges = reg.exchanges - ex0
         fused = None
@@ -211,7 +213,7 @@ def main():
                        "qubits": n, "gates_per_step": gates_per_step, "shard_qubits": args.n_local,
                        "parallelism": "1 GPU" if args.gpus == 1 else f"state sharded by top {k} qubits over {args.gpus} ranks, "
                                       f"all-to-all qubit remap for global targets ({exchanges} exchanges in the {args.steps} timed sweeps"
-                                      + (f", mean {sum(exch_ms) / len(exch_ms):.1f} ms per exchange+gate)" if args.gpus > 1 and exch_ms else ")")},
+                                      + (f", exchange overlapped with the neighbouring gates on {1 << reg.sigma} slices)" if args.gpus > 1 or args.force_sharded else ")")},
             "hbm_gbs_sweep_average": args.steps * gates_per_step * bytes_per_launch * args.gpus / dt / 1e9,
             "roofline": {"bound": "hbm", "kernel": "qcx::k_h_pair (Hadamard, pair form, target qubit >= 3)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

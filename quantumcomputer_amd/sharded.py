@@ -25,6 +25,7 @@ exercised on CPU with the gloo backend in tests.
 """
 import ctypes as C
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -90,7 +91,7 @@ class HipEngine:
 class ShardedRegister:
     """Register (qc_shor.c:194-203) sharded by its top log2(world) physical index bits."""
 
-    def __init__(self, L_size, M_size, device=None, group=None, engine=None, max_queue=8192):
+    def __init__(self, L_size, M_size, device=None, group=None, engine=None, max_queue=8192, slices_log2=None):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -102,9 +103,22 @@ class ShardedRegister:
         self.num_qubits = n = self.L_size + self.M_size
         self.num_states = 1 << n
         self.n_local = n - k
-        self.min_evict = max(MIN_EVICT_POS if self.n_local - 2 * k >= MIN_EVICT_POS else 0, self.M_size)
+        # sigma spectator bits -> 2^sigma slices for the overlapped exchange (QCX_SHARD_SLICES_LOG2, default 2)
+        sigma = int(os.environ.get("QCX_SHARD_SLICES_LOG2", "2")) if slices_log2 is None else int(slices_log2)
+        if not k:
+            sigma = 0
+        while True:
+            self.min_evict = max(MIN_EVICT_POS if self.n_local - sigma - 2 * k >= MIN_EVICT_POS else 0, self.M_size)
+            if sigma == 0 or self.n_local - sigma - self.min_evict >= 2 * k:
+                break
+            sigma -= 1
         if self.n_local < 1 or (k and self.n_local - self.min_evict < 2 * k):
             raise ValueError("register too small for this many ranks (need n_local - max(M, 6) >= 2 log2(world))")
+        self.sigma = sigma
+        self.slice_bits = self.n_local - sigma
+        self.zone_lo = self.slice_bits - k
+        self.overlap = os.environ.get("QCX_SHARD_OVERLAP", "1") != "0"
+        self.overlapped_gates = 0
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = torch.device(device)
@@ -134,44 +148,71 @@ class ShardedRegister:
         self.perm[logical] = pos
         self.inv[pos] = logical
 
-    def _apply_local_swaps(self, swaps):
-        """swaps = index-bit transpositions (a, b) in APPLICATION order (data at index i moves to the index
-        with bits a and b exchanged).  One out-of-place pass per 8 transpositions."""
+    # -- slices ---------------------------------------------------------------------------------
+    # physical local index bits:  [ 0 .. zone_lo )  [ zone_lo .. slice_bits ) = trade zone (k bits)
+    #                             [ slice_bits .. n_local ) = spectator bits (sigma bits, never traded)
+    # A slice = fixed spectator bits = one contiguous 2^slice_bits range of the shard.  The exchange with the
+    # rank id is done slice by slice (pack -> all-to-all), which lets the gates before/after it run on the
+    # slices that are not in flight: exchange and compute overlap.
+    def _views(self, buf):
+        w = 2 << self.slice_bits
+        return [buf[s * w:(s + 1) * w] for s in range(1 << self.sigma)]
+
+    def _plan_give(self, give):
+        """transpositions (application order) that bring local position give[j] to trade-zone slot j"""
+        pos, swaps = list(give), []
+        for j in range(self.k):
+            t, p = self.zone_lo + j, pos[j]
+            if p != t:
+                swaps.append((p, t))
+                for jj in range(j + 1, self.k):
+                    if pos[jj] == t:
+                        pos[jj] = p
+        return swaps
+
+    def _book(self, swaps, trade):
+        for a, b in swaps:
+            la, lb = self.inv[a], self.inv[b]
+            self._set_phys(la, b); self._set_phys(lb, a)
+        if trade:
+            for j in range(self.k):
+                lt, lr = self.inv[self.zone_lo + j], self.inv[self.n_local + j]
+                self._set_phys(lt, self.n_local + j); self._set_phys(lr, self.zone_lo + j)
+
+    def _move_slice(self, sidx, swaps, src_buf, dst_buf, async_op):
+        """pack (optional) + all-to-all of one slice; returns (work, buffer holding the result)"""
+        src, dst = self._views(src_buf)[sidx], self._views(dst_buf)[sidx]
+        if swaps:
+            rev = list(reversed(swaps))            # dst[j] = src[s_1(...s_m(j))]: kernel applies its list in array order
+            self.engine.swap_bits(src, dst, self.slice_bits, [x[0] for x in rev], [x[1] for x in rev])
+            src, dst, out = dst, src, src_buf
+        else:
+            out = dst_buf
+        work = dist.all_to_all_single(dst, src, group=self.group, async_op=async_op)
+        return work, out
+
+    def _trade_now(self, give):
+        """whole-shard exchange without any overlap (used when restoring the identity layout)"""
+        swaps = self._plan_give(give)
+        src_buf, dst_buf = self.bufs[self.cur], self.bufs[self.cur ^ 1]
+        for sidx in range(1 << self.sigma):
+            self._move_slice(sidx, swaps, src_buf, dst_buf, False)
+        if not swaps:                      # with a pack pass the data travels there and back: same buffer
+            self.cur ^= 1
+        self._book(swaps, True)
+        self.exchanges += 1
+        self.pack_passes += 1 if swaps else 0
+
+    def _local_permute(self, swaps):
+        """transpositions among local positions on the whole shard (8 per out-of-place pass)"""
         for lo in range(0, len(swaps), 8):
             part = swaps[lo:lo + 8]
             src, dst = self.bufs[self.cur], self.bufs[self.cur ^ 1]
-            # dst[j] = src[s_1(s_2(...s_m(j)))]: the kernel applies its list to the index in array order
             rev = list(reversed(part))
             self.engine.swap_bits(src, dst, self.n_local, [x[0] for x in rev], [x[1] for x in rev])
             self.cur ^= 1
             self.pack_passes += 1
-            for a, b in part:
-                la, lb = self.inv[a], self.inv[b]
-                self._set_phys(la, b); self._set_phys(lb, a)
-
-    def _trade(self, give):
-        """exchange the k rank bits with k local positions: the qubit at local position give[j] ends up in
-        rank bit j, the qubit of rank bit j at local position n_local - k + j.
-          pack  : transpositions bringing give[j] to top slot j (out of place = the send buffer fill)
-          trade : one all_to_all_single of equal chunks (chunk c of rank r <-> chunk r of rank c)"""
-        k, nl = self.k, self.n_local
-        pos = list(give)
-        swaps = []
-        for j in range(k):
-            t, p = nl - k + j, pos[j]
-            if p != t:
-                swaps.append((p, t))
-                for jj in range(j + 1, k):
-                    if pos[jj] == t:
-                        pos[jj] = p
-        self._apply_local_swaps(swaps)
-        src, dst = self.bufs[self.cur], self.bufs[self.cur ^ 1]
-        dist.all_to_all_single(dst, src, group=self.group)
-        self.cur ^= 1
-        self.exchanges += 1
-        for j in range(k):
-            lt, lr = self.inv[nl - k + j], self.inv[nl + j]
-            self._set_phys(lt, nl + j); self._set_phys(lr, nl - k + j)
+            self._book(part, False)
 
     def _next_use(self, logical, start):
         """index in the queue of the next H on `logical` at or after `start` (len(queue) + 1 = never)"""
@@ -181,14 +222,11 @@ class ShardedRegister:
                 return i
         return len(self.queue) + 1
 
-    def _make_local(self, q, at):
-        """bring logical qubit q (and with it every qubit of the rank id) to local positions, giving up the
-        k local qubits whose next use as an H target lies furthest ahead in the queue (Belady)"""
-        nl, k = self.n_local, self.k
-        cand = list(range(self.min_evict, nl))
+    def _choose_give(self, at):
+        """the k local positions (outside the spectator bits) whose qubits are H targets latest (Belady)"""
+        cand = list(range(self.min_evict, self.slice_bits))
         cand.sort(key=lambda p: (-self._next_use(self.inv[p], at), -p))
-        self._trade(sorted(cand[:k]))
-        assert self.perm[q] < nl
+        return sorted(cand[:self.k])
 
     def _identity(self):
         """restore logical == physical (the order measurement and read-back need)"""
@@ -201,12 +239,10 @@ class ShardedRegister:
             if any(self.perm[g] >= nl for g in G):
                 # some rightful rank-id qubits sit in the rank id but in the wrong slot / beside strangers:
                 # one trade brings the whole rank id local (giving up positions that hold none of G)
-                cand = [p for p in range(nl - 1, self.min_evict - 1, -1) if self.inv[p] not in G][:k]
-                self._trade(cand)
-            self._trade([self.perm[nl + j] for j in range(k)])         # rank bit j <- logical qubit nl + j
-        swaps = []
-        perm = list(self.perm)
-        inv = list(self.inv)
+                cand = [p for p in range(self.slice_bits - 1, self.min_evict - 1, -1) if self.inv[p] not in G][:k]
+                self._trade_now(cand)
+            self._trade_now([self.perm[nl + j] for j in range(k)])     # rank bit j <- logical qubit nl + j
+        swaps, perm, inv = [], list(self.perm), list(self.inv)
         for q in range(nl):
             a = perm[q]
             if a != q:
@@ -214,7 +250,7 @@ class ShardedRegister:
                 other = inv[q]
                 perm[q], perm[other] = q, a
                 inv[q], inv[a] = q, other
-        self._apply_local_swaps(swaps)
+        self._local_permute(swaps)
         assert self.perm == list(range(n)), self.perm
 
     # -- queue ----------------------------------------------------------------------------------
@@ -223,42 +259,104 @@ class ShardedRegister:
         if len(self.queue) >= self.max_queue:
             self.flush()
 
+    def _resolve(self, g):
+        """queue entry -> physical operation under the CURRENT layout"""
+        if g[0] == "h":
+            return ("h", self.perm[g[1]])
+        if g[0] == "p":
+            return ("p", self.perm[g[1]], self.perm[g[2]], g[3], g[4])
+        return ("c", g[1], g[2], self.perm[g[3]])
+
+    def _bit_outside(self, pq, nbits, sidx):
+        """value of physical index bit pq >= nbits for the amplitudes of this view: spectator bit of the slice
+        or bit of the rank id"""
+        if pq >= self.n_local:
+            return (self.rank >> (pq - self.n_local)) & 1
+        return (sidx >> (pq - nbits)) & 1
+
+    def _run(self, op, view, nbits, sidx):
+        """execute one resolved operation on `view` = 2^nbits consecutive amplitudes of the shard"""
+        ev0 = None
+        if self.profile is not None and self.device.type == "cuda":
+            ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True); ev0.record()
+        if op[0] == "h":
+            assert op[1] < nbits
+            self.engine.hadamard(view, nbits, op[1])
+        elif op[0] == "p":
+            mask, skip = 0, False
+            for pq in (op[1], op[2]):
+                if pq >= nbits:
+                    skip = skip or not self._bit_outside(pq, nbits, sidx)   # all amplitudes here have the bit at 0
+                else:
+                    mask |= 1 << pq
+            if not skip:
+                self.engine.phase(view, nbits, mask, op[3], op[4])
+        else:
+            pc = op[3]
+            if pc >= nbits:
+                if self._bit_outside(pc, nbits, sidx):
+                    self.engine.camodc(view, nbits, self.M_size, op[1], op[2], -1)
+            else:
+                self.engine.camodc(view, nbits, self.M_size, op[1], op[2], pc)
+        if ev0 is not None:
+            ev1.record()
+            self.profile.append((op[0], op[1] if op[0] == "h" else -1, ev0, ev1, nbits))
+
+    def _sliceable(self, g):
+        """may this queued gate run slice by slice under the current layout?  (an H must not target a spectator
+        bit, nor a qubit of the rank id)"""
+        return g[0] != "h" or self.perm[g[1]] < self.slice_bits
+
     def flush(self):
         if not self.queue:
             return
-        queue, i = self.queue, 0
-        nl = self.n_local
-        while i < len(queue):
-            g = queue[i]
-            ev0 = None
-            if self.profile is not None and self.device.type == "cuda":
-                ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True); ev0.record()
-            exchanged = False
-            if g[0] == "h":
-                if self.perm[g[1]] >= nl:
-                    self._make_local(g[1], i)
-                    exchanged = True
-                self.engine.hadamard(self.shard, nl, self.perm[g[1]])
-            elif g[0] == "p":
-                mask, skip = 0, False
-                for pq in (self.perm[g[1]], self.perm[g[2]]):
-                    if pq >= nl:
-                        skip = skip or not self._rank_bit(pq)      # this rank's amplitudes all have the bit at 0
-                    else:
-                        mask |= 1 << pq
-                if not skip:
-                    self.engine.phase(self.shard, nl, mask, g[3], g[4])
-            else:
-                pc = self.perm[g[3]]
-                if pc >= nl:
-                    if self._rank_bit(pc):
-                        self.engine.camodc(self.shard, nl, self.M_size, g[1], g[2], -1)
-                else:
-                    self.engine.camodc(self.shard, nl, self.M_size, g[1], g[2], pc)
-            if ev0 is not None:
-                ev1.record()
-                self.profile.append((g[0], self.perm[g[1]] if g[0] == "h" else -1, ev0, ev1, exchanged))
-            i += 1
+        q, nl, S = self.queue, self.n_local, 1 << self.sigma
+        i = 0
+        while i < len(q):
+            x = next((j for j in range(i, len(q)) if q[j][0] == "h" and self.perm[q[j][1]] >= nl), None)
+            if x is None:
+                for g in q[i:]:
+                    self._run(self._resolve(g), self.shard, nl, 0)
+                break
+            # gates that can share the pipeline with the exchange at x: a run before it ...
+            a = x
+            if S > 1 and self.overlap:
+                while a > i and self._sliceable(q[a - 1]):
+                    a -= 1
+            for g in q[i:a]:
+                self._run(self._resolve(g), self.shard, nl, 0)
+            pre_ops = [self._resolve(g) for g in q[a:x]]            # resolved under the layout before the trade
+            swaps = self._plan_give(self._choose_give(x))
+            self._book(swaps, True)
+            # ... and a run after it, under the new layout
+            b = x
+            while b < len(q) and self._sliceable(q[b]) and not (q[b][0] == "h" and self.perm[q[b][1]] >= nl):
+                b += 1
+                if not (S > 1 and self.overlap) and b > x:           # no overlap: only the gate that needed the trade
+                    break
+            post_ops = [self._resolve(g) for g in q[x:b]]
+            src_buf, dst_buf = self.bufs[self.cur], self.bufs[self.cur ^ 1]
+            src_views = self._views(src_buf)
+            works, outs = [None] * S, [None] * S
+            for sidx in range(S):
+                for op in pre_ops:
+                    self._run(op, src_views[sidx], self.slice_bits, sidx)
+                works[sidx], outs[sidx] = self._move_slice(sidx, swaps, src_buf, dst_buf, True)
+                if sidx >= 1:
+                    works[sidx - 1].wait()
+                    view = self._views(outs[sidx - 1])[sidx - 1]
+                    for op in post_ops:
+                        self._run(op, view, self.slice_bits, sidx - 1)
+            works[S - 1].wait()
+            view = self._views(outs[S - 1])[S - 1]
+            for op in post_ops:
+                self._run(op, view, self.slice_bits, S - 1)
+            if outs[0] is dst_buf:
+                self.cur ^= 1
+            self.exchanges += 1
+            self.pack_passes += 1 if swaps else 0
+            self.overlapped_gates += len(pre_ops) + len(post_ops)
+            i = b
         self.queue = []
 
     def synchronize(self):

@@ -88,7 +88,7 @@ def _worker(rank, world, port, scenario, q):
     try:
         from oracle import binding as ob
         from quantumcomputer_amd.sharded import ShardedRegister
-        out = scenario(rank, world, ob, lambda L, M: ShardedRegister(L, M, device="cpu", engine=OracleEngine()))
+        out = scenario(rank, world, ob, lambda L, M, **kw: ShardedRegister(L, M, device="cpu", engine=OracleEngine(), **kw))
         if rank == 0:
             q.put(("ok", out))
     except Exception as e:      # pragma: no cover
@@ -248,3 +248,30 @@ def test_sharded_world8():
     assert ok
     assert ex == 2             # one exchange per sweep
     assert ex2 <= 3            # whole Shor circuit: the top qubits are traded in once and out once
+
+
+def sc_slice_counts(rank, world, ob, make):
+    """the overlapped exchange with 1, 2, 4 and 8 slices, long and short queues: always the oracle's bits"""
+    n = 11
+    res = []
+    for sl in (0, 1, 2, 3):
+        for max_queue in (8192, 5):                 # 5: the queue is flushed mid-sweep (short look-ahead)
+            reg = make(n, 0, slices_log2=sl, max_queue=max_queue)
+            reg.fill_random(40 + sl)
+            want = ob.fill_random(n, 40 + sl)
+            for rep in range(2):
+                for qb in list(range(n)) + [n - 1, 3, n - 2]:
+                    reg.hadamard_gate(qb); ob.hadamard(want, n, qb)
+                reg.c_phase_shift_gate(n - 1, 2, 0.3); ob.cphase(want, n, n - 1, 2, 0.3)
+                reg.c_phase_shift_gate(n - 2, n - 3, 1.3); ob.cphase(want, n, n - 2, n - 3, 1.3)
+            reg.flush()
+            ov = reg.overlapped_gates
+            res.append((sl, max_queue, reg.sigma, bool(np.array_equal(bits(reg.gather()), bits(want))), ov))
+    return res
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_overlap_slice_counts(world):
+    res = run(world, sc_slice_counts)
+    assert all(r[3] for r in res), res
+    assert any(r[2] >= 2 and r[4] > 10 for r in res)      # real overlap windows were exercised

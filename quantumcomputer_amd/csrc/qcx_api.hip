@@ -205,40 +205,40 @@ extern "C" int qcx_shard_fill_random(void *amp, unsigned n_local, uint64_t first
 }
 
 template <int PPT, bool NTL, bool NTS, bool WC, int BLOCK>
-static void launch_h_pair(amp_t *a, unsigned q, uint64_t npairs, hipStream_t st)
+static void launch_h_pair(const Tune &t, amp_t *a, unsigned q, uint64_t npairs, hipStream_t st)
 {
-    const unsigned grid = grid_for(npairs, BLOCK * PPT, g_tune.h_grid_cap);
+    const unsigned grid = grid_for(npairs, BLOCK * PPT, t.h_grid_cap);
     // stream-interleaved tile order only for an uncapped power-of-two grid that divides evenly
     unsigned glog = 0, slog = 0;
     if ((grid & (grid - 1)) == 0 && (uint64_t)grid * (BLOCK * PPT) == npairs) {
         glog = 31u - (unsigned)__builtin_clz(grid);
-        if (g_tune.h_streams_log2 > 0 && (unsigned)g_tune.h_streams_log2 <= glog) slog = (unsigned)g_tune.h_streams_log2;
+        if (t.h_streams_log2 > 0 && (unsigned)t.h_streams_log2 <= glog) slog = (unsigned)t.h_streams_log2;
     }
     hipLaunchKernelGGL((k_h_pair<PPT, NTL, NTS, WC, BLOCK>), dim3(grid), dim3(BLOCK), 0, st, a, q, npairs, glog, slog);
 }
 
 template <int PPT, int BLOCK>
-static void launch_h_pair_flags(amp_t *a, unsigned q, uint64_t npairs, hipStream_t st, long nt, bool wc)
+static void launch_h_pair_flags(const Tune &t, amp_t *a, unsigned q, uint64_t npairs, hipStream_t st, long nt, bool wc)
 {
     const int f = (int)(nt & 3) | (wc ? 4 : 0);
     switch (f) {
-    case 0: launch_h_pair<PPT, false, false, false, BLOCK>(a, q, npairs, st); break;
-    case 3: launch_h_pair<PPT, true, true, false, BLOCK>(a, q, npairs, st); break;
-    case 4: launch_h_pair<PPT, false, false, true, BLOCK>(a, q, npairs, st); break;
-    case 7: launch_h_pair<PPT, true, true, true, BLOCK>(a, q, npairs, st); break;
-    case 1: case 5: launch_h_pair<PPT, true, false, false, BLOCK>(a, q, npairs, st); break;
-    default: launch_h_pair<PPT, false, true, false, BLOCK>(a, q, npairs, st); break;
+    case 0: launch_h_pair<PPT, false, false, false, BLOCK>(t, a, q, npairs, st); break;
+    case 3: launch_h_pair<PPT, true, true, false, BLOCK>(t, a, q, npairs, st); break;
+    case 4: launch_h_pair<PPT, false, false, true, BLOCK>(t, a, q, npairs, st); break;
+    case 7: launch_h_pair<PPT, true, true, true, BLOCK>(t, a, q, npairs, st); break;
+    case 1: case 5: launch_h_pair<PPT, true, false, false, BLOCK>(t, a, q, npairs, st); break;
+    default: launch_h_pair<PPT, false, true, false, BLOCK>(t, a, q, npairs, st); break;
     }
 }
 
 template <int PPT>
-static void launch_h_pair_block(amp_t *a, unsigned q, uint64_t npairs, hipStream_t st, long nt, bool wc)
+static void launch_h_pair_block(const Tune &t, amp_t *a, unsigned q, uint64_t npairs, hipStream_t st, long nt, bool wc)
 {
-    switch (g_tune.h_block) {
-    case 64:  launch_h_pair_flags<PPT, 64>(a, q, npairs, st, nt, wc); break;
-    case 128: launch_h_pair_flags<PPT, 128>(a, q, npairs, st, nt, wc); break;
-    case 512: launch_h_pair_flags<PPT, 512>(a, q, npairs, st, nt, wc); break;
-    default:  launch_h_pair_flags<PPT, 256>(a, q, npairs, st, nt, wc); break;
+    switch (t.h_block) {
+    case 64:  launch_h_pair_flags<PPT, 64>(t, a, q, npairs, st, nt, wc); break;
+    case 128: launch_h_pair_flags<PPT, 128>(t, a, q, npairs, st, nt, wc); break;
+    case 512: launch_h_pair_flags<PPT, 512>(t, a, q, npairs, st, nt, wc); break;
+    default:  launch_h_pair_flags<PPT, 256>(t, a, q, npairs, st, nt, wc); break;
     }
 }
 
@@ -252,43 +252,43 @@ static void stream_map(unsigned grid, uint64_t covered, uint64_t total, long wan
 }
 
 template <int Q, int R, bool NTL, bool NTS>
-static void launch_h_wave_q(amp_t *a, uint64_t namps, hipStream_t st)
+static void launch_h_wave_q(const Tune &t, amp_t *a, uint64_t namps, hipStream_t st)
 {
     const uint64_t ntiles = namps / (64 * R);
     unsigned glog, slog;
-    if (g_tune.h_wave_block == 64) {
-        const unsigned grid = grid_for(ntiles, 1, g_tune.h_grid_cap);
-        stream_map(grid, grid, ntiles, g_tune.h_streams_log2, &glog, &slog);
+    if (t.h_wave_block == 64) {
+        const unsigned grid = grid_for(ntiles, 1, t.h_grid_cap);
+        stream_map(grid, grid, ntiles, t.h_streams_log2, &glog, &slog);
         hipLaunchKernelGGL((k_h_wave<Q, R, NTL, NTS, 64>), dim3(grid), dim3(64), 0, st, a, ntiles, glog, slog);
     } else {
-        const unsigned grid = grid_for(ntiles, 4 /* waves per 256-thread block */, g_tune.h_grid_cap);
-        stream_map(grid, (uint64_t)grid * 4, ntiles, g_tune.h_streams_log2, &glog, &slog);
+        const unsigned grid = grid_for(ntiles, 4 /* waves per 256-thread block */, t.h_grid_cap);
+        stream_map(grid, (uint64_t)grid * 4, ntiles, t.h_streams_log2, &glog, &slog);
         hipLaunchKernelGGL((k_h_wave<Q, R, NTL, NTS, 256>), dim3(grid), dim3(256), 0, st, a, ntiles, glog, slog);
     }
 }
 
 template <int R, bool NTL, bool NTS>
-static bool launch_h_wave(amp_t *a, unsigned q, uint64_t namps, hipStream_t st)
+static bool launch_h_wave(const Tune &t, amp_t *a, unsigned q, uint64_t namps, hipStream_t st)
 {
     switch (q) {
-    case 0: launch_h_wave_q<0, R, NTL, NTS>(a, namps, st); return true;
-    case 1: launch_h_wave_q<1, R, NTL, NTS>(a, namps, st); return true;
-    case 2: launch_h_wave_q<2, R, NTL, NTS>(a, namps, st); return true;
-    case 3: launch_h_wave_q<3, R, NTL, NTS>(a, namps, st); return true;
-    case 4: launch_h_wave_q<4, R, NTL, NTS>(a, namps, st); return true;
-    case 5: launch_h_wave_q<5, R, NTL, NTS>(a, namps, st); return true;
-    case 6: launch_h_wave_q<6, R, NTL, NTS>(a, namps, st); return true;
-    case 7: if constexpr (R >= 4) { launch_h_wave_q<7, R, NTL, NTS>(a, namps, st); return true; } return false;
-    case 8: if constexpr (R >= 8) { launch_h_wave_q<8, R, NTL, NTS>(a, namps, st); return true; } return false;
+    case 0: launch_h_wave_q<0, R, NTL, NTS>(t, a, namps, st); return true;
+    case 1: launch_h_wave_q<1, R, NTL, NTS>(t, a, namps, st); return true;
+    case 2: launch_h_wave_q<2, R, NTL, NTS>(t, a, namps, st); return true;
+    case 3: launch_h_wave_q<3, R, NTL, NTS>(t, a, namps, st); return true;
+    case 4: launch_h_wave_q<4, R, NTL, NTS>(t, a, namps, st); return true;
+    case 5: launch_h_wave_q<5, R, NTL, NTS>(t, a, namps, st); return true;
+    case 6: launch_h_wave_q<6, R, NTL, NTS>(t, a, namps, st); return true;
+    case 7: if constexpr (R >= 4) { launch_h_wave_q<7, R, NTL, NTS>(t, a, namps, st); return true; } return false;
+    case 8: if constexpr (R >= 8) { launch_h_wave_q<8, R, NTL, NTS>(t, a, namps, st); return true; } return false;
     default: return false;
     }
 }
 
 template <int R>
-static bool launch_h_wave_flags(amp_t *a, unsigned q, uint64_t namps, hipStream_t st, long nt)
+static bool launch_h_wave_flags(const Tune &t, amp_t *a, unsigned q, uint64_t namps, hipStream_t st, long nt)
 {
-    if ((nt & 3) == 3) return launch_h_wave<R, true, true>(a, q, namps, st);
-    return launch_h_wave<R, false, false>(a, q, namps, st);
+    if ((nt & 3) == 3) return launch_h_wave<R, true, true>(t, a, q, namps, st);
+    return launch_h_wave<R, false, false>(t, a, q, namps, st);
 }
 
 // Launch plan per target qubit, measured on MI355X (tools/tune_h.py, profiles/r01_tune_h_*.json).
@@ -320,38 +320,37 @@ extern "C" int qcx_shard_hadamard(void *amp, unsigned n_local, unsigned q, void 
     amp_t *a = (amp_t *)amp;
     const uint64_t namps = (uint64_t)1 << n_local, npairs = namps >> 1;
 
-    Tune saved = g_tune;
-    if (g_tune.h_variant == 0) {                     // auto: the measured plan
+    Tune t = g_tune;                                 // local copy: the entry point is re-entrant
+    if (t.h_variant == 0) {                          // auto: the measured plan
         const HPlan pl = h_plan(q);
-        g_tune.h_variant = pl.wave_form ? 2 : 1;
-        g_tune.h_wave_r = 2; g_tune.h_wave_block = pl.block;
-        g_tune.h_ppt = pl.ppt; g_tune.h_block = pl.block;
-        g_tune.h_streams_log2 = pl.slog; g_tune.h_nt = 3; g_tune.h_wc = 0; g_tune.h_grid_cap = 0;
+        t.h_variant = pl.wave_form ? 2 : 1;
+        t.h_wave_r = 2; t.h_wave_block = pl.block;
+        t.h_ppt = pl.ppt; t.h_block = pl.block;
+        t.h_streams_log2 = pl.slog; t.h_nt = 3; t.h_wc = 0; t.h_grid_cap = 0;
     }
     int status = QCX_NO_ERROR;
     bool launched = false;
     // wave-tile form: needs whole 64*R tiles and the partner inside the tile
-    const int R = (g_tune.h_wave_r >= 8) ? 8 : (g_tune.h_wave_r >= 4 ? 4 : 2);
+    const int R = (t.h_wave_r >= 8) ? 8 : (t.h_wave_r >= 4 ? 4 : 2);
     const unsigned tile_bits = (R == 8) ? 9 : (R == 4 ? 8 : 7);
-    if (g_tune.h_variant == 2 && q < tile_bits && n_local >= tile_bits + 2) {
-        launched = (R == 8) ? launch_h_wave_flags<8>(a, q, namps, st, g_tune.h_nt)
-                 : (R == 4) ? launch_h_wave_flags<4>(a, q, namps, st, g_tune.h_nt)
-                            : launch_h_wave_flags<2>(a, q, namps, st, g_tune.h_nt);
+    if (t.h_variant == 2 && q < tile_bits && n_local >= tile_bits + 2) {
+        launched = (R == 8) ? launch_h_wave_flags<8>(t, a, q, namps, st, t.h_nt)
+                 : (R == 4) ? launch_h_wave_flags<4>(t, a, q, namps, st, t.h_nt)
+                            : launch_h_wave_flags<2>(t, a, q, namps, st, t.h_nt);
     }
     if (!launched) {
-        long ppt = g_tune.h_ppt;
+        long ppt = t.h_ppt;
         while (ppt > 1 && npairs < (uint64_t)512 * (uint64_t)ppt) ppt >>= 1;
         // nontemporal accesses only pay when a wave-instruction covers whole 128-B lines (q >= 3)
-        const long nt = (q >= 3) ? g_tune.h_nt : 0;
-        const bool wc = g_tune.h_wc != 0;
+        const long nt = (q >= 3) ? t.h_nt : 0;
+        const bool wc = t.h_wc != 0;
         switch (ppt) {
-        case 8: launch_h_pair_block<8>(a, q, npairs, st, nt, wc); break;
-        case 4: launch_h_pair_block<4>(a, q, npairs, st, nt, wc); break;
-        case 2: launch_h_pair_block<2>(a, q, npairs, st, nt, wc); break;
-        default: launch_h_pair_block<1>(a, q, npairs, st, nt, wc); break;
+        case 8: launch_h_pair_block<8>(t, a, q, npairs, st, nt, wc); break;
+        case 4: launch_h_pair_block<4>(t, a, q, npairs, st, nt, wc); break;
+        case 2: launch_h_pair_block<2>(t, a, q, npairs, st, nt, wc); break;
+        default: launch_h_pair_block<1>(t, a, q, npairs, st, nt, wc); break;
         }
     }
-    g_tune = saved;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_last_error, sizeof g_last_error, "hadamard launch: %s", hipGetErrorString(e)); status = QCX_HIP_ERROR; }
     return status;

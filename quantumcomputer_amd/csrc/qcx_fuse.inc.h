@@ -169,7 +169,62 @@ static int fuse_flush(qcx_register *r)
                 memcpy(&o.c, &X, sizeof X);
             }
         }
-        HIP_TRY(hipMemcpyAsync(gq->d_ops, gq->h_ops, nops * sizeof(FuseOp), hipMemcpyHostToDevice, r->stream));
+        size_t nsend = nops;
+        if (g_tune.fuse_rounds && P.T >= 10 && P.T <= 12) {
+            // ROUNDS form: group the list into rounds of at most two distinct H bits (the round's register bits)
+            std::vector<FuseOp> out, cur;
+            std::vector<unsigned> rb;
+            auto close_round = [&]() {
+                if (cur.empty()) { rb.clear(); return; }
+                for (unsigned b = P.T; rb.size() < 2 && b-- > 0;)
+                    if (std::find(rb.begin(), rb.end(), b) == rb.end()) rb.push_back(b);
+                std::sort(rb.begin(), rb.end());
+                FuseOp hdr; memset(&hdr, 0, sizeof hdr);
+                hdr.type = FUSE_ROUND; hdr.a = rb[0] | (rb[1] << 8); hdr.mask = cur.size();
+                out.push_back(hdr);
+                const uint32_t regmask = (1u << rb[0]) | (1u << rb[1]);
+                for (FuseOp o : cur) {
+                    if (o.type == FUSE_H) o.a = (o.a == rb[0]) ? 0u : 1u;
+                    else {
+                        const uint32_t mr = o.a & regmask;
+                        uint32_t rsel = 0;
+                        for (unsigned q = 0; q < 4; q++) {
+                            const uint32_t bits = ((q & 1u) << rb[0]) | ((q >> 1) << rb[1]);
+                            if ((bits & mr) == mr) rsel |= 1u << q;
+                        }
+                        o.a &= ~regmask;
+                        o.type = FUSE_PHASE | (rsel << 8);
+                    }
+                    out.push_back(o);
+                }
+                cur.clear(); rb.clear();
+            };
+            for (size_t k2 = 0; k2 < nops; k2++) {
+                const FuseOp &o = gq->h_ops[k2];
+                if (o.type == FUSE_CAMODC) { close_round(); out.push_back(o); }
+                else if (o.type == FUSE_H) {
+                    if (std::find(rb.begin(), rb.end(), o.a) == rb.end()) {
+                        if (rb.size() == 2) close_round();
+                        rb.push_back(o.a);
+                    }
+                    cur.push_back(o);
+                } else cur.push_back(o);
+            }
+            close_round();
+            nsend = out.size();
+            if (gq->h_cap < nsend) {
+                HIP_TRY(hipHostFree(gq->h_ops)); gq->h_ops = nullptr; gq->h_cap = 0;
+                HIP_TRY(hipHostMalloc(&gq->h_ops, nsend * sizeof(FuseOp))); gq->h_cap = nsend;
+            }
+            if (gq->d_cap < nsend) {
+                HIP_TRY(hipFree(gq->d_ops)); gq->d_ops = nullptr; gq->d_cap = 0;
+                HIP_TRY(hipMalloc(&gq->d_ops, nsend * sizeof(FuseOp))); gq->d_cap = nsend;
+            }
+            memcpy(gq->h_ops, out.data(), nsend * sizeof(FuseOp));
+            P.nops = (uint32_t)nsend;
+            P.cam_ctl_local[0] = 1;
+        }
+        HIP_TRY(hipMemcpyAsync(gq->d_ops, gq->h_ops, nsend * sizeof(FuseOp), hipMemcpyHostToDevice, r->stream));
         const uint64_t ntiles = (uint64_t)1 << (n - P.T);
         const unsigned grid = grid_for(ntiles, 1, g_tune.fuse_grid_cap);
         const size_t lds = (size_t)16 << P.T;

@@ -603,7 +603,7 @@ struct FuseCamExtra {           // overlays c, s of a CAMODC op (16 bytes)
 };
 struct FusePass {
     uint32_t nops, T, c, nh;
-    int32_t  cam_ctl_local[4];  // unused padding / future
+    int32_t  cam_ctl_local[4];  // [0]: 1 = ops are in ROUNDS form (fuse_apply_rounds), 0 = one LDS step per gate
     uint8_t  hbit[16];          // global bit carried by tile-local bit c + j, ascending
 };
 
@@ -701,6 +701,94 @@ __device__ __forceinline__ void fuse_apply_ops(amp_t *tile, const FusePass &P, c
 
 }
 
+// ROUNDS form of the gate list (tiles with exactly 4 amplitudes per thread).  The host cuts the list into
+// rounds; in a round every thread keeps the 4 amplitudes that differ in the round's two REGISTER BITS
+// (rb0 < rb1, tile-local) in registers and applies the whole round to them:
+//   H on a register bit   = butterflies between registers (two H's per LDS round trip: radix 4);
+//   controlled phase      = rotate the registers the host selected (rsel: which of the 4 have the mask's
+//                           register bits set), after ONE test of the remaining local bits per thread and one
+//                           scalar test of the bits outside the tile per tile.
+// Same arithmetic, same order per amplitude as the per-gate kernels.
+enum : uint32_t { FUSE_ROUND = 3 };
+
+__device__ __forceinline__ void rotate_amp(amp_t &v, double cc, double ss)
+{
+    amp_t w;
+    w.x = ((cc * v.x) - (ss * v.y)) + 0.0;
+    w.y = ((cc * v.y) + (ss * v.x)) + 0.0;
+    v = w;
+}
+
+template <int BLOCK, int TT>
+__device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, const FusePass &P, const FuseOp *__restrict__ ops, uint64_t base)
+{
+    static_assert((1u << TT) == 4u * BLOCK, "rounds form needs 4 amplitudes per thread");
+    unsigned i = 0;
+    while (i < P.nops) {
+        const uint32_t type = ops[i].type & 0xffu;
+        if (type == FUSE_ROUND) {
+            const unsigned rb0 = ops[i].a & 0xffu, rb1 = (ops[i].a >> 8) & 0xffu;
+            const unsigned cnt = (unsigned)ops[i].mask;
+            const unsigned p = (unsigned)insert_zero(insert_zero(threadIdx.x, rb0), rb1);
+            const unsigned e1 = p | (1u << rb0), e2 = p | (1u << rb1), e3 = e1 | (1u << rb1);
+            amp_t v0 = tile[p], v1 = tile[e1], v2 = tile[e2], v3 = tile[e3];
+            for (unsigned o = i + 1; o <= i + cnt; o++) {
+                const uint32_t t = ops[o].type;
+                if ((t & 0xffu) == FUSE_H) {
+                    if (ops[o].a == 0) { h_butterfly(v0, v1); h_butterfly(v2, v3); }
+                    else               { h_butterfly(v0, v2); h_butterfly(v1, v3); }
+                } else {
+                    const uint64_t mext = ops[o].mask;
+                    if ((base & mext) != mext) continue;                 // scalar: bits outside the tile
+                    const uint32_t mloc = ops[o].a;
+                    if ((p & mloc) != mloc) continue;                    // one vector test per thread
+                    const uint32_t rsel = (t >> 8) & 0xfu;
+                    const double cc = ops[o].c, ss = ops[o].s;
+                    if (rsel & 1u) rotate_amp(v0, cc, ss);
+                    if (rsel & 2u) rotate_amp(v1, cc, ss);
+                    if (rsel & 4u) rotate_amp(v2, cc, ss);
+                    if (rsel & 8u) rotate_amp(v3, cc, ss);
+                }
+            }
+            tile[p] = v0; tile[e1] = v1; tile[e2] = v2; tile[e3] = v3;
+            __syncthreads();
+            i += 1 + cnt;
+        } else {    // FUSE_CAMODC between rounds: closed-form gather as in k_camodc
+            const unsigned M = ops[i].a;
+            const FuseCamExtra X = *reinterpret_cast<const FuseCamExtra *>(&ops[i].c);
+            const uint64_t cm = ops[i].mask;
+            const unsigned blkmask = (1u << M) - 1u;
+            // element k of a thread: tile-local index k * BLOCK + tid (same map as the tile fill)
+            const unsigned lowmask = (1u << P.c) - 1u;
+            amp_t acc[4];
+            bool wr[4];
+#pragma unroll
+            for (unsigned k = 0; k < 4; k++) {
+                wr[k] = false;
+                const unsigned e = k * BLOCK + threadIdx.x;
+                uint64_t gi = base | (e & lowmask);
+                for (unsigned j = 0; j < P.nh; j++) gi |= (uint64_t)((e >> (P.c + j)) & 1u) << P.hbit[j];
+                const unsigned f = e & blkmask;
+                if ((gi & cm) == cm && f < X.C) {
+                    amp_t s2; s2.x = 0.0; s2.y = 0.0;
+                    if (f % X.d == 0) {
+                        unsigned src = (unsigned)(((uint64_t)(f / X.d) * X.inv) % X.Cd);
+                        const amp_t *blk = tile + (e - f);
+                        for (unsigned q = 0; q < X.d; q++, src += X.Cd) { s2.x += blk[src].x; s2.y += blk[src].y; }
+                    }
+                    acc[k] = s2; wr[k] = true;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (unsigned k = 0; k < 4; k++)
+                if (wr[k]) tile[k * BLOCK + threadIdx.x] = acc[k];
+            __syncthreads();
+            i++;
+        }
+    }
+}
+
 template <int BLOCK, int TT, bool LDSDMA>   // TT = tile bits when known at compile time (loops unroll, loads batch); 0 = generic
 __global__ __launch_bounds__(BLOCK) void k_fused(amp_t *__restrict__ amp, unsigned n, FusePass P,
                                                    const FuseOp *__restrict__ ops, uint64_t ntiles)
@@ -749,7 +837,12 @@ __global__ __launch_bounds__(BLOCK) void k_fused(amp_t *__restrict__ amp, unsign
         }
         __syncthreads();
 
-        fuse_apply_ops<BLOCK, TT, EPT>(tile, P, ops, base, off_t, off_k, tsize, ept);
+        if constexpr (TT != 0 && (1u << TT) == 4u * BLOCK) {
+            if (P.cam_ctl_local[0]) fuse_apply_rounds<BLOCK, TT>(tile, P, ops, base);
+            else fuse_apply_ops<BLOCK, TT, EPT>(tile, P, ops, base, off_t, off_k, tsize, ept);
+        } else {
+            fuse_apply_ops<BLOCK, TT, EPT>(tile, P, ops, base, off_t, off_k, tsize, ept);
+        }
 
         {
             amp_t v[EPT];
@@ -821,7 +914,12 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fused_pipe(amp_t *__restrict__ amp
         const uint64_t tn = t + gridDim.x;
         if (tn < ntiles) fill(buf0 + (cur ^ 1) * tsize, tile_base(tn));
 
-        fuse_apply_ops<BLOCK, TT, EPT>(tile, P, ops, base, off_t, off_k, tsize, EPT);
+        if constexpr ((1u << TT) == 4u * BLOCK) {
+            if (P.cam_ctl_local[0]) fuse_apply_rounds<BLOCK, TT>(tile, P, ops, base);
+            else fuse_apply_ops<BLOCK, TT, EPT>(tile, P, ops, base, off_t, off_k, tsize, EPT);
+        } else {
+            fuse_apply_ops<BLOCK, TT, EPT>(tile, P, ops, base, off_t, off_k, tsize, EPT);
+        }
 
         amp_t *g = amp + (base | off_t);
         amp_t v[EPT];

@@ -14,7 +14,7 @@ def bits(a):
 
 @pytest.fixture()
 def tune_guard(qc):
-    keys = ("fuse_T", "fuse_c", "fuse_grid_cap", "fuse_max_queue")
+    keys = ("fuse_T", "fuse_c", "fuse_grid_cap", "fuse_max_queue", "fuse_rounds", "fuse_pipe", "fuse_ldsdma")
     old = {k: qc.lib().qcx_tune_get(k.encode()) for k in keys}
     yield
     qc.tune(**old)
@@ -61,6 +61,17 @@ def test_random_programs_fused_bit_exact(qc, ob, L, M, Cn):
         assert np.array_equal(bits(got), bits(want)), f"L={L} M={M} trial {trial}"
     if L + M >= 8:
         assert stats[0] > 0 and stats[1] >= stats[0]
+
+
+@pytest.mark.parametrize("rounds,pipe,dma", [(1, 1, 1), (0, 1, 1), (1, 0, 1), (0, 0, 0), (1, 0, 0)])
+def test_kernel_forms(qc, ob, tune_guard, rounds, pipe, dma):
+    """rounds / per-gate op form, persistent double-buffered / plain kernel, LDS-DMA / register fill"""
+    qc.tune(fuse_rounds=rounds, fuse_pipe=pipe, fuse_ldsdma=dma)
+    rs = np.random.RandomState(rounds * 4 + pipe * 2 + dma)
+    for (L, M, Cn) in ((13, 5, 21), (16, 4, 15), (20, 0, 1)):
+        prog = random_program(rs, L + M, M, Cn, 90)
+        got, want, _ = run_both(qc, ob, L, M, Cn, prog, 11)
+        assert np.array_equal(bits(got), bits(want)), (L, M)
 
 
 @pytest.mark.parametrize("T,c", [(8, 2), (9, 4), (10, 6), (11, 3), (12, 4), (12, 6), (12, 0), (10, 10)])

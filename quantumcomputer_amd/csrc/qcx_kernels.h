@@ -221,7 +221,7 @@ __global__ __launch_bounds__(BLOCK) void k_camodc(amp_t *__restrict__ amp, Camod
             if (!on || f >= P.C) continue;                     // identity rows (Q:611-613, Q:631-634)
             amp_t acc; acc.x = 0.0; acc.y = 0.0;
             if (f % P.d == 0) {
-                unsigned src = (unsigned)(((uint64_t)(f / P.d) * P.inv) % P.Cd);
+                unsigned src = ((f / P.d) * P.inv) % P.Cd;            // < C^2 <= 2^32: 32-bit arithmetic is exact (host checks)
                 const amp_t *blk = tile + (e - f);
                 for (unsigned t = 0; t < P.d; t++, src += P.Cd) { acc.x += blk[src].x; acc.y += blk[src].y; }
             }
@@ -682,7 +682,7 @@ __device__ __forceinline__ void fuse_apply_ops(amp_t *tile, const FusePass &P, c
                     if ((gi & cm) == cm && f < X.C) {
                         amp_t s2; s2.x = 0.0; s2.y = 0.0;
                         if (f % X.d == 0) {
-                            unsigned src = (unsigned)(((uint64_t)(f / X.d) * X.inv) % X.Cd);
+                            unsigned src = ((f / X.d) * X.inv) % X.Cd;
                             const amp_t *blk = tile + (e - f);
                             for (unsigned q = 0; q < X.d; q++, src += X.Cd) { s2.x += blk[src].x; s2.y += blk[src].y; }
                         }
@@ -732,6 +732,7 @@ __device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, const FusePass &P
             const unsigned p = (unsigned)insert_zero(insert_zero(threadIdx.x, rb0), rb1);
             const unsigned e1 = p | (1u << rb0), e2 = p | (1u << rb1), e3 = e1 | (1u << rb1);
             amp_t v0 = tile[p], v1 = tile[e1], v2 = tile[e2], v3 = tile[e3];
+#pragma unroll 4
             for (unsigned o = i + 1; o <= i + cnt; o++) {
                 const uint32_t t = ops[o].type;
                 if ((t & 0xffu) == FUSE_H) {
@@ -772,7 +773,7 @@ __device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, const FusePass &P
                 if ((gi & cm) == cm && f < X.C) {
                     amp_t s2; s2.x = 0.0; s2.y = 0.0;
                     if (f % X.d == 0) {
-                        unsigned src = (unsigned)(((uint64_t)(f / X.d) * X.inv) % X.Cd);
+                        unsigned src = ((f / X.d) * X.inv) % X.Cd;
                         const amp_t *blk = tile + (e - f);
                         for (unsigned q = 0; q < X.d; q++, src += X.Cd) { s2.x += blk[src].x; s2.y += blk[src].y; }
                     }

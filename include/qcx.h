@@ -83,6 +83,9 @@ int  qcx_inverse_QFT(qcx_register *reg);                                        
  * reference's 32-bit INT_POW(a, x) including its wrap (Q:158-159, Q:729) */
 int  qcx_quantum_computation(unsigned C, unsigned a, int intpow_mode, qcx_register *reg); /* Q:712-737 */
 
+/* the reference's INT_POW macro (Q:158-159) exactly as x86-64 gcc evaluates it, 32-bit wrap included */
+unsigned qcx_ref_int_pow(double base, double power);
+
 /* ---- gate fusion (no reference counterpart) ------------
  * enable = 1: gate calls are queued and executed as fused passes (one HBM round trip applies many
  * gates to LDS-resident tiles).  Results are bit-identical to the per-gate kernels.  Every call that

@@ -45,7 +45,6 @@ typedef struct {                                            /* Q:194-203 */
 
 /* Q:150-151, Q:158-159 (INT_POW keeps the reference's 32-bit behaviour) */
 #define GET_BIT(integer, n) ( ((integer) >> (n)) & 1 )
-unsigned qcx_ref_int_pow(double base, double power);
 #define INT_POW(base, power) ( qcx_ref_int_pow((double)(base), (double)(power)) )
 
 static inline void qcx_compat_die(int status, const char *what)

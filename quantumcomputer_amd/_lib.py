@@ -45,6 +45,7 @@ SIGNATURES = {
     "qcx_swap_states": (_i, [_p]),
     "qcx_inverse_QFT": (_i, [_p]),
     "qcx_quantum_computation": (_i, [_u, _u, _i, _p]),
+    "qcx_ref_int_pow": (_u, [_d, _d]),
     "qcx_set_fusion": (_i, [_p, _i]),
     "qcx_flush": (_i, [_p]),
     "qcx_fusion_stats": (_i, [_p, C.POINTER(_ul), C.POINTER(_ul)]),
@@ -80,7 +81,6 @@ _EXTRA = {
     "qcx_last_error": (C.c_char_p, []),
     "qcx_tune_set": (_i, [C.c_char_p, C.c_long]),
     "qcx_tune_get": (C.c_long, [C.c_char_p]),
-    "qcx_ref_int_pow": (_u, [_d, _d]),
     "qcx_measure_last_stats": (_i, [C.POINTER(_u), C.POINTER(_u)]),
 }
 

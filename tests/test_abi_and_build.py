@@ -13,9 +13,17 @@ HEADER = os.path.join(ROOT, "include", "qcx.h")
 
 
 def declared_symbols():
-    txt = open(HEADER).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(qcx_[a-zA-Z0-9_]+)\s*\(", txt)))
+    """every non-inline qcx_* function any header under include/ declares"""
+    names = set()
+    inc = os.path.join(ROOT, "include")
+    for h in sorted(os.listdir(inc)):
+        txt = open(os.path.join(inc, h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        # declarations start in column 0 with a return type; calls inside inline bodies are indented
+        for m in re.finditer(r"^(?![ \t])[^\n#{}()]*?\b(qcx_[a-zA-Z0-9_]+)\s*\([^;{]*\)\s*;", txt, flags=re.M):
+            if "static" not in m.group(0):
+                names.add(m.group(1))
+    return sorted(names)
 
 
 def test_header_symbols_all_exported(qc):

@@ -91,6 +91,7 @@ def test_cli_without_gpu_fails_loudly(hostlib):
     (["-C", "33", "-L", "5", "-M", "5", "-f", "7"], (11, 3)),         # the reference's documented example, with -f
     (["-C", "21", "-L", "9", "-M", "5", "-a", "2"], (3, 7)),
     (["-C", "35", "-L", "5", "-M", "6"], None),                      # loop mode over trial integers
+    (["-C", "21", "-L", "11", "-M", "5", "-a", "2", "-F"], (3, 7)),  # with gate fusion
 ])
 def test_cli_factors_on_gpu(hostlib, args, factors):
     ok = 0

@@ -19,10 +19,14 @@ def _v(variant, ppt=1, nt=3, cap=0, r=4, wc=0, blk=256, sl=0, wb=256):
                 h_streams_log2=sl, h_wave_block=wb)
 
 
-VARIANTS = {
-    "auto": dict(h_variant=0),
-    "p1_b64_s1": _v(1, blk=64, sl=1), "p1_b256_nt0": _v(1, blk=256, nt=0), "p4_b256_nt0": _v(1, ppt=4, blk=256, nt=0),
-}
+VARIANTS = {"auto": dict(h_variant=0)}
+for _ppt in (1, 2, 4):
+    for _wc in (0, 1):
+        for _sl in (0, 1, 2, 3, 4):
+            for _blk in (64, 128):
+                if _ppt == 1 and _wc:
+                    continue
+                VARIANTS[f"p{_ppt}{'w' if _wc else ''}_b{_blk}_s{_sl}"] = _v(1, ppt=_ppt, blk=_blk, sl=_sl, wc=_wc)
 
 
 def main():

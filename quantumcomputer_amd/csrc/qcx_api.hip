@@ -603,13 +603,75 @@ struct qcx_register {
     hipEvent_t ev0, ev1;
     hipEvent_t *events;
     unsigned   n_events;
+    amp_t     *scratch;         // second buffer, allocated on first use (M > 12 modular multiply only)
     int        fusion;          // 1: gate calls are queued and executed as fused passes (qcx_fuse.inc.h)
     struct GateQueue *queue;
 };
 
+static int reg_camodc(qcx_register *r, unsigned C, unsigned A, unsigned ctl);
+
 #include "qcx_fuse.inc.h"
 
 #define FLUSH(r) QCX_TRY(fuse_flush(r))
+
+// M > 12: the 2^M-block does not fit an LDS tile -> out of place into the scratch buffer, then swap
+static int reg_camodc_large(qcx_register *r, unsigned C, unsigned A, unsigned ctl)
+{
+    const unsigned M = (unsigned)r->M;
+    if (M > 26) return QCX_UNSUPPORTED;
+    if (!r->scratch) {
+        hipError_t e = hipMalloc(&r->scratch, r->dim * sizeof(amp_t));
+        if (e != hipSuccess) { snprintf(g_last_error, sizeof g_last_error, "hipMalloc(scratch): %s", hipGetErrorString(e)); return QCX_INSUFFICIENT_MEMORY; }
+    }
+    CamodcParams P;
+    memset(&P, 0, sizeof P);
+    P.M = M; P.logT = M; P.ctl = (int)ctl; P.C = C; P.ntiles = 0;
+    const uint64_t blk = (uint64_t)1 << M;
+    const unsigned grid = grid_for(r->dim, 256, 65536);
+    if (camodc_closed_form(r->n, M, C, A, ctl)) {
+        P.d = gcd_u32(A, C); P.Cd = C / P.d; P.inv = modinv_u32(A / P.d, P.Cd);
+        hipLaunchKernelGGL((k_camodc_oop<false, 256>), dim3(grid), dim3(256), 0, r->stream, r->amp, r->scratch, r->dim, P, nullptr, nullptr);
+    } else {
+        std::vector<uint32_t> cnt(blk + 1, 0), dst(blk);
+        for (uint64_t f = 0; f < blk; f++) {
+            uint32_t d = (uint32_t)f;
+            const bool on = (ctl < M) ? ((f >> ctl) & 1u) : true;
+            if (on && f < C) d = (uint32_t)(((uint32_t)(A * (uint32_t)f)) % C) & (uint32_t)(blk - 1);
+            dst[f] = d; cnt[d + 1]++;
+        }
+        for (uint64_t g = 0; g < blk; g++) cnt[g + 1] += cnt[g];
+        std::vector<uint32_t> tab(2 * blk + 1);
+        memcpy(tab.data(), cnt.data(), (blk + 1) * sizeof(uint32_t));
+        std::vector<uint32_t> fill(cnt.begin(), cnt.end() - 1);
+        for (uint64_t f = 0; f < blk; f++) tab[blk + 1 + fill[dst[f]]++] = (uint32_t)f;
+        Workspace *w;
+        QCX_TRY(workspace(&w));
+        const size_t need = tab.size() * sizeof(uint32_t);
+        {
+            std::lock_guard<std::mutex> lock(g_ws_mutex);
+            if (w->tab_cap < need) {
+                if (w->tab) HIP_TRY(hipFree(w->tab));
+                w->tab = nullptr; w->tab_cap = 0;
+                HIP_TRY(hipMalloc(&w->tab, need));
+                w->tab_cap = need;
+            }
+        }
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        HIP_TRY(hipMemcpy(w->tab, tab.data(), need, hipMemcpyHostToDevice));
+        if (ctl < M) P.ctl = -1;                     // the table already encodes a control inside the M register
+        hipLaunchKernelGGL((k_camodc_oop<true, 256>), dim3(grid), dim3(256), 0, r->stream, r->amp, r->scratch, r->dim, P,
+                           w->tab, w->tab + blk + 1);
+    }
+    HIP_TRY(hipGetLastError());
+    amp_t *t = r->amp; r->amp = r->scratch; r->scratch = t;       // swap_states (Q:242-249)
+    return QCX_NO_ERROR;
+}
+
+static int reg_camodc(qcx_register *r, unsigned C, unsigned A, unsigned ctl)
+{
+    if ((unsigned)r->M > 12) return reg_camodc_large(r, C, A, ctl);
+    return qcx_shard_camodc(r->amp, r->n, (unsigned)r->M, C, A, (int)ctl, r->stream);
+}
 
 extern "C" int qcx_register_create(int L, int M, qcx_register **out)
 {
@@ -645,6 +707,7 @@ extern "C" int qcx_register_destroy(qcx_register *r)
     free(r->events);
     (void)hipStreamDestroy(r->own_stream);
     (void)hipFree(r->amp);
+    if (r->scratch) (void)hipFree(r->scratch);
     free(r);
     return QCX_NO_ERROR;
 }
@@ -731,13 +794,12 @@ extern "C" int qcx_c_amodc_gate(unsigned C, unsigned long long atox, unsigned c,
     if (!r || C == 0) return QCX_BAD_ARGUMENTS;
     if (c >= r->n) return QCX_BAD_QUBIT;
     if (r->fusion) {
-        if ((unsigned)r->M > 12) return QCX_UNSUPPORTED;
         QGate g; memset(&g, 0, sizeof g);
         g.q = c; g.C = C; g.A = (unsigned)(atox % C);
-        g.type = camodc_closed_form(r->n, (unsigned)r->M, C, g.A, c) ? (uint32_t)FUSE_CAMODC : 99u;
+        g.type = ((unsigned)r->M <= 12 && camodc_closed_form(r->n, (unsigned)r->M, C, g.A, c)) ? (uint32_t)FUSE_CAMODC : 99u;
         return fuse_push(r, g);
     }
-    return qcx_shard_camodc(r->amp, r->n, (unsigned)r->M, C, (unsigned)(atox % C), (int)c, r->stream);
+    return reg_camodc(r, C, (unsigned)(atox % C), c);
 }
 
 extern "C" int qcx_swap_states(qcx_register *r) { return r ? QCX_NO_ERROR : QCX_BAD_ARGUMENTS; }

@@ -71,7 +71,7 @@ static int fuse_flush(qcx_register *r)
             int s = QCX_NO_ERROR;
             if (g.type == FUSE_H) s = qcx_shard_hadamard(r->amp, n, g.q, r->stream);
             else if (g.type == FUSE_PHASE) s = qcx_shard_phase(r->amp, n, g.mask, g.c, g.s, r->stream);
-            else s = qcx_shard_camodc(r->amp, n, (unsigned)r->M, g.C, g.A, (int)g.q, r->stream);
+            else s = reg_camodc(r, g.C, g.A, g.q);
             if (s != QCX_NO_ERROR) return s;
             i++;
             continue;
@@ -97,7 +97,7 @@ static int fuse_flush(qcx_register *r)
         if (pl.last == pl.first) {               // a single gate that does not fit the tile budget: stand-alone
             const QGate &g = gates[i];
             int s = (g.type == FUSE_H) ? qcx_shard_hadamard(r->amp, n, g.q, r->stream)
-                                       : qcx_shard_camodc(r->amp, n, (unsigned)r->M, g.C, g.A, (int)g.q, r->stream);
+                                       : reg_camodc(r, g.C, g.A, g.q);
             if (s != QCX_NO_ERROR) return s;
             i++;
             continue;
@@ -108,7 +108,7 @@ static int fuse_flush(qcx_register *r)
             int s;
             if (g.type == FUSE_H) s = qcx_shard_hadamard(r->amp, n, g.q, r->stream);
             else if (g.type == FUSE_PHASE) s = qcx_shard_phase(r->amp, n, g.mask, g.c, g.s, r->stream);
-            else s = qcx_shard_camodc(r->amp, n, (unsigned)r->M, g.C, g.A, (int)g.q, r->stream);
+            else s = reg_camodc(r, g.C, g.A, g.q);
             if (s != QCX_NO_ERROR) return s;
             continue;
         }

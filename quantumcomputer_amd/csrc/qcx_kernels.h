@@ -956,4 +956,38 @@ __global__ __launch_bounds__(BLOCK) void k_swap_bits(const amp_t *__restrict__ s
     }
 }
 
+// ---------------------------------------------------------------------------
+// K3b  controlled modular multiply for M registers too large for an LDS tile (M > 12): out of place,
+// dst = gate(src), the caller swaps the two buffers afterwards (the reference's swap_states, Q:242-249).
+// Sources are gathered straight from HBM/L2 (16-B reads inside a 2^M block), so this path is correct
+// but not fast; every M the reference can practically reach (M <= 12) takes the LDS kernels above.
+// TABLE = false: closed form (control >= M, C <= 2^M, no 32-bit wrap);  true: CSR source table.
+// ---------------------------------------------------------------------------
+template <bool TABLE, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_camodc_oop(const amp_t *__restrict__ src, amp_t *__restrict__ dst, uint64_t count,
+                                                        CamodcParams P, const uint32_t *__restrict__ off,
+                                                        const uint32_t *__restrict__ srcs)
+{
+    const uint64_t blkmask = ((uint64_t)1 << P.M) - 1;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < count; i += (uint64_t)gridDim.x * BLOCK) {
+        const uint64_t f = i & blkmask, b0 = i - f;
+        const bool on = (P.ctl < 0) ? true : ((i >> P.ctl) & 1u);
+        amp_t acc;
+        if (TABLE) {
+            if (!on) { dst[i] = src[i]; continue; }
+            acc.x = 0.0; acc.y = 0.0;
+            for (uint32_t k = off[f]; k < off[f + 1]; k++) { const amp_t v = src[b0 + srcs[k]]; acc.x += v.x; acc.y += v.y; }
+        } else {
+            if (!on || f >= P.C) { dst[i] = src[i]; continue; }
+            acc.x = 0.0; acc.y = 0.0;
+            const uint32_t g = (uint32_t)f;
+            if (g % P.d == 0) {
+                uint32_t s0 = (uint32_t)(((uint64_t)(g / P.d) * P.inv) % P.Cd);
+                for (uint32_t t = 0; t < P.d; t++, s0 += P.Cd) { const amp_t v = src[b0 + s0]; acc.x += v.x; acc.y += v.y; }
+            }
+        }
+        dst[i] = acc;
+    }
+}
+
 }  // namespace qcx

@@ -92,6 +92,9 @@ CAMODC_CASES = [
     (4, 3, 15, 7, 4), (4, 3, 21, 2, 5),                                # C > 2^M: only bits < M of f' kept
     (3, 5, 21, 2, 2), (3, 5, 21, 10, 0), (3, 4, 15, 7, 3),             # control inside the M register
     (12, 4, 15, 7, 15), (13, 5, 21, 4, 17), (9, 5, 21, 2, 10),         # control above / inside the LDS tile
+    # M > 12: out-of-place path with buffer swap (closed form, many-to-one, control inside M, C > 2^M)
+    (2, 13, 8191, 1234, 14), (3, 13, 5000, 7, 13), (1, 14, 16000, 3, 14), (2, 13, 8190, 6, 13),
+    (2, 13, 6000, 12, 5), (2, 13, 9000, 7, 14),
 ]
 
 
@@ -99,10 +102,15 @@ CAMODC_CASES = [
 def test_camodc_bit_exact(qc, ob, L, M, C, atox, ctl):
     n = L + M
     a = ob.random_state(n, 500 + ctl)
-    with qc.Register(L, M) as reg:
-        reg.write(a); qc.c_amodc_gate(C, atox, ctl, reg); got = reg.read()
     want = a.copy(); ob.camodc(want, n, M, C, atox, ctl)
-    assert_bits_equal(got, want, f"C_AMODC L={L} M={M} C={C} atox={atox} ctl={ctl}")
+    for fusion in (False, True):
+        with qc.Register(L, M) as reg:
+            reg.write(a); reg.set_fusion(fusion)
+            qc.c_amodc_gate(C, atox, ctl, reg)
+            qc.hadamard_gate(n - 1, reg)                   # something after it (the M > 12 path swaps buffers)
+            got = reg.read()
+        w2 = want.copy(); ob.hadamard(w2, n, n - 1)
+        assert_bits_equal(got, w2, f"C_AMODC L={L} M={M} C={C} atox={atox} ctl={ctl} fusion={fusion}")
 
 
 def test_reset_register(qc):

@@ -103,8 +103,8 @@ class ShardedRegister:
         self.num_qubits = n = self.L_size + self.M_size
         self.num_states = 1 << n
         self.n_local = n - k
-        # sigma spectator bits -> 2^sigma slices for the overlapped exchange (QCX_SHARD_SLICES_LOG2, default 2)
-        sigma = int(os.environ.get("QCX_SHARD_SLICES_LOG2", "2")) if slices_log2 is None else int(slices_log2)
+        # sigma spectator bits -> 2^sigma slices for the overlapped exchange (QCX_SHARD_SLICES_LOG2, default 3)
+        sigma = int(os.environ.get("QCX_SHARD_SLICES_LOG2", "3")) if slices_log2 is None else int(slices_log2)
         if not k:
             sigma = 0
         while True:

@@ -1,0 +1,34 @@
+"""GPU: a C program written in the reference's own style (gate calls with the matrix argument, Register by
+value, INT_POW, gsl_rng) built against include/qcx_compat.h + libqcx.so reproduces the oracle bit for bit."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("c") / "refstyle")
+    lib = os.path.join(ROOT, "quantumcomputer_amd")
+    subprocess.run(["gcc", "-std=gnu11", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c", "refstyle_circuit.c"), "-L", lib, "-lqcx", "-lm",
+                    "-Wl,-rpath," + lib, "-o", out], check=True)
+    return out
+
+
+@pytest.mark.parametrize("C,L,M,a", [(15, 3, 4, 7), (21, 5, 5, 2), (15, 8, 4, 7), (33, 5, 5, 7)])
+def test_reference_style_c_program(exe, ob, C, L, M, a):
+    n = L + M
+    r = subprocess.run([exe, str(C), str(L), str(M), str(a), "12345"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.split()
+    got = np.array([int(x, 16) for x in lines[:2 << n]], dtype=np.uint64)
+    want = np.zeros(2 << n); ob.reset(want, n)
+    ob.quantum_computation(want, n, M, C, a, ref_intpow=True)        # the C program uses the reference's INT_POW
+    assert np.array_equal(got, want.view(np.uint64))
+    rng = ob.Rng(12345)
+    assert int(lines[-1]) == ob.measure(want, n, rng.uniform())

@@ -162,8 +162,16 @@ static int fuse_flush(qcx_register *r)
                 }
                 o.a = mloc; o.mask = mext; o.c = g.c; o.s = g.s;
             } else {
-                o.a = (unsigned)r->M;
-                o.mask = (uint64_t)1 << g.q;
+                // control: tile-local position (+1) in bits 8.., or an outside bit tested against the tile base
+                unsigned ctl_local_p1 = 0; uint64_t mext = 0;
+                if (g.q < c) ctl_local_p1 = g.q + 1;
+                else {
+                    auto it = std::find(pl.hbits.begin(), pl.hbits.end(), g.q);
+                    if (it != pl.hbits.end()) ctl_local_p1 = c + (unsigned)(it - pl.hbits.begin()) + 1;
+                    else mext = (uint64_t)1 << g.q;
+                }
+                o.a = (unsigned)r->M | (ctl_local_p1 << 8);
+                o.mask = mext;
                 FuseCamExtra X;
                 X.C = g.C; X.d = gcd_u32(g.A, g.C); X.Cd = g.C / X.d; X.inv = modinv_u32(g.A / X.d, X.Cd);
                 memcpy(&o.c, &X, sizeof X);
@@ -227,12 +235,13 @@ static int fuse_flush(qcx_register *r)
         HIP_TRY(hipMemcpyAsync(gq->d_ops, gq->h_ops, nsend * sizeof(FuseOp), hipMemcpyHostToDevice, r->stream));
         const uint64_t ntiles = (uint64_t)1 << (n - P.T);
         const unsigned grid = grid_for(ntiles, 1, g_tune.fuse_grid_cap);
-        const size_t lds = (size_t)16 << P.T;
+        const size_t lut_bytes = ((size_t)2 << std::min(12u, (unsigned)r->M)) + 16;   // source table of a modular-multiply step
+        const size_t lds = ((size_t)16 << P.T) + lut_bytes;
         // 4 amplitudes per thread (all loads of a tile in flight at once, few registers): block = 2^T / 4
 #define QCX_FUSE_LAUNCH(B, TTv) do { \
             if (g_tune.fuse_pipe && ntiles >= 4096) { \
                 const unsigned pg = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)g_tune.fuse_pipe_grid); \
-                hipLaunchKernelGGL((k_fused_pipe<B, TTv>), dim3(pg), dim3(B), 2 * lds, r->stream, r->amp, n, P, gq->d_ops, ntiles); \
+                hipLaunchKernelGGL((k_fused_pipe<B, TTv>), dim3(pg), dim3(B), 2 * ((size_t)16 << P.T) + lut_bytes, r->stream, r->amp, n, P, gq->d_ops, ntiles); \
             } else if (g_tune.fuse_ldsdma) hipLaunchKernelGGL((k_fused<B, TTv, true>), dim3(grid), dim3(B), lds, r->stream, r->amp, n, P, gq->d_ops, ntiles); \
             else hipLaunchKernelGGL((k_fused<B, TTv, false>), dim3(grid), dim3(B), lds, r->stream, r->amp, n, P, gq->d_ops, ntiles); } while (0)
         switch (P.T) {

@@ -607,9 +607,59 @@ struct FusePass {
     uint8_t  hbit[16];          // global bit carried by tile-local bit c + j, ascending
 };
 
+// One controlled modular multiply on an LDS-resident tile whose low M local bits are the M register.
+//   op.a    = M | (ctl_local + 1) << 8      (0 in the high part: the control is outside the tile)
+//   op.mask = global-index mask of an outside control (0 if the control is tile-local)
+// The destination -> source map of the permutation case (d = 1) is tabulated once per step by the first 2^M
+// threads (one 32-bit modulo each) instead of one modulo per amplitude; `lut` lives behind the tile buffers.
+template <int BLOCK, unsigned EPTC>
+__device__ __forceinline__ void fuse_camodc_step(amp_t *tile, unsigned short *lut, const FuseOp *__restrict__ op,
+                                                 uint64_t base, unsigned tsize)
+{
+    const uint64_t mext = op->mask;
+    if ((base & mext) != mext) return;                                   // control outside the tile is 0: identity
+    const unsigned M = op->a & 0xffu;
+    const int ctl_local = (int)((op->a >> 8) & 0xffu) - 1;
+    const FuseCamExtra X = *reinterpret_cast<const FuseCamExtra *>(&op->c);
+    const unsigned blk = 1u << M, blkmask = blk - 1u;
+    const bool perm = (X.d == 1);
+    if (perm) {
+        for (unsigned f = threadIdx.x; f < blk; f += BLOCK) lut[f] = (unsigned short)(f < X.C ? (f * X.inv) % X.C : f);
+        __syncthreads();
+    }
+    amp_t acc[EPTC];
+    bool wr[EPTC];
+#pragma unroll
+    for (unsigned k = 0; k < EPTC; k++) {
+        wr[k] = false;
+        const unsigned e = k * BLOCK + threadIdx.x;
+        if (e < tsize) {
+            const unsigned f = e & blkmask;
+            const bool on = ctl_local < 0 || ((e >> ctl_local) & 1u);
+            if (on && f < X.C) {
+                amp_t s2; s2.x = 0.0; s2.y = 0.0;
+                if (perm) {
+                    const amp_t sv = tile[(e - f) + lut[f]];
+                    s2.x += sv.x; s2.y += sv.y;
+                } else if (f % X.d == 0) {
+                    unsigned src = ((f / X.d) * X.inv) % X.Cd;
+                    const amp_t *b = tile + (e - f);
+                    for (unsigned q = 0; q < X.d; q++, src += X.Cd) { s2.x += b[src].x; s2.y += b[src].y; }
+                }
+                acc[k] = s2; wr[k] = true;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (unsigned k = 0; k < EPTC; k++)
+        if (wr[k]) tile[k * BLOCK + threadIdx.x] = acc[k];
+    __syncthreads();
+}
+
 // the gate list applied to one LDS-resident tile (shared by the plain and the pipelined pass kernels)
 template <int BLOCK, int TT, unsigned EPT>
-__device__ __forceinline__ void fuse_apply_ops(amp_t *tile, const FusePass &P, const FuseOp *__restrict__ ops,
+__device__ __forceinline__ void fuse_apply_ops(amp_t *tile, unsigned short *lut, const FusePass &P, const FuseOp *__restrict__ ops,
                                                uint64_t base, uint64_t off_t, const uint64_t (&off_k)[EPT],
                                                unsigned tsize, unsigned ept)
 {
@@ -664,37 +714,8 @@ __device__ __forceinline__ void fuse_apply_ops(amp_t *tile, const FusePass &P, c
             }
             __syncthreads();
             i = gend;
-        } else {    // FUSE_CAMODC: mask = control bit as a global-index mask
-            const unsigned M = ops[i].a;
-            const FuseCamExtra X = *reinterpret_cast<const FuseCamExtra *>(&ops[i].c);
-            const uint64_t cm = ops[i].mask;
-            const unsigned blkmask = (1u << M) - 1u;
-            // the elements of a thread are gathered before anything is overwritten
-            amp_t acc[EPT];
-            bool wr[EPT];
-#pragma unroll
-            for (unsigned k = 0; k < EPT; k++) {
-                wr[k] = false;
-                const unsigned e = k * BLOCK + threadIdx.x;
-                if (k < ept && e < tsize) {
-                    const uint64_t gi = base | off_t | off_k[k];
-                    const unsigned f = e & blkmask;
-                    if ((gi & cm) == cm && f < X.C) {
-                        amp_t s2; s2.x = 0.0; s2.y = 0.0;
-                        if (f % X.d == 0) {
-                            unsigned src = ((f / X.d) * X.inv) % X.Cd;
-                            const amp_t *blk = tile + (e - f);
-                            for (unsigned q = 0; q < X.d; q++, src += X.Cd) { s2.x += blk[src].x; s2.y += blk[src].y; }
-                        }
-                        acc[k] = s2; wr[k] = true;
-                    }
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (unsigned k = 0; k < EPT; k++)
-                if (wr[k]) tile[k * BLOCK + threadIdx.x] = acc[k];
-            __syncthreads();
+        } else {    // FUSE_CAMODC
+            fuse_camodc_step<BLOCK, EPT>(tile, lut, ops + i, base, tsize);
             i++;
         }
     }
@@ -720,7 +741,7 @@ __device__ __forceinline__ void rotate_amp(amp_t &v, double cc, double ss)
 }
 
 template <int BLOCK, int TT>
-__device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, const FusePass &P, const FuseOp *__restrict__ ops, uint64_t base)
+__device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, unsigned short *lut, const FusePass &P, const FuseOp *__restrict__ ops, uint64_t base)
 {
     static_assert((1u << TT) == 4u * BLOCK, "rounds form needs 4 amplitudes per thread");
     unsigned i = 0;
@@ -754,37 +775,8 @@ __device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, const FusePass &P
             tile[p] = v0; tile[e1] = v1; tile[e2] = v2; tile[e3] = v3;
             __syncthreads();
             i += 1 + cnt;
-        } else {    // FUSE_CAMODC between rounds: closed-form gather as in k_camodc
-            const unsigned M = ops[i].a;
-            const FuseCamExtra X = *reinterpret_cast<const FuseCamExtra *>(&ops[i].c);
-            const uint64_t cm = ops[i].mask;
-            const unsigned blkmask = (1u << M) - 1u;
-            // element k of a thread: tile-local index k * BLOCK + tid (same map as the tile fill)
-            const unsigned lowmask = (1u << P.c) - 1u;
-            amp_t acc[4];
-            bool wr[4];
-#pragma unroll
-            for (unsigned k = 0; k < 4; k++) {
-                wr[k] = false;
-                const unsigned e = k * BLOCK + threadIdx.x;
-                uint64_t gi = base | (e & lowmask);
-                for (unsigned j = 0; j < P.nh; j++) gi |= (uint64_t)((e >> (P.c + j)) & 1u) << P.hbit[j];
-                const unsigned f = e & blkmask;
-                if ((gi & cm) == cm && f < X.C) {
-                    amp_t s2; s2.x = 0.0; s2.y = 0.0;
-                    if (f % X.d == 0) {
-                        unsigned src = ((f / X.d) * X.inv) % X.Cd;
-                        const amp_t *blk = tile + (e - f);
-                        for (unsigned q = 0; q < X.d; q++, src += X.Cd) { s2.x += blk[src].x; s2.y += blk[src].y; }
-                    }
-                    acc[k] = s2; wr[k] = true;
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (unsigned k = 0; k < 4; k++)
-                if (wr[k]) tile[k * BLOCK + threadIdx.x] = acc[k];
-            __syncthreads();
+        } else {    // FUSE_CAMODC between rounds
+            fuse_camodc_step<BLOCK, 4>(tile, lut, ops + i, base, 1u << TT);
             i++;
         }
     }
@@ -798,6 +790,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(amp_t *__restrict__ amp, unsign
     amp_t *tile = reinterpret_cast<amp_t *>(qcx_lds_raw);
     const unsigned T = TT ? (unsigned)TT : P.T, c = P.c, nh = P.nh;
     const unsigned tsize = 1u << T;
+    unsigned short *lut = reinterpret_cast<unsigned short *>(tile + tsize);  // behind the tile (host sizes the LDS)
     constexpr unsigned EPT = TT ? ((1u << TT) + BLOCK - 1) / BLOCK : 16;      // elements per thread (<= 16)
     const unsigned ept = TT ? EPT : (tsize + BLOCK - 1) / BLOCK;
     const unsigned lowmask = (1u << c) - 1u;
@@ -839,10 +832,10 @@ __global__ __launch_bounds__(BLOCK) void k_fused(amp_t *__restrict__ amp, unsign
         __syncthreads();
 
         if constexpr (TT != 0 && (1u << TT) == 4u * BLOCK) {
-            if (P.cam_ctl_local[0]) fuse_apply_rounds<BLOCK, TT>(tile, P, ops, base);
-            else fuse_apply_ops<BLOCK, TT, EPT>(tile, P, ops, base, off_t, off_k, tsize, ept);
+            if (P.cam_ctl_local[0]) fuse_apply_rounds<BLOCK, TT>(tile, lut, P, ops, base);
+            else fuse_apply_ops<BLOCK, TT, EPT>(tile, lut, P, ops, base, off_t, off_k, tsize, ept);
         } else {
-            fuse_apply_ops<BLOCK, TT, EPT>(tile, P, ops, base, off_t, off_k, tsize, ept);
+            fuse_apply_ops<BLOCK, TT, EPT>(tile, lut, P, ops, base, off_t, off_k, tsize, ept);
         }
 
         {
@@ -871,6 +864,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fused_pipe(amp_t *__restrict__ amp
     constexpr unsigned tsize = 1u << TT;
     constexpr unsigned EPT = tsize / BLOCK;
     static_assert(EPT >= 1 && EPT <= 8, "tile / block geometry");
+    unsigned short *lut = reinterpret_cast<unsigned short *>(buf0 + 2 * tsize);   // behind both tile buffers
     const unsigned c = P.c, nh = P.nh;
     const unsigned lowmask = (1u << c) - 1u;
     auto scatter = [&](unsigned e) -> uint64_t {
@@ -916,10 +910,10 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fused_pipe(amp_t *__restrict__ amp
         if (tn < ntiles) fill(buf0 + (cur ^ 1) * tsize, tile_base(tn));
 
         if constexpr ((1u << TT) == 4u * BLOCK) {
-            if (P.cam_ctl_local[0]) fuse_apply_rounds<BLOCK, TT>(tile, P, ops, base);
-            else fuse_apply_ops<BLOCK, TT, EPT>(tile, P, ops, base, off_t, off_k, tsize, EPT);
+            if (P.cam_ctl_local[0]) fuse_apply_rounds<BLOCK, TT>(tile, lut, P, ops, base);
+            else fuse_apply_ops<BLOCK, TT, EPT>(tile, lut, P, ops, base, off_t, off_k, tsize, EPT);
         } else {
-            fuse_apply_ops<BLOCK, TT, EPT>(tile, P, ops, base, off_t, off_k, tsize, EPT);
+            fuse_apply_ops<BLOCK, TT, EPT>(tile, lut, P, ops, base, off_t, off_k, tsize, EPT);
         }
 
         amp_t *g = amp + (base | off_t);

@@ -91,7 +91,8 @@ class HipEngine:
 class ShardedRegister:
     """Register (qc_shor.c:194-203) sharded by its top log2(world) physical index bits."""
 
-    def __init__(self, L_size, M_size, device=None, group=None, engine=None, max_queue=8192, slices_log2=None):
+    def __init__(self, L_size, M_size, device=None, group=None, engine=None, max_queue=8192, slices_log2=None,
+                 dry_run=False):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -123,7 +124,11 @@ class ShardedRegister:
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = torch.device(device)
         self.engine = engine if engine is not None else HipEngine(self.device)
-        self.bufs = [torch.zeros(2 << self.n_local, dtype=torch.float64, device=self.device) for _ in range(2 if k else 1)]
+        self.dry_run = bool(dry_run)              # schedule only (tools/model_sharded.py): no amplitude storage
+        if self.dry_run:
+            self.bufs = [("buf", 0), ("buf", 1)]
+        else:
+            self.bufs = [torch.zeros(2 << self.n_local, dtype=torch.float64, device=self.device) for _ in range(2 if k else 1)]
         self.cur = 0
         self.perm = list(range(n))        # logical qubit -> physical index bit
         self.inv = list(range(n))         # physical index bit -> logical qubit
@@ -155,6 +160,8 @@ class ShardedRegister:
     # rank id is done slice by slice (pack -> all-to-all), which lets the gates before/after it run on the
     # slices that are not in flight: exchange and compute overlap.
     def _views(self, buf):
+        if self.dry_run:
+            return [(buf, s) for s in range(1 << self.sigma)]
         w = 2 << self.slice_bits
         return [buf[s * w:(s + 1) * w] for s in range(1 << self.sigma)]
 
@@ -334,6 +341,10 @@ class ShardedRegister:
                 b += 1
                 if not (S > 1 and self.overlap) and b > x:           # no overlap: only the gate that needed the trade
                     break
+            if S > 1 and self.overlap and b < len(q) and q[b][0] == "h" and self.perm[q[b][1]] >= nl:
+                # the run ends at the NEXT exchange: leave its second half to that exchange's pre-window, so
+                # that both transfers have gates to hide behind
+                b = x + max(1, (b - x + 1) // 2)
             post_ops = [self._resolve(g) for g in q[x:b]]
             src_buf, dst_buf = self.bufs[self.cur], self.bufs[self.cur ^ 1]
             src_views = self._views(src_buf)

@@ -144,6 +144,7 @@ struct Workspace {
 };
 static const unsigned NORM_BLOCKS = 2048;
 static std::mutex g_ws_mutex;
+static std::mutex g_ws_use[64];       // one user of a device's scratch (norm / measurement) at a time
 static Workspace g_ws[64];
 
 static int workspace(Workspace **out)
@@ -476,6 +477,7 @@ extern "C" int qcx_shard_camodc(void *amp, unsigned n_local, unsigned M, unsigne
 
     Workspace *w;
     QCX_TRY(workspace(&w));
+    std::lock_guard<std::mutex> use(g_ws_use[w - g_ws]);     // the table is per-device scratch: one user at a time
     const size_t need = tab.size() * sizeof(uint32_t);
     {
         std::lock_guard<std::mutex> lock(g_ws_mutex);
@@ -495,6 +497,7 @@ extern "C" int qcx_shard_camodc(void *amp, unsigned n_local, unsigned M, unsigne
     const unsigned grid = grid_for(Pt.ntiles, 1, g_tune.cam_grid_cap);
     hipLaunchKernelGGL((k_camodc_table<256>), dim3(grid), dim3(256), lds, st, a, Pt, w->tab, w->tab + blk + 1);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));                       // rare path: finish before the table can be replaced
     return QCX_NO_ERROR;
 }
 
@@ -521,6 +524,7 @@ extern "C" int qcx_shard_norm2(const void *amp, unsigned n_local, double *out, v
     if (!amp || !out || n_local > 40) return QCX_BAD_ARGUMENTS;
     Workspace *w;
     QCX_TRY(workspace(&w));
+    std::lock_guard<std::mutex> use(g_ws_use[w - g_ws]);
     hipStream_t st = (hipStream_t)stream;
     const uint64_t count = (uint64_t)1 << n_local;
     const unsigned grid = grid_for(count, 256 * 8, NORM_BLOCKS);
@@ -540,6 +544,7 @@ extern "C" int qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_
     if (!amp || !found || !index || !cum_out || n_local > 40) return QCX_BAD_ARGUMENTS;
     Workspace *w;
     QCX_TRY(workspace(&w));
+    std::lock_guard<std::mutex> use(g_ws_use[w - g_ws]);
     hipStream_t st = (hipStream_t)stream;
     uint64_t count = (uint64_t)1 << n_local;
     if (first_global >= last_excluded) count = 0;
@@ -646,6 +651,7 @@ static int reg_camodc_large(qcx_register *r, unsigned C, unsigned A, unsigned ct
         for (uint64_t f = 0; f < blk; f++) tab[blk + 1 + fill[dst[f]]++] = (uint32_t)f;
         Workspace *w;
         QCX_TRY(workspace(&w));
+        std::lock_guard<std::mutex> use(g_ws_use[w - g_ws]);
         const size_t need = tab.size() * sizeof(uint32_t);
         {
             std::lock_guard<std::mutex> lock(g_ws_mutex);
@@ -661,6 +667,7 @@ static int reg_camodc_large(qcx_register *r, unsigned C, unsigned A, unsigned ct
         if (ctl < M) P.ctl = -1;                     // the table already encodes a control inside the M register
         hipLaunchKernelGGL((k_camodc_oop<true, 256>), dim3(grid), dim3(256), 0, r->stream, r->amp, r->scratch, r->dim, P,
                            w->tab, w->tab + blk + 1);
+        HIP_TRY(hipStreamSynchronize(r->stream));            // rare path: finish before the table can be replaced
     }
     HIP_TRY(hipGetLastError());
     amp_t *t = r->amp; r->amp = r->scratch; r->scratch = t;       // swap_states (Q:242-249)

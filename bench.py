@@ -195,10 +195,10 @@ def main():
         # on N > 1 the event interval of a global qubit also holds the all-to-all, so those are left out
         dom = [q for q in range(3, args.n_local)]
         dom_ms = [x for q in dom for x in per_q_ms[q]]
-        per_q_ms = [v if v else [float("nan")] for v in per_q_ms]
         avg_ms = sum(dom_ms) / len(dom_ms)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        per_q_gbs = [round(bytes_per_launch / (min(per_q_ms[q]) * 1e-3) / 1e9, 1) for q in range(n)]
+        # (index = physical target bit; null where no launch hit that bit, e.g. the rank-id bits at N > 1)
+        per_q_gbs = [round(bytes_per_launch / (min(per_q_ms[q]) * 1e-3) / 1e9, 1) if per_q_ms[q] else None for q in range(n)]
         out = {
             "metric": "amplitude-updates/s (gate*2^n/s), n=30 H-sweep" if args.gpus == 1 else
                       f"amplitude-updates/s (gate*2^n/s), n={n} H-sweep sharded over {args.gpus} GPUs",

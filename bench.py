@@ -85,6 +85,12 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=28)
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON); libraries that chat on fd 1 (RCCL prints a version banner
+    # there when a communicator is created) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import quantumcomputer_amd as qc
 
@@ -227,7 +233,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_n)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     if args.gpus > 1 or args.force_sharded:
         import torch.distributed as dist

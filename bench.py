@@ -96,7 +96,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("QCX_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))     # (override: test rigs only)
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")

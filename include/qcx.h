@@ -83,6 +83,10 @@ int  qcx_inverse_QFT(qcx_register *reg);                                        
  * reference's 32-bit INT_POW(a, x) including its wrap (Q:158-159, Q:729) */
 int  qcx_quantum_computation(unsigned C, unsigned a, int intpow_mode, qcx_register *reg); /* Q:712-737 */
 
+/* e^{i theta} as the reference's gsl_complex_polar(1.0, theta) yields it under gcc -O2 + glibc: one sincos()
+ * call (Q:526).  Hosts that compute the phase factor themselves (qcx_shard_phase) must use this. */
+void qcx_polar(double theta, double *cos_out, double *sin_out);
+
 /* the reference's INT_POW macro (Q:158-159) exactly as x86-64 gcc evaluates it, 32-bit wrap included */
 unsigned qcx_ref_int_pow(double base, double power);
 

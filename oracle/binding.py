@@ -71,6 +71,7 @@ def lib():
         L.orc_measure_range.restype = C.c_int
         L.orc_norm2.argtypes = [dp, C.c_uint]; L.orc_norm2.restype = C.c_double
         L.orc_fill_random.argtypes = [dp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double]
+        L.orc_polar.argtypes = [C.c_double, dp, dp]
         L.orc_ref_intpow.argtypes = [C.c_double, C.c_double]; L.orc_ref_intpow.restype = C.c_uint
         L.orc_modpow.argtypes = [C.c_ulonglong] * 3; L.orc_modpow.restype = C.c_ulonglong
         L.orc_gcd.argtypes = [C.c_uint, C.c_uint]; L.orc_gcd.restype = C.c_uint
@@ -173,6 +174,12 @@ def measure_range(a, first, count, last_excluded, cum_in, r):
     idx = C.c_uint64(0); cum = C.c_double(0.0)
     hit = lib().orc_measure_range(_dp(a), first, count, last_excluded, cum_in, r, C.byref(idx), C.byref(cum))
     return bool(hit), int(idx.value), float(cum.value)
+
+
+def polar(theta):
+    re, im = C.c_double(0.0), C.c_double(0.0)
+    lib().orc_polar(float(theta), C.byref(re), C.byref(im))
+    return re.value, im.value
 
 
 def ref_intpow(b, p): return int(lib().orc_ref_intpow(float(b), float(p)))

@@ -9,6 +9,7 @@
  * -ffp-contract=off matters: the reference's products and sums are separately
  * rounded binary64 operations (plain x86-64 gcc -O2 emits no FMA).
  */
+#define _GNU_SOURCE            /* sincos */
 #include "qcx_oracle.h"
 
 #include <math.h>
@@ -21,6 +22,18 @@
 #ifndef M_SQRT1_2
 #define M_SQRT1_2 0.70710678118654752440
 #endif
+
+/* gsl_complex_polar(1.0, theta) = (1*cos(theta), 1*sin(theta)) (Q:526, Q:323).  Under gcc -O2 the two calls
+ * on the same argument become ONE glibc sincos() call -- in libgsl as much as in a program that inlines it --
+ * and glibc's sincos can differ from its stand-alone sin()/cos() in the last bit.  The oracle pins that
+ * behaviour by calling sincos explicitly instead of depending on what an optimiser does with cos()+sin(). */
+void orc_polar(double theta, double *re, double *im)
+{
+    double sn, cs;
+    sincos(theta, &sn, &cs);
+    *re = 1.0 * cs;
+    *im = 1.0 * sn;
+}
 
 /* bit b of x (qubit b == bit b of the state index, Q:150-151) */
 static inline unsigned bit_of(uint64_t x, unsigned b) { return (unsigned)((x >> b) & 1u); }
@@ -128,8 +141,7 @@ void orc_lit_reset(orc_reg *r)                                   /* Q:318-324 */
 {
     double *s = orc_reg_state(r);
     memset(s, 0, 2 * r->dim * sizeof(double));
-    s[2] = 1.0 * cos(0.0);    /* polar(1, 0) */
-    s[3] = 1.0 * sin(0.0);
+    orc_polar(0.0, &s[2], &s[3]);    /* polar(1, 0) */
 }
 
 /* Q:370-420: zero the other buffer, walk the triplets in insertion order
@@ -176,7 +188,8 @@ void orc_lit_hadamard(unsigned q, orc_reg *r, orc_coo *m)        /* Q:442-484 */
 
 void orc_lit_cphase(unsigned c, unsigned t, double theta, orc_reg *r, orc_coo *m) /* Q:513-565 */
 {
-    const double er = 1.0 * cos(theta), ei = 1.0 * sin(theta);   /* gsl_complex_polar(1, theta), Q:526 */
+    double er, ei;
+    orc_polar(theta, &er, &ei);                                   /* gsl_complex_polar(1, theta), Q:526 */
     for (uint64_t i = 0; i < r->dim; i++)
         for (uint64_t j = 0; j < r->dim; j++) {
             if (!same_elsewhere(i, j, r->n, c, t)) continue;
@@ -286,7 +299,9 @@ void orc_pair_hadamard(double *amp, unsigned n, unsigned q, int threads)
 
 void orc_pair_cphase(double *amp, unsigned n, unsigned c, unsigned t, double theta, int threads)
 {
-    const double er = 1.0 * cos(theta), ei = 1.0 * sin(theta), one = 1.0, z = 0.0;
+    const double one = 1.0, z = 0.0;
+    double er, ei;
+    orc_polar(theta, &er, &ei);
     const uint64_t dim = (uint64_t)1 << n;
     const uint64_t both = ((uint64_t)1 << c) | ((uint64_t)1 << t);
     (void)threads;

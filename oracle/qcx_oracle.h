@@ -108,6 +108,8 @@ double orc_norm2(const double *amp, unsigned n);        /* T:28-37, sequential *
 /* CPU twin of the product's device-side synthetic-state generator */
 void orc_fill_random(double *amp, uint64_t first, uint64_t count, uint64_t seed, double scale);
 
+void orc_polar(double theta, double *re, double *im);   /* gsl_complex_polar(1, theta) as gcc -O2 + glibc evaluate it */
+
 /* ---- host-side scalar helpers restated from the reference ---------------- */
 unsigned orc_ref_intpow(double base, double power);     /* Q:158-159 incl. x86-64 wrap */
 unsigned long long orc_modpow(unsigned long long a, unsigned long long e, unsigned long long m);

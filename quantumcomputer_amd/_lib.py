@@ -46,6 +46,7 @@ SIGNATURES = {
     "qcx_inverse_QFT": (_i, [_p]),
     "qcx_quantum_computation": (_i, [_u, _u, _i, _p]),
     "qcx_ref_int_pow": (_u, [_d, _d]),
+    "qcx_polar": (None, [_d, C.POINTER(_d), C.POINTER(_d)]),
     "qcx_set_fusion": (_i, [_p, _i]),
     "qcx_flush": (_i, [_p]),
     "qcx_fusion_stats": (_i, [_p, C.POINTER(_ul), C.POINTER(_ul)]),
@@ -130,6 +131,13 @@ def lib():
 def check(status, where=""):
     if status != NO_ERROR:
         raise QcxError(status, where)
+
+
+def polar(theta):
+    """(cos, sin) of theta exactly as the gate path computes them (glibc sincos, include/qcx.h: qcx_polar)"""
+    c, s = C.c_double(0.0), C.c_double(0.0)
+    lib().qcx_polar(float(theta), C.byref(c), C.byref(s))
+    return c.value, s.value
 
 
 def tune(**kv):

@@ -94,6 +94,7 @@ struct Tune {
     long fuse_grid_cap = 0;
     long fuse_pipe   = 1;      // fused passes: persistent double-buffered form (fill of tile i+1 under tile i)
     long fuse_pipe_grid = 512; // workgroups of the persistent form
+    long fuse_pruns  = 1;      // rounds form: group equal-selection phases into branch-free runs
     long fuse_rounds = 1;      // fused passes: rounds form (4 amplitudes per thread in registers, radix-4 H steps)
     long fuse_ldsdma = 1;      // fused passes: fill the tile with global_load_lds (LDS-DMA)
     long fuse_max_queue = 4096;
@@ -105,7 +106,7 @@ static Tune g_tune;
 extern "C" int qcx_tune_set(const char *key, long value)
 {
 #define K(name) if (!strcmp(key, #name)) { g_tune.name = value; return QCX_NO_ERROR; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_pipe) K(fuse_pipe_grid)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_pruns) K(fuse_pipe) K(fuse_pipe_grid)
 #undef K
     return QCX_BAD_ARGUMENTS;
 }
@@ -113,7 +114,7 @@ extern "C" int qcx_tune_set(const char *key, long value)
 extern "C" long qcx_tune_get(const char *key)
 {
 #define K(name) if (!strcmp(key, #name)) return g_tune.name;
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_pipe) K(fuse_pipe_grid)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_pruns) K(fuse_pipe) K(fuse_pipe_grid)
 #undef K
     return -1;
 }
@@ -782,12 +783,24 @@ extern "C" int qcx_hadamard_gate(unsigned q, qcx_register *r)
     return qcx_shard_hadamard(r->amp, r->n, q, r->stream);
 }
 
+// e^{i theta} the way the reference obtains it: gsl_complex_polar(1.0, theta) = (1*cos, 1*sin) (Q:526), which
+// gcc -O2 compiles to ONE glibc sincos() call (cos and sin of the same argument are merged).  glibc's sincos
+// and its stand-alone sin/cos can differ in the last bit (e.g. sin(0.20966817126512538)), so sincos is called
+// explicitly here and in the oracle instead of leaving the choice to each compiler.
+extern "C" void qcx_polar(double theta, double *cos_out, double *sin_out)
+{
+    double sn, cs;
+    sincos(theta, &sn, &cs);
+    *cos_out = 1.0 * cs;
+    *sin_out = 1.0 * sn;
+}
+
 extern "C" int qcx_c_phase_shift_gate(unsigned c, unsigned t, double theta, qcx_register *r)
 {
     if (!r) return QCX_BAD_ARGUMENTS;
     if (c >= r->n || t >= r->n || c == t) return QCX_BAD_QUBIT;
-    // gsl_complex_polar(1.0, theta) (Q:526): host libm, so the oracle sees the same two doubles
-    const double er = 1.0 * cos(theta), ei = 1.0 * sin(theta);
+    double er, ei;
+    qcx_polar(theta, &er, &ei);
     if (r->fusion) {
         QGate g; memset(&g, 0, sizeof g);
         g.type = FUSE_PHASE; g.mask = ((uint64_t)1 << c) | ((uint64_t)1 << t); g.c = er; g.s = ei;

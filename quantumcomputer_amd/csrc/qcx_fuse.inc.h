@@ -191,20 +191,31 @@ static int fuse_flush(qcx_register *r)
                 hdr.type = FUSE_ROUND; hdr.a = rb[0] | (rb[1] << 8); hdr.mask = cur.size();
                 out.push_back(hdr);
                 const uint32_t regmask = (1u << rb[0]) | (1u << rb[1]);
+                const size_t hdr_at = out.size() - 1;
+                size_t run_hdr = (size_t)-1; uint32_t run_rsel = 0;
                 for (FuseOp o : cur) {
-                    if (o.type == FUSE_H) o.a = (o.a == rb[0]) ? 0u : 1u;
-                    else {
-                        const uint32_t mr = o.a & regmask;
-                        uint32_t rsel = 0;
-                        for (unsigned q = 0; q < 4; q++) {
-                            const uint32_t bits = ((q & 1u) << rb[0]) | ((q >> 1) << rb[1]);
-                            if ((bits & mr) == mr) rsel |= 1u << q;
+                    if (o.type == FUSE_H) { o.a = (o.a == rb[0]) ? 0u : 1u; run_hdr = (size_t)-1; out.push_back(o); continue; }
+                    const uint32_t mr = o.a & regmask;
+                    uint32_t rsel = 0;
+                    for (unsigned q = 0; q < 4; q++) {
+                        const uint32_t bits = ((q & 1u) << rb[0]) | ((q >> 1) << rb[1]);
+                        if ((bits & mr) == mr) rsel |= 1u << q;
+                    }
+                    o.a &= ~regmask;
+                    o.type = FUSE_PHASE | (rsel << 8);
+                    if (g_tune.fuse_pruns) {
+                        // consecutive phases that rotate the same registers form a run (branch-free kernel loop)
+                        if (run_hdr == (size_t)-1 || rsel != run_rsel) {
+                            FuseOp rh; memset(&rh, 0, sizeof rh);
+                            rh.type = FUSE_PRUN; rh.a = rsel; rh.mask = 0;
+                            run_hdr = out.size(); run_rsel = rsel;
+                            out.push_back(rh);
                         }
-                        o.a &= ~regmask;
-                        o.type = FUSE_PHASE | (rsel << 8);
+                        out[run_hdr].mask++;
                     }
                     out.push_back(o);
                 }
+                out[hdr_at].mask = out.size() - 1 - hdr_at;          // the round spans everything emitted after its header
                 cur.clear(); rb.clear();
             };
             for (size_t k2 = 0; k2 < nops; k2++) {

@@ -740,6 +740,31 @@ __device__ __forceinline__ void rotate_amp(amp_t &v, double cc, double ss)
     v = w;
 }
 
+// A run of consecutive controlled phases that rotate the same registers (RSEL): branch-free body.
+// Lanes (or whole tiles) whose mask test fails rotate by (1, 0) instead, which is exact: (1*x - 0*y) + 0 == x
+// and (1*y + 0*x) + 0 == y for every finite canonical (+0) value, so no control-flow merges and no register
+// copies are needed; the next gate's record is fetched while the current one is applied.
+enum : uint32_t { FUSE_PRUN = 4 };
+
+template <unsigned RSEL>
+__device__ __forceinline__ void fuse_phase_run(amp_t &v0, amp_t &v1, amp_t &v2, amp_t &v3, const FuseOp *__restrict__ rec,
+                                               unsigned count, uint64_t base, unsigned p)
+{
+    uint64_t mext = rec[0].mask;
+    uint32_t mloc = rec[0].a;
+    double cc = rec[0].c, ss = rec[0].s;
+    for (unsigned o = 0; o < count; o++) {
+        const uint64_t mext_c = mext; const uint32_t mloc_c = mloc; const double cc_c = cc, ss_c = ss;
+        if (o + 1 < count) { mext = rec[o + 1].mask; mloc = rec[o + 1].a; cc = rec[o + 1].c; ss = rec[o + 1].s; }
+        const bool go = ((base & mext_c) == mext_c) && ((p & mloc_c) == mloc_c);
+        const double c = go ? cc_c : 1.0, s2 = go ? ss_c : 0.0;
+        if (RSEL & 1u) rotate_amp(v0, c, s2);
+        if (RSEL & 2u) rotate_amp(v1, c, s2);
+        if (RSEL & 4u) rotate_amp(v2, c, s2);
+        if (RSEL & 8u) rotate_amp(v3, c, s2);
+    }
+}
+
 template <int BLOCK, int TT>
 __device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, unsigned short *lut, const FusePass &P, const FuseOp *__restrict__ ops, uint64_t base)
 {
@@ -753,12 +778,33 @@ __device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, unsigned short *l
             const unsigned p = (unsigned)insert_zero(insert_zero(threadIdx.x, rb0), rb1);
             const unsigned e1 = p | (1u << rb0), e2 = p | (1u << rb1), e3 = e1 | (1u << rb1);
             amp_t v0 = tile[p], v1 = tile[e1], v2 = tile[e2], v3 = tile[e3];
-#pragma unroll 4
             for (unsigned o = i + 1; o <= i + cnt; o++) {
                 const uint32_t t = ops[o].type;
                 if ((t & 0xffu) == FUSE_H) {
                     if (ops[o].a == 0) { h_butterfly(v0, v1); h_butterfly(v2, v3); }
                     else               { h_butterfly(v0, v2); h_butterfly(v1, v3); }
+                } else if ((t & 0xffu) == FUSE_PRUN) {
+                    const unsigned rc = (unsigned)ops[o].mask;
+                    const FuseOp *rec = ops + o + 1;
+                    switch (ops[o].a & 0xfu) {
+                    case 1:  fuse_phase_run<1>(v0, v1, v2, v3, rec, rc, base, p); break;
+                    case 2:  fuse_phase_run<2>(v0, v1, v2, v3, rec, rc, base, p); break;
+                    case 3:  fuse_phase_run<3>(v0, v1, v2, v3, rec, rc, base, p); break;
+                    case 4:  fuse_phase_run<4>(v0, v1, v2, v3, rec, rc, base, p); break;
+                    case 5:  fuse_phase_run<5>(v0, v1, v2, v3, rec, rc, base, p); break;
+                    case 6:  fuse_phase_run<6>(v0, v1, v2, v3, rec, rc, base, p); break;
+                    case 7:  fuse_phase_run<7>(v0, v1, v2, v3, rec, rc, base, p); break;
+                    case 8:  fuse_phase_run<8>(v0, v1, v2, v3, rec, rc, base, p); break;
+                    case 9:  fuse_phase_run<9>(v0, v1, v2, v3, rec, rc, base, p); break;
+                    case 10: fuse_phase_run<10>(v0, v1, v2, v3, rec, rc, base, p); break;
+                    case 11: fuse_phase_run<11>(v0, v1, v2, v3, rec, rc, base, p); break;
+                    case 12: fuse_phase_run<12>(v0, v1, v2, v3, rec, rc, base, p); break;
+                    case 13: fuse_phase_run<13>(v0, v1, v2, v3, rec, rc, base, p); break;
+                    case 14: fuse_phase_run<14>(v0, v1, v2, v3, rec, rc, base, p); break;
+                    case 15: fuse_phase_run<15>(v0, v1, v2, v3, rec, rc, base, p); break;
+                    default: break;
+                    }
+                    o += rc;                                              // skip the run's records
                 } else {
                     const uint64_t mext = ops[o].mask;
                     if ((base & mext) != mext) continue;                 // scalar: bits outside the tile

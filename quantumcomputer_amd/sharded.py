@@ -30,7 +30,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from ._lib import check, lib
+from ._lib import check, lib, polar
 
 MIN_EVICT_POS = 6          # never trade away index bits below this: runs of the pack pass stay >= 1 KiB
 
@@ -397,7 +397,8 @@ class ShardedRegister:
     def c_phase_shift_gate(self, c, t, theta):
         if c == t or not (0 <= c < self.num_qubits and 0 <= t < self.num_qubits):
             raise ValueError("bad qubit")
-        self._push(("p", c, t, 1.0 * math.cos(theta), 1.0 * math.sin(theta)))
+        cs, sn = polar(theta)                      # glibc sincos, like the single-GPU path and the reference
+        self._push(("p", c, t, cs, sn))
 
     def c_amodc_gate(self, Cn, atox, ctl):
         if not 0 <= ctl < self.num_qubits:

@@ -123,3 +123,21 @@ def test_product_int_pow_matches_reference_wrap(qc, ob):
     for b, p in [(2, 32), (2, 31), (7, 16), (7, 32), (2, 64), (3, 20), (7, 2), (2, 0), (10, 9), (10, 10)]:
         assert qc.lib().qcx_ref_int_pow(float(b), float(p)) == ob.ref_intpow(b, p)
     assert qc.lib().qcx_ref_int_pow(7.0, 16.0) == 2768600449
+
+
+def test_polar_is_glibc_sincos_in_product_and_oracle(qc, ob):
+    """the phase factor is gsl_complex_polar(1, theta) as gcc -O2 + glibc evaluate it: ONE sincos call.  glibc's
+    sincos and sin() differ in the last bit for some arguments; product, oracle and libm sincos must agree there."""
+    import math
+    m = C.CDLL("libm.so.6")
+    m.sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    th = 0.20966817126512538
+    sn, cs = C.c_double(), C.c_double()
+    m.sincos(th, C.byref(sn), C.byref(cs))
+    assert qc.polar(th) == ob.polar(th) == (cs.value, sn.value)
+    assert sn.value != math.sin(th)                       # the witness: stand-alone sin() rounds the other way here
+    import random
+    rnd = random.Random(5)
+    for _ in range(2000):
+        t = rnd.uniform(-8, 8) if rnd.random() < 0.5 else math.pi / (1 << rnd.randrange(1, 40))
+        assert qc.polar(t) == ob.polar(t)

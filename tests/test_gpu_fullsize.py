@@ -74,7 +74,7 @@ def test_cphase_fullsize_windows_bit_exact(qc, ob, big, c, t):
     big.fill_random(seed)
     qc.c_phase_shift_gate(c, t, theta, big)
     rs = np.random.RandomState(seed)
-    er, ei = 1.0 * math.cos(theta), 1.0 * math.sin(theta)
+    er, ei = ob.polar(theta)                  # glibc sincos, as the gate path and the reference compute it
     starts = {0, (1 << n) - (1 << W)} | {int(x) << W for x in rs.randint(0, 1 << (n - W), 6)}
     starts |= {(((1 << c) | (1 << t)) >> W) << W}            # a window where both bits are set
     for s in sorted(starts):

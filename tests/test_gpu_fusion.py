@@ -14,7 +14,7 @@ def bits(a):
 
 @pytest.fixture()
 def tune_guard(qc):
-    keys = ("fuse_T", "fuse_c", "fuse_grid_cap", "fuse_max_queue", "fuse_rounds", "fuse_pipe", "fuse_ldsdma")
+    keys = ("fuse_T", "fuse_c", "fuse_grid_cap", "fuse_max_queue", "fuse_rounds", "fuse_pipe", "fuse_ldsdma", "fuse_pruns")
     old = {k: qc.lib().qcx_tune_get(k.encode()) for k in keys}
     yield
     qc.tune(**old)
@@ -63,11 +63,11 @@ def test_random_programs_fused_bit_exact(qc, ob, L, M, Cn):
         assert stats[0] > 0 and stats[1] >= stats[0]
 
 
-@pytest.mark.parametrize("rounds,pipe,dma", [(1, 1, 1), (0, 1, 1), (1, 0, 1), (0, 0, 0), (1, 0, 0)])
-def test_kernel_forms(qc, ob, tune_guard, rounds, pipe, dma):
-    """rounds / per-gate op form, persistent double-buffered / plain kernel, LDS-DMA / register fill"""
-    qc.tune(fuse_rounds=rounds, fuse_pipe=pipe, fuse_ldsdma=dma)
-    rs = np.random.RandomState(rounds * 4 + pipe * 2 + dma)
+@pytest.mark.parametrize("rounds,pipe,dma,pruns", [(1, 1, 1, 1), (1, 1, 1, 0), (0, 1, 1, 1), (1, 0, 1, 1), (0, 0, 0, 0), (1, 0, 0, 0)])
+def test_kernel_forms(qc, ob, tune_guard, rounds, pipe, dma, pruns):
+    """rounds / per-gate op form, persistent double-buffered / plain kernel, LDS-DMA / register fill, phase runs"""
+    qc.tune(fuse_rounds=rounds, fuse_pipe=pipe, fuse_ldsdma=dma, fuse_pruns=pruns)
+    rs = np.random.RandomState(rounds * 8 + pipe * 4 + dma * 2 + pruns)
     for (L, M, Cn) in ((13, 5, 21), (16, 4, 15), (20, 0, 1)):
         prog = random_program(rs, L + M, M, Cn, 90)
         got, want, _ = run_both(qc, ob, L, M, Cn, prog, 11)

@@ -62,7 +62,7 @@ def test_shard_entry_points_with_global_bits(pg, ob, qc):
     assert np.array_equal(bits(t.cpu().numpy()), bits(mine))
     # CPHASE(control = qubit 12 (rank bit 2, set on rank 5), target = 4)
     th = math.pi / 16
-    eng.phase(t, nl, 1 << 4, math.cos(th), math.sin(th))
+    eng.phase(t, nl, 1 << 4, *qc.polar(th))
     ob.cphase(full, n, 12, 4, th)
     # C_AMODC with control = qubit 10 (rank bit 0, set on rank 5), M = 5
     eng.camodc(t, nl, 5, 21, 16, -1)

@@ -275,3 +275,39 @@ def test_sharded_overlap_slice_counts(world):
     res = run(world, sc_slice_counts)
     assert all(r[3] for r in res), res
     assert any(r[2] >= 2 and r[4] > 10 for r in res)      # real overlap windows were exercised
+
+
+def sc_random_programs(rank, world, ob, make):
+    """seeded random programs (all gate kinds, random angles / controls / targets) on the sharded register"""
+    res = []
+    for seed in range(6):
+        rs = np.random.RandomState(500 + seed)
+        L, M = int(rs.randint(7, 10)), int(rs.randint(0, 4))
+        n = L + M
+        Cn = int(rs.randint(2, (1 << M) + 1)) if M else 2
+        reg = make(L, M, slices_log2=int(rs.randint(0, 3)), max_queue=int(rs.choice([7, 8192])))
+        reg.fill_random(seed)
+        want = ob.fill_random(n, seed)
+        for _ in range(60):
+            kind = rs.randint(0, 10)
+            if kind < 4:
+                qb = int(rs.randint(0, n)); reg.hadamard_gate(qb); ob.hadamard(want, n, qb)
+            elif kind < 8 or M == 0:
+                c, t = (int(x) for x in rs.choice(n, 2, replace=False))
+                th = float(rs.uniform(-9, 9)) if rs.randint(0, 2) else math.pi / (1 << int(rs.randint(1, 20)))
+                reg.c_phase_shift_gate(c, t, th); ob.cphase(want, n, c, t, th)
+            else:
+                atox, ctl = int(rs.randint(0, 1 << 16)), int(rs.randint(M, n))
+                reg.c_amodc_gate(Cn, atox, ctl); ob.camodc(want, n, M, Cn, atox, ctl)
+        same = bool(np.array_equal(bits(reg.gather()), bits(want)))
+        r = float(rs.uniform(0, 1))
+        w2 = want.copy()
+        same = same and reg.measure_state(r) == ob.measure(w2, n, r)
+        res.append((seed, same))
+    return res
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_random_programs(world):
+    res = run(world, sc_random_programs)
+    assert all(ok for _, ok in res), res

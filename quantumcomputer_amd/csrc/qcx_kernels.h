@@ -756,7 +756,8 @@ __device__ __forceinline__ void fuse_phase_run(amp_t &v0, amp_t &v1, amp_t &v2, 
     for (unsigned o = 0; o < count; o++) {
         const uint64_t mext_c = mext; const uint32_t mloc_c = mloc; const double cc_c = cc, ss_c = ss;
         if (o + 1 < count) { mext = rec[o + 1].mask; mloc = rec[o + 1].a; cc = rec[o + 1].c; ss = rec[o + 1].s; }
-        const bool go = ((base & mext_c) == mext_c) && ((p & mloc_c) == mloc_c);
+        if ((base & mext_c) != mext_c) continue;          // wave-uniform (scalar): a control outside the tile is 0
+        const bool go = (p & mloc_c) == mloc_c;
         const double c = go ? cc_c : 1.0, s2 = go ? ss_c : 0.0;
         if (RSEL & 1u) rotate_amp(v0, c, s2);
         if (RSEL & 2u) rotate_amp(v1, c, s2);

@@ -49,8 +49,9 @@ def main():
         shard_bytes = 16.0 * (1 << nl)
         g = [v for kk, v in res.items() if kk.startswith("global")]
         out.update(n=n, shard_GiB=shard_bytes / 2**30, results=res,
-                   exchange_GBps_per_gpu=shard_bytes * (world - 1) / world / (min(g) * 1e-3 - res["local_h_ms"] * 1e-3) / 1e9,
                    note="a global H = pack + all-to-all of (W-1)/W of the shard + the local gate")
+        if g and min(g) > res["local_h_ms"]:
+            out["exchange_GBps_per_gpu"] = shard_bytes * (world - 1) / world / ((min(g) - res["local_h_ms"]) * 1e-3) / 1e9
     else:
         L, M, Cn, aa = 25, 5, 21, 2
         reg = ShardedRegister(L, M)

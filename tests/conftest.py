@@ -22,6 +22,10 @@ def ob():
 
 @pytest.fixture(scope="session")
 def qc():
+    """the product package; builds libqcx.so first if this is a fresh checkout (hipcc cross-compiles on CPU)"""
+    import subprocess
     import quantumcomputer_amd
+    if not os.path.exists(quantumcomputer_amd.LIB_PATH):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "quantumcomputer_amd", "csrc"), "-s"], check=True)
     quantumcomputer_amd.lib()
     return quantumcomputer_amd

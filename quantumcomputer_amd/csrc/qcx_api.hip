@@ -79,6 +79,7 @@ struct Tune {
     long h_wc        = 0;      // pair form: per-wave-contiguous load order
     long h_block     = 64;     // pair form: threads per block (64/128/256/512)
     long h_streams_log2 = 0;   // pair form: deal tiles as 2^k interleaved streams (3 = one per XCD)
+    long h_skew      = 0;      // pair form: stream j is rotated by j * skew tiles inside its segment
     long h_grid_cap  = 0;      // 0: one tile per block (no cap)
     long h_wave_r    = 4;      // registers per lane, wave-tile form (2, 4 or 8)
     long h_wave_block = 256;   // wave-tile form: threads per block (64 or 256)
@@ -106,7 +107,7 @@ static Tune g_tune;
 extern "C" int qcx_tune_set(const char *key, long value)
 {
 #define K(name) if (!strcmp(key, #name)) { g_tune.name = value; return QCX_NO_ERROR; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_pruns) K(fuse_pipe) K(fuse_pipe_grid)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_pruns) K(fuse_pipe) K(fuse_pipe_grid)
 #undef K
     return QCX_BAD_ARGUMENTS;
 }
@@ -114,7 +115,7 @@ extern "C" int qcx_tune_set(const char *key, long value)
 extern "C" long qcx_tune_get(const char *key)
 {
 #define K(name) if (!strcmp(key, #name)) return g_tune.name;
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_pruns) K(fuse_pipe) K(fuse_pipe_grid)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_pruns) K(fuse_pipe) K(fuse_pipe_grid)
 #undef K
     return -1;
 }
@@ -217,6 +218,7 @@ static void launch_h_pair(const Tune &t, amp_t *a, unsigned q, uint64_t npairs, 
         glog = 31u - (unsigned)__builtin_clz(grid);
         if (t.h_streams_log2 > 0 && (unsigned)t.h_streams_log2 <= glog) slog = (unsigned)t.h_streams_log2;
     }
+    if (slog && t.h_skew > 0) slog |= (unsigned)t.h_skew << 8;
     hipLaunchKernelGGL((k_h_pair<PPT, NTL, NTS, WC, BLOCK>), dim3(grid), dim3(BLOCK), 0, st, a, q, npairs, glog, slog);
 }
 

@@ -70,7 +70,13 @@ __global__ __launch_bounds__(BLOCK) void k_h_pair(amp_t *__restrict__ amp, unsig
     // blocks b, b + 2^slog, ... walk one contiguous region (slog = 3: one stream per XCD under the
     // round-robin block placement; speed only, any placement is correct)
     uint64_t tile0 = blockIdx.x;
-    if (slog) tile0 = ((uint64_t)(blockIdx.x & ((1u << slog) - 1u)) << (glog - slog)) | (blockIdx.x >> slog);
+    if (slog & 0xffu) {
+        // streams; optional skew (slog >> 8): stream j walks its segment rotated by j * skew tiles, so that the
+        // concurrently active windows are NOT a power-of-two distance apart
+        const unsigned sl = slog & 0xffu, skew = slog >> 8;
+        const uint64_t j = blockIdx.x & ((1u << sl) - 1u), pos = blockIdx.x >> sl, seg = (uint64_t)1 << (glog - sl);
+        tile0 = (j << (glog - sl)) | ((pos + j * skew) & (seg - 1));
+    }
     for (uint64_t base = tile0 * (BLOCK * PPT); base < npairs; base += step) {
         amp_t a[PPT], b[PPT];
         uint64_t i0[PPT];

@@ -16,17 +16,15 @@ import quantumcomputer_amd as qc  # noqa: E402
 
 def _v(variant, ppt=1, nt=3, cap=0, r=4, wc=0, blk=256, sl=0, wb=256):
     return dict(h_variant=variant, h_ppt=ppt, h_nt=nt, h_grid_cap=cap, h_wave_r=r, h_wc=wc, h_block=blk,
-                h_streams_log2=sl, h_wave_block=wb)
+                h_streams_log2=sl, h_wave_block=wb, h_skew=0)
 
 
 VARIANTS = {"auto": dict(h_variant=0)}
-for _ppt in (1, 2, 4):
-    for _wc in (0, 1):
-        for _sl in (0, 1, 2, 3, 4):
-            for _blk in (64, 128):
-                if _ppt == 1 and _wc:
-                    continue
-                VARIANTS[f"p{_ppt}{'w' if _wc else ''}_b{_blk}_s{_sl}"] = _v(1, ppt=_ppt, blk=_blk, sl=_sl, wc=_wc)
+for _sl in (1, 2, 3):
+    for _skew in (0, 1237, 4099, 30011, 262147):
+        for _ppt in (1, 2):
+            d = _v(1, ppt=_ppt, blk=64, sl=_sl); d["h_skew"] = _skew
+            VARIANTS[f"p{_ppt}_s{_sl}_k{_skew}"] = d
 
 
 def main():

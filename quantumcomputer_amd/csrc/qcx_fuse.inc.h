@@ -104,7 +104,7 @@ static void build_pass_ops(const qcx_register *r, const std::vector<QGate> &gate
 
 // ROUNDS form: group a pass's records into rounds of at most two distinct H bits (the round's register bits);
 // inside a round consecutive phases that rotate the same registers form runs (FUSE_PRUN)
-static void to_rounds(const std::vector<FuseOp> &legacy, unsigned T, std::vector<FuseOp> &out)
+static void to_rounds(const std::vector<FuseOp> &legacy, unsigned T, std::vector<FuseOp> &out, std::vector<unsigned char> &blob)
 {
     std::vector<FuseOp> cur;
     std::vector<unsigned> rb;
@@ -143,8 +143,34 @@ static void to_rounds(const std::vector<FuseOp> &legacy, unsigned T, std::vector
         out[hdr_at].mask = out.size() - 1 - hdr_at;          // the round spans everything emitted after its header
         cur.clear(); rb.clear();
     };
-    for (const FuseOp &o : legacy) {
-        if (o.type == FUSE_CAMODC) { close_round(); out.push_back(o); }
+    for (size_t li = 0; li < legacy.size(); li++) {
+        const FuseOp &o = legacy[li];
+        if (o.type == FUSE_CAMODC) {
+            close_round();
+            // fold a run of >= 2 consecutive permutation-type multiplies with the same modulus into one gather
+            FuseCamExtra X0; memcpy(&X0, &o.c, sizeof X0);
+            size_t lj = li;
+            while (g_tune.fuse_camruns && lj < legacy.size() && legacy[lj].type == FUSE_CAMODC) {
+                FuseCamExtra X; memcpy(&X, &legacy[lj].c, sizeof X);
+                if (X.d != 1 || X.C != X0.C || X.C > 256 || (legacy[lj].a & 0xffu) != (o.a & 0xffu)) break;
+                lj++;
+            }
+            const size_t cnt = lj - li;
+            if (cnt >= 2 && cnt < 65536) {
+                const unsigned cpad = (X0.C + 31u) & ~31u;
+                FuseOp hdr; memset(&hdr, 0, sizeof hdr);
+                hdr.type = FUSE_CAMRUN; hdr.a = (uint32_t)cnt | (cpad << 16); hdr.mask = blob.size();
+                out.push_back(hdr);
+                for (size_t q = li; q < lj; q++) {
+                    FuseCamExtra X; memcpy(&X, &legacy[q].c, sizeof X);
+                    const size_t at = blob.size();
+                    blob.resize(at + cpad, 0);
+                    for (unsigned x = 0; x < X.C; x++) blob[at + x] = (unsigned char)(((uint64_t)x * X.inv) % X.C);
+                    out.push_back(legacy[q]);
+                }
+                li = lj - 1;
+            } else out.push_back(o);
+        }
         else if (o.type == FUSE_H) {
             if (std::find(rb.begin(), rb.end(), o.a) == rb.end()) {
                 if (rb.size() == 2) close_round();
@@ -161,7 +187,8 @@ static int launch_pass(qcx_register *r, const FusePass &P, const FuseOp *d_ops)
     const unsigned n = r->n;
     const uint64_t ntiles = (uint64_t)1 << (n - P.T);
     const unsigned grid = grid_for(ntiles, 1, g_tune.fuse_grid_cap);
-    const size_t lut_bytes = ((size_t)2 << std::min(12u, (unsigned)r->M)) + 16;   // source table of a modular-multiply step
+    const size_t lut_only = ((size_t)2 << std::min(12u, (unsigned)r->M)) + 16;    // source table of a modular-multiply step
+    const size_t lut_bytes = lut_only + (size_t)P.cam_ctl_local[1];                // + tables of folded multiply runs
     const size_t lds = ((size_t)16 << P.T) + lut_bytes;
     // 4 amplitudes per thread (all loads of a tile in flight at once, few registers): block = 2^T / 4
 #define QCX_FUSE_LAUNCH(B, TTv) do { \
@@ -231,18 +258,28 @@ static int fuse_flush(qcx_register *r)
         act.fused = 1;
         act.ngates = i - first;
         act.P.c = c; act.P.nh = (uint32_t)hbits.size(); act.P.T = c + act.P.nh;
+        act.P.cam_ctl_local[3] = (int32_t)(((size_t)2 << std::min(12u, (unsigned)r->M)) + 16);   // table area sits behind the lut
         for (unsigned j = 0; j < act.P.nh; j++) act.P.hbit[j] = (uint8_t)hbits[j];
         legacy.clear();
         build_pass_ops(r, gates, first, i, c, hbits, legacy);
         act.op_off = all_ops.size();
         if (g_tune.fuse_rounds && act.P.T >= 10 && act.P.T <= 12) {
-            to_rounds(legacy, act.P.T, all_ops);
+            std::vector<unsigned char> blob;
+            to_rounds(legacy, act.P.T, all_ops, blob);
             act.P.cam_ctl_local[0] = 1;
+            if (!blob.empty()) {                 // the tables ride behind the pass's records, padded to whole records
+                blob.resize((blob.size() + sizeof(FuseOp) - 1) / sizeof(FuseOp) * sizeof(FuseOp), 0);
+                act.P.cam_ctl_local[1] = (int32_t)blob.size();
+                act.P.cam_ctl_local[2] = (int32_t)(all_ops.size() - act.op_off);
+                const size_t at = all_ops.size();
+                all_ops.resize(at + blob.size() / sizeof(FuseOp));
+                memcpy(&all_ops[at], blob.data(), blob.size());
+            }
         } else {
             all_ops.insert(all_ops.end(), legacy.begin(), legacy.end());
         }
         act.op_cnt = all_ops.size() - act.op_off;
-        act.P.nops = (uint32_t)act.op_cnt;
+        act.P.nops = (uint32_t)(act.P.cam_ctl_local[1] ? (size_t)act.P.cam_ctl_local[2] : act.op_cnt);
         acts.push_back(act);
     }
 

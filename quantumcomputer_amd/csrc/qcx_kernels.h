@@ -609,7 +609,8 @@ struct FuseCamExtra {           // overlays c, s of a CAMODC op (16 bytes)
 };
 struct FusePass {
     uint32_t nops, T, c, nh;
-    int32_t  cam_ctl_local[4];  // [0]: 1 = ops are in ROUNDS form (fuse_apply_rounds), 0 = one LDS step per gate
+    int32_t  cam_ctl_local[4];  // [0]: 1 = ROUNDS form; [1]: bytes of folded-multiply tables, [2]: their record offset in ops,
+                                // [3]: byte offset of the table area behind the lut in LDS
     uint8_t  hbit[16];          // global bit carried by tile-local bit c + j, ascending
 };
 
@@ -736,7 +737,7 @@ __device__ __forceinline__ void fuse_apply_ops(amp_t *tile, unsigned short *lut,
 //                           register bits set), after ONE test of the remaining local bits per thread and one
 //                           scalar test of the bits outside the tile per tile.
 // Same arithmetic, same order per amplitude as the per-gate kernels.
-enum : uint32_t { FUSE_ROUND = 3 };
+enum : uint32_t { FUSE_ROUND = 3, FUSE_CAMRUN = 5 };
 
 __device__ __forceinline__ void rotate_amp(amp_t &v, double cc, double ss)
 {
@@ -773,7 +774,8 @@ __device__ __forceinline__ void fuse_phase_run(amp_t &v0, amp_t &v1, amp_t &v2, 
 }
 
 template <int BLOCK, int TT>
-__device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, unsigned short *lut, const FusePass &P, const FuseOp *__restrict__ ops, uint64_t base)
+__device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, unsigned short *lut, const unsigned char *camtab,
+                                                  const FusePass &P, const FuseOp *__restrict__ ops, uint64_t base)
 {
     static_assert((1u << TT) == 4u * BLOCK, "rounds form needs 4 amplitudes per thread");
     unsigned i = 0;
@@ -828,6 +830,47 @@ __device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, unsigned short *l
             tile[p] = v0; tile[e1] = v1; tile[e2] = v2; tile[e3] = v3;
             __syncthreads();
             i += 1 + cnt;
+        } else if (type == FUSE_CAMRUN) {
+            // a run of consecutive permutation-type modular multiplies (gcd(A, C) = 1, same C) folded into ONE
+            // gather: inside a 2^M block all amplitudes share the L-register bits, so the run moves the amplitude
+            // of value g from  f0 = (prod of the inverses whose control is set) * g  mod C.  The product is
+            // walked through per-gate tables x -> x * inv_i mod C kept in LDS (camtab); pure data movement, the
+            // same bits as applying the gates one by one.
+            const unsigned cnt = ops[i].a & 0xffffu, cpad = ops[i].a >> 16;
+            const unsigned char *tabs = camtab + (unsigned)ops[i].mask;
+            const FuseOp *rec = ops + i + 1;
+            const unsigned M = rec[0].a & 0xffu, blkmask = (1u << M) - 1u;
+            const unsigned Cn = reinterpret_cast<const FuseCamExtra *>(&rec[0].c)->C;
+            unsigned x0 = 1, x1 = 1, x2 = 1, x3 = 1;
+            for (unsigned g = 0; g < cnt; g++) {
+                const uint64_t mext = rec[g].mask;
+                if ((base & mext) != mext) continue;                      // outside control is 0 for this tile
+                const int cl = (int)((rec[g].a >> 8) & 0xffu) - 1;
+                const unsigned char *tb = tabs + g * cpad;
+                const unsigned e0 = threadIdx.x, e1 = BLOCK + threadIdx.x, e2 = 2 * BLOCK + threadIdx.x, e3 = 3 * BLOCK + threadIdx.x;
+                if (cl < 0 || ((e0 >> cl) & 1u)) x0 = tb[x0];
+                if (cl < 0 || ((e1 >> cl) & 1u)) x1 = tb[x1];
+                if (cl < 0 || ((e2 >> cl) & 1u)) x2 = tb[x2];
+                if (cl < 0 || ((e3 >> cl) & 1u)) x3 = tb[x3];
+            }
+            const unsigned xs[4] = {x0, x1, x2, x3};
+            amp_t acc[4];
+            bool wr[4];
+#pragma unroll
+            for (unsigned k = 0; k < 4; k++) {
+                const unsigned e = k * BLOCK + threadIdx.x, f = e & blkmask;
+                wr[k] = (xs[k] != 1u) && (f < Cn);
+                if (wr[k]) {
+                    const amp_t sv = tile[(e - f) + (xs[k] * f) % Cn];
+                    acc[k].x = 0.0 + sv.x; acc[k].y = 0.0 + sv.y;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (unsigned k = 0; k < 4; k++)
+                if (wr[k]) tile[k * BLOCK + threadIdx.x] = acc[k];
+            __syncthreads();
+            i += 1 + cnt;
         } else {    // FUSE_CAMODC between rounds
             fuse_camodc_step<BLOCK, 4>(tile, lut, ops + i, base, 1u << TT);
             i++;
@@ -844,6 +887,10 @@ __global__ __launch_bounds__(BLOCK) void k_fused(amp_t *__restrict__ amp, unsign
     const unsigned T = TT ? (unsigned)TT : P.T, c = P.c, nh = P.nh;
     const unsigned tsize = 1u << T;
     unsigned short *lut = reinterpret_cast<unsigned short *>(tile + tsize);  // behind the tile (host sizes the LDS)
+    unsigned char *camtab = reinterpret_cast<unsigned char *>(lut) + P.cam_ctl_local[3];   // tables of folded multiply runs
+    for (unsigned b = threadIdx.x; b < (unsigned)P.cam_ctl_local[1]; b += BLOCK)
+        camtab[b] = reinterpret_cast<const unsigned char *>(ops + P.cam_ctl_local[2])[b];
+    __syncthreads();
     constexpr unsigned EPT = TT ? ((1u << TT) + BLOCK - 1) / BLOCK : 16;      // elements per thread (<= 16)
     const unsigned ept = TT ? EPT : (tsize + BLOCK - 1) / BLOCK;
     const unsigned lowmask = (1u << c) - 1u;
@@ -885,7 +932,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(amp_t *__restrict__ amp, unsign
         __syncthreads();
 
         if constexpr (TT != 0 && (1u << TT) == 4u * BLOCK) {
-            if (P.cam_ctl_local[0]) fuse_apply_rounds<BLOCK, TT>(tile, lut, P, ops, base);
+            if (P.cam_ctl_local[0]) fuse_apply_rounds<BLOCK, TT>(tile, lut, camtab, P, ops, base);
             else fuse_apply_ops<BLOCK, TT, EPT>(tile, lut, P, ops, base, off_t, off_k, tsize, ept);
         } else {
             fuse_apply_ops<BLOCK, TT, EPT>(tile, lut, P, ops, base, off_t, off_k, tsize, ept);
@@ -918,6 +965,10 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fused_pipe(amp_t *__restrict__ amp
     constexpr unsigned EPT = tsize / BLOCK;
     static_assert(EPT >= 1 && EPT <= 8, "tile / block geometry");
     unsigned short *lut = reinterpret_cast<unsigned short *>(buf0 + 2 * tsize);   // behind both tile buffers
+    unsigned char *camtab = reinterpret_cast<unsigned char *>(lut) + P.cam_ctl_local[3];   // tables of folded multiply runs
+    for (unsigned b = threadIdx.x; b < (unsigned)P.cam_ctl_local[1]; b += BLOCK)
+        camtab[b] = reinterpret_cast<const unsigned char *>(ops + P.cam_ctl_local[2])[b];
+    __syncthreads();
     const unsigned c = P.c, nh = P.nh;
     const unsigned lowmask = (1u << c) - 1u;
     auto scatter = [&](unsigned e) -> uint64_t {
@@ -963,7 +1014,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fused_pipe(amp_t *__restrict__ amp
         if (tn < ntiles) fill(buf0 + (cur ^ 1) * tsize, tile_base(tn));
 
         if constexpr ((1u << TT) == 4u * BLOCK) {
-            if (P.cam_ctl_local[0]) fuse_apply_rounds<BLOCK, TT>(tile, lut, P, ops, base);
+            if (P.cam_ctl_local[0]) fuse_apply_rounds<BLOCK, TT>(tile, lut, camtab, P, ops, base);
             else fuse_apply_ops<BLOCK, TT, EPT>(tile, lut, P, ops, base, off_t, off_k, tsize, EPT);
         } else {
             fuse_apply_ops<BLOCK, TT, EPT>(tile, lut, P, ops, base, off_t, off_k, tsize, EPT);

@@ -14,7 +14,7 @@ def bits(a):
 
 @pytest.fixture()
 def tune_guard(qc):
-    keys = ("fuse_T", "fuse_c", "fuse_grid_cap", "fuse_max_queue", "fuse_rounds", "fuse_pipe", "fuse_ldsdma", "fuse_pruns")
+    keys = ("fuse_T", "fuse_c", "fuse_grid_cap", "fuse_max_queue", "fuse_rounds", "fuse_pipe", "fuse_ldsdma", "fuse_pruns", "fuse_camruns")
     old = {k: qc.lib().qcx_tune_get(k.encode()) for k in keys}
     yield
     qc.tune(**old)
@@ -158,3 +158,24 @@ def test_fullsize_fused_sweep_matches_unfused_windows(qc):
         for s in (0, 12345 << 13, (1 << n) - (1 << 13), 1 << 27):
             assert np.array_equal(bits(r1.read(s, 1 << 13)), bits(r2.read(s, 1 << 13)))
         assert r2.fusion_stats()[0] <= 6
+
+
+@pytest.mark.parametrize("camruns", [1, 0])
+def test_runs_of_modular_multiplies_fold_exactly(qc, ob, tune_guard, camruns):
+    """consecutive C_AMODC gates (the Shor ladder) are folded into one gather per tile: same bits as one by one;
+    controls inside and outside the tile, identity multipliers, a non-coprime gate breaking the run"""
+    qc.tune(fuse_camruns=camruns)
+    for (L, M, Cn, mults) in ((14, 5, 21, [2, 4, 16, 4, 16, 1, 2, 20, 3, 5, 10, 8, 11, 13]),
+                              (11, 4, 15, [7, 4, 1, 13, 5, 2, 8, 11, 14, 7, 3]),
+                              (12, 8, 255, [2, 4, 16, 1, 7, 254, 128, 13, 17, 3, 64, 32])):
+        n = L + M
+        want = ob.random_state(n, 21)
+        with qc.Register(L, M) as reg:
+            reg.write(want); reg.set_fusion(True)
+            qc.hadamard_gate(n - 1, reg); ob.hadamard(want, n, n - 1)
+            for k, a in enumerate(mults):
+                ctl = M + (k * 5) % L
+                qc.c_amodc_gate(Cn, a, ctl, reg); ob.camodc(want, n, M, Cn, a, ctl)
+            qc.c_phase_shift_gate(n - 1, M, 0.3, reg); ob.cphase(want, n, n - 1, M, 0.3)
+            got = reg.read()
+        assert np.array_equal(bits(got), bits(want)), (L, M, Cn)

@@ -554,6 +554,27 @@ __global__ __launch_bounds__(64) void k_meas_chain(const amp_t *__restrict__ amp
         MeasBlock mine; mine.S = 0; mine.meta = MEAS_ALLZERO; mine.pad = 0;
         if (b0 + lane < nblocks) mine = blocks[b0 + lane];
         const unsigned lim = min(64u, nblocks - b0);
+        {   // group step: when all 64 records are plain (no flag, same binade as the running sum, or all-zero) their
+            // increments simply add up; the sum is monotone, so checking the END of the group (still inside the
+            // binade, still below r) validates every intermediate value -- 64 blocks for the price of one
+            const uint64_t cb = (uint64_t)__double_as_longlong(cum);
+            const int ec = (int)((cb >> 52) & 0x7ff);
+            const bool zero = (mine.meta & MEAS_ALLZERO) != 0;
+            const bool plain = zero || (!(mine.meta & (MEAS_TIE | MEAS_BIG | MEAS_EUNK)) && (int)(mine.meta & 0x7ff) == ec);
+            if (!force && ec != 0 && ec != 0x7ff && __ballot(!plain) == 0ULL) {
+                unsigned long long tot = zero ? 0ULL : (unsigned long long)mine.S;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o, 64);
+                tot = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(tot >> 32), 0) << 32) |
+                      (uint32_t)__builtin_amdgcn_readlane((int)(tot & 0xffffffffu), 0);
+                const uint64_t K = (cb & 0xfffffffffffffULL) | ((uint64_t)1 << 52);
+                const uint64_t Kn = K + tot;
+                if (Kn < ((uint64_t)1 << 53)) {
+                    const double cn = __longlong_as_double((long long)(((uint64_t)ec << 52) | (Kn & 0xfffffffffffffULL)));
+                    if (!(cn >= r)) { cum = cn; continue; }
+                }
+            }
+        }
         for (unsigned j = 0; j < lim; j++) {
             const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)mine.meta, j);
             if ((meta & MEAS_ALLZERO) && !force) continue;

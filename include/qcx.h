@@ -147,6 +147,16 @@ int  qcx_shard_camodc(void *amp, unsigned n_local, unsigned M, unsigned C, unsig
 int  qcx_shard_swap_bits(const void *src, void *dst, unsigned n_local, unsigned npairs,
                          const unsigned *pos_a, const unsigned *pos_b, void *stream);
 int  qcx_shard_norm2(const void *amp, unsigned n_local, double *out, void *stream);
+/* a list of gates on a shard, executed through the fusion scheduler (fused LDS-tile passes, same bits as the
+ * one-by-one entry points).  All bit positions are LOCAL index bits of the shard. */
+typedef struct {
+    uint32_t type;      /* 0: Hadamard, 1: phase, 2: controlled modular multiply */
+    uint32_t q;         /* Hadamard: target bit;  modular multiply: control bit, or 0xffffffff = always on */
+    uint64_t mask;      /* phase: local bits that must all be 1 (0 = every amplitude of the shard) */
+    double   c, s;      /* phase: cos, sin (qcx_polar) */
+    uint32_t C, A;      /* modular multiply: modulus and multiplier (A < C) */
+} qcx_gate_desc;
+int  qcx_shard_run_fused(void *amp, unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates, void *stream);
 /* sequential cumulative scan of |amp|^2 over this shard continuing from cum_in
  * (global index of local 0 = first_global; indices >= last_excluded are not
  * examined, Q:283).  Synchronous. */

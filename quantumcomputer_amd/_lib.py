@@ -74,6 +74,7 @@ SIGNATURES = {
     "qcx_shard_camodc": (_i, [_p, _u, _u, _u, _u, _i, _p]),
     "qcx_shard_swap_bits": (_i, [_p, _p, _u, _u, C.POINTER(_u), C.POINTER(_u), _p]),
     "qcx_shard_norm2": (_i, [_p, _u, C.POINTER(_d), _p]),
+    "qcx_shard_run_fused": (_i, [_p, _u, _u, _u, _p, _p]),
     "qcx_shard_measure_scan": (_i, [_p, _u, _u64, _u64, _d, _d, C.POINTER(_i), C.POINTER(_u64), C.POINTER(_d), _p]),
     "qcx_shard_collapse": (_i, [_p, _u, _i64, _p]),
 }
@@ -84,6 +85,12 @@ _EXTRA = {
     "qcx_tune_get": (C.c_long, [C.c_char_p]),
     "qcx_measure_last_stats": (_i, [C.POINTER(_u), C.POINTER(_u)]),
 }
+
+class GateDesc(C.Structure):
+    """qcx_gate_desc (include/qcx.h)"""
+    _fields_ = [("type", C.c_uint32), ("q", C.c_uint32), ("mask", C.c_uint64), ("c", C.c_double), ("s", C.c_double),
+                ("C", C.c_uint32), ("A", C.c_uint32)]
+
 
 _lib = None
 

@@ -729,6 +729,47 @@ extern "C" int qcx_L_size(const qcx_register *r) { return r ? r->L : 0; }
 extern "C" int qcx_M_size(const qcx_register *r) { return r ? r->M : 0; }
 extern "C" void *qcx_device_pointer(qcx_register *r) { if (r) (void)fuse_flush(r); return r ? (void *)r->amp : nullptr; }
 
+// shard-level gate list through the fusion scheduler (one queue per device, one user at a time)
+static GateQueue *g_shard_queue[64];
+static std::mutex g_shard_queue_mutex[64];
+
+extern "C" int qcx_shard_run_fused(void *amp, unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates, void *stream)
+{
+    if (!amp || n_local == 0 || n_local > 40 || M > n_local || (count && !gates)) return QCX_BAD_ARGUMENTS;
+    if (M > 12) return QCX_UNSUPPORTED;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return QCX_HIP_ERROR;
+    std::lock_guard<std::mutex> lock(g_shard_queue_mutex[dev]);
+    if (!g_shard_queue[dev]) g_shard_queue[dev] = new GateQueue();
+    qcx_register tmp;
+    memset(&tmp, 0, sizeof tmp);
+    tmp.L = (int)(n_local - M); tmp.M = (int)M; tmp.n = n_local; tmp.dim = (uint64_t)1 << n_local;
+    tmp.amp = (amp_t *)amp; tmp.stream = tmp.own_stream = (hipStream_t)stream;
+    tmp.fusion = 1; tmp.queue = g_shard_queue[dev];
+    tmp.queue->gates.clear();
+    for (unsigned k = 0; k < count; k++) {
+        const qcx_gate_desc &d = gates[k];
+        QGate g; memset(&g, 0, sizeof g);
+        if (d.type == 0) {
+            if (d.q >= n_local) return QCX_BAD_QUBIT;
+            g.type = FUSE_H; g.q = d.q;
+        } else if (d.type == 1) {
+            if (n_local < 64 && (d.mask >> n_local) != 0) return QCX_BAD_QUBIT;
+            if (__builtin_popcountll(d.mask) > 2) return QCX_BAD_ARGUMENTS;
+            g.type = FUSE_PHASE; g.mask = d.mask; g.c = d.c; g.s = d.s;
+        } else if (d.type == 2) {
+            if (d.C == 0 || (d.q != 0xffffffffu && d.q >= n_local)) return QCX_BAD_ARGUMENTS;
+            g.q = d.q; g.C = d.C; g.A = d.A % d.C;
+            const bool closed = (d.q == 0xffffffffu) ? camodc_closed_form(n_local, M, d.C, g.A, M)   // "control" outside M
+                                                     : camodc_closed_form(n_local, M, d.C, g.A, d.q);
+            g.type = closed ? (uint32_t)FUSE_CAMODC : 99u;
+        } else return QCX_BAD_ARGUMENTS;
+        tmp.queue->gates.push_back(g);
+    }
+    return fuse_flush(&tmp);
+}
+
 // gate fusion: 1 = queue gates and run them as fused LDS-tile passes; results are
 // bit-identical to the per-gate kernels.  Observing calls (read, norm, measure, synchronize, timers) flush.
 extern "C" int qcx_set_fusion(qcx_register *r, int enable)

@@ -58,6 +58,8 @@ static int launch_standalone(qcx_register *r, const QGate &g)
 {
     if (g.type == FUSE_H) return qcx_shard_hadamard(r->amp, r->n, g.q, r->stream);
     if (g.type == FUSE_PHASE) return qcx_shard_phase(r->amp, r->n, g.mask, g.c, g.s, r->stream);
+    if (g.q == 0xffffffffu)          // shard mode: the control is a rank bit that is 1
+        return qcx_shard_camodc(r->amp, r->n, (unsigned)r->M, g.C, g.A, -1, r->stream);
     return reg_camodc(r, g.C, g.A, g.q);
 }
 
@@ -91,9 +93,11 @@ static void build_pass_ops(const qcx_register *r, const std::vector<QGate> &gate
             o.a = mloc; o.mask = mext; o.c = g.c; o.s = g.s;
         } else {
             // control: tile-local position (+1) in bits 8.., or an outside bit tested against the tile base
-            const unsigned lb = local_of(g.q, &in);
+            unsigned lb = 0;
+            in = false;
+            if (g.q != 0xffffffffu) lb = local_of(g.q, &in);
             o.a = (unsigned)r->M | ((in ? lb + 1 : 0u) << 8);
-            o.mask = in ? 0 : (uint64_t)1 << g.q;
+            o.mask = (in || g.q == 0xffffffffu) ? 0 : (uint64_t)1 << g.q;     // 0xffffffff: always on
             FuseCamExtra X;
             X.C = g.C; X.d = gcd_u32(g.A, g.C); X.Cd = g.C / X.d; X.inv = modinv_u32(g.A / X.d, X.Cd);
             memcpy(&o.c, &X, sizeof X);

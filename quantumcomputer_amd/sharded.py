@@ -30,7 +30,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from ._lib import check, lib, polar
+from ._lib import GateDesc, check, lib, polar
 
 MIN_EVICT_POS = 6          # never trade away index bits below this: runs of the pack pass stay >= 1 KiB
 
@@ -67,6 +67,15 @@ class HipEngine:
     def camodc(self, t, n_local, M, Cn, A, ctl_local):
         check(lib().qcx_shard_camodc(self._p(t), n_local, M, Cn, A, ctl_local, self._s()), "qcx_shard_camodc")
 
+    def run_ops(self, t, n_local, M, descs):
+        """a list of (type, q, mask, c, s, C, A) tuples through the fusion scheduler (qcx_shard_run_fused)"""
+        if not descs:
+            return
+        arr = (GateDesc * len(descs))()
+        for i, d in enumerate(descs):
+            arr[i].type, arr[i].q, arr[i].mask, arr[i].c, arr[i].s, arr[i].C, arr[i].A = d
+        check(lib().qcx_shard_run_fused(self._p(t), n_local, M, len(descs), C.cast(arr, C.c_void_p), self._s()), "qcx_shard_run_fused")
+
     def swap_bits(self, src, dst, n_local, pos_a, pos_b):
         m = len(pos_a)
         a = (C.c_uint * max(m, 1))(*pos_a)
@@ -92,7 +101,7 @@ class ShardedRegister:
     """Register (qc_shor.c:194-203) sharded by its top log2(world) physical index bits."""
 
     def __init__(self, L_size, M_size, device=None, group=None, engine=None, max_queue=8192, slices_log2=None,
-                 dry_run=False):
+                 dry_run=False, fusion=False):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -120,6 +129,7 @@ class ShardedRegister:
         self.zone_lo = self.slice_bits - k
         self.overlap = os.environ.get("QCX_SHARD_OVERLAP", "1") != "0"
         self.overlapped_gates = 0
+        self.fusion = bool(fusion)         # run gate lists through the fused-pass scheduler (same bits, fewer HBM passes)
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = torch.device(device)
@@ -309,6 +319,43 @@ class ShardedRegister:
             ev1.record()
             self.profile.append((op[0], op[1] if op[0] == "h" else -1, ev0, ev1, nbits))
 
+    def _run_ops(self, ops, view, nbits, sidx):
+        """a list of resolved operations on one view: one by one, or as ONE fused gate list"""
+        if not ops:
+            return
+        if not (self.fusion and hasattr(self.engine, "run_ops")):
+            for op in ops:
+                self._run(op, view, nbits, sidx)
+            return
+        descs = []
+        for op in ops:
+            if op[0] == "h":
+                assert op[1] < nbits
+                descs.append((0, op[1], 0, 0.0, 0.0, 0, 0))
+            elif op[0] == "p":
+                mask, skip = 0, False
+                for pq in (op[1], op[2]):
+                    if pq >= nbits:
+                        skip = skip or not self._bit_outside(pq, nbits, sidx)
+                    else:
+                        mask |= 1 << pq
+                if not skip:
+                    descs.append((1, 0, mask, op[3], op[4], 0, 0))
+            else:
+                pc = op[3]
+                if pc >= nbits:
+                    if self._bit_outside(pc, nbits, sidx):
+                        descs.append((2, 0xFFFFFFFF, 0, 0.0, 0.0, op[1], op[2]))
+                else:
+                    descs.append((2, pc, 0, 0.0, 0.0, op[1], op[2]))
+        ev0 = None
+        if self.profile is not None and self.device.type == "cuda":
+            ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True); ev0.record()
+        self.engine.run_ops(view, nbits, self.M_size, descs)
+        if ev0 is not None:
+            ev1.record()
+            self.profile.append(("f", -1, ev0, ev1, nbits))
+
     def _sliceable(self, g):
         """may this queued gate run slice by slice under the current layout?  (an H must not target a spectator
         bit, nor a qubit of the rank id)"""
@@ -322,16 +369,14 @@ class ShardedRegister:
         while i < len(q):
             x = next((j for j in range(i, len(q)) if q[j][0] == "h" and self.perm[q[j][1]] >= nl), None)
             if x is None:
-                for g in q[i:]:
-                    self._run(self._resolve(g), self.shard, nl, 0)
+                self._run_ops([self._resolve(g) for g in q[i:]], self.shard, nl, 0)
                 break
             # gates that can share the pipeline with the exchange at x: a run before it ...
             a = x
             if S > 1 and self.overlap:
                 while a > i and self._sliceable(q[a - 1]):
                     a -= 1
-            for g in q[i:a]:
-                self._run(self._resolve(g), self.shard, nl, 0)
+            self._run_ops([self._resolve(g) for g in q[i:a]], self.shard, nl, 0)
             pre_ops = [self._resolve(g) for g in q[a:x]]            # resolved under the layout before the trade
             swaps = self._plan_give(self._choose_give(x))
             self._book(swaps, True)
@@ -350,18 +395,15 @@ class ShardedRegister:
             src_views = self._views(src_buf)
             works, outs = [None] * S, [None] * S
             for sidx in range(S):
-                for op in pre_ops:
-                    self._run(op, src_views[sidx], self.slice_bits, sidx)
+                self._run_ops(pre_ops, src_views[sidx], self.slice_bits, sidx)
                 works[sidx], outs[sidx] = self._move_slice(sidx, swaps, src_buf, dst_buf, True)
                 if sidx >= 1:
                     works[sidx - 1].wait()
                     view = self._views(outs[sidx - 1])[sidx - 1]
-                    for op in post_ops:
-                        self._run(op, view, self.slice_bits, sidx - 1)
+                    self._run_ops(post_ops, view, self.slice_bits, sidx - 1)
             works[S - 1].wait()
             view = self._views(outs[S - 1])[S - 1]
-            for op in post_ops:
-                self._run(op, view, self.slice_bits, S - 1)
+            self._run_ops(post_ops, view, self.slice_bits, S - 1)
             if outs[0] is dst_buf:
                 self.cur ^= 1
             self.exchanges += 1

@@ -70,3 +70,41 @@ def test_shard_entry_points_with_global_bits(pg, ob, qc):
     eng.hadamard(t, nl, 7)
     ob.hadamard(full, n, 7)
     assert np.array_equal(bits(t.cpu().numpy()), bits(full[(rank << nl) * 2:((rank + 1) << nl) * 2]))
+
+
+def test_shard_run_fused_gate_list(pg, ob, qc):
+    """qcx_shard_run_fused: a gate list on a shard (rank-bit controls folded in: always-on multiply, reduced phase
+    masks) through the fusion scheduler equals the same gates applied one by one by the oracle"""
+    import torch
+    from quantumcomputer_amd.sharded import HipEngine
+    rs = np.random.RandomState(77)
+    nl, M, Cn = 15, 5, 21
+    eng = HipEngine("cuda:0")
+    for trial in range(4):
+        want = ob.random_state(nl, 90 + trial)
+        t = torch.from_numpy(want.copy()).to("cuda:0")
+        descs = []
+        for _ in range(70):
+            k = rs.randint(0, 10)
+            if k < 4:
+                q = int(rs.randint(0, nl)); descs.append((0, q, 0, 0.0, 0.0, 0, 0)); ob.hadamard(want, nl, q)
+            elif k < 8:
+                nb = int(rs.randint(0, 3))
+                bits_ = [int(b) for b in rs.choice(nl, nb, replace=False)]
+                mask = sum(1 << b for b in bits_)
+                c, s = qc.polar(float(rs.uniform(-4, 4)))
+                descs.append((1, 0, mask, c, s, 0, 0))
+                v = want.reshape(-1, 2); idx = np.arange(v.shape[0]); sel = (idx & mask) == mask
+                re, im = v[sel, 0].copy(), v[sel, 1].copy()
+                v[sel, 0] = 0.0 + ((c * re) - (s * im)); v[sel, 1] = 0.0 + ((c * im) + (s * re))
+            else:
+                A = int(rs.randint(0, Cn))
+                if rs.randint(0, 2):
+                    ctl = int(rs.randint(M, nl)); descs.append((2, ctl, 0, 0.0, 0.0, Cn, A)); ob.camodc(want, nl, M, Cn, A, ctl)
+                else:                                   # control = a rank bit that is 1: every block moves
+                    descs.append((2, 0xFFFFFFFF, 0, 0.0, 0.0, Cn, A))
+                    ext = np.concatenate([np.zeros_like(want), want]); ob.camodc(ext, nl + 1, M, Cn, A, nl)
+                    want[:] = ext[want.size:]
+        eng.run_ops(t, nl, M, descs)
+        got = t.cpu().numpy()
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), trial

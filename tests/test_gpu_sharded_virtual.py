@@ -126,14 +126,14 @@ def test_virtual_ranks_sweeps_and_mixed_gates(ob, world, slices):
         assert outs[0][1][1] > 10
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_virtual_ranks_shor_and_measurement(ob, world):
+@pytest.mark.parametrize("world,fusion", [(2, False), (4, False), (2, True), (4, True)])
+def test_virtual_ranks_shor_and_measurement(ob, world, fusion):
     L, M, Cn, a = 13, 5, 21, 2
     n = L + M
     r = 0.4142135623
 
     def body(rank, SR):
-        reg = SR(L, M)
+        reg = SR(L, M, fusion=fusion)
         reg.reset_register()
         reg.quantum_computation(Cn, a)
         state = reg.gather()

@@ -55,6 +55,16 @@ class OracleEngine:
             new[:, d, :] += v[:, f, :]
         v[...] = new
 
+    def run_ops(self, t, n_local, M, descs):
+        """the fused gate-list entry point, emulated gate by gate (same semantics as qcx_shard_run_fused)"""
+        for typ, q, mask, c, s, Cn, A in descs:
+            if typ == 0:
+                self.hadamard(t, n_local, q)
+            elif typ == 1:
+                self.phase(t, n_local, mask, c, s)
+            else:
+                self.camodc(t, n_local, M, Cn, A, -1 if q == 0xFFFFFFFF else q)
+
     def swap_bits(self, src, dst, n_local, pos_a, pos_b):
         j = np.arange(1 << n_local, dtype=np.int64)
         i = j.copy()
@@ -285,7 +295,7 @@ def sc_random_programs(rank, world, ob, make):
         L, M = int(rs.randint(7, 10)), int(rs.randint(0, 4))
         n = L + M
         Cn = int(rs.randint(2, (1 << M) + 1)) if M else 2
-        reg = make(L, M, slices_log2=int(rs.randint(0, 3)), max_queue=int(rs.choice([7, 8192])))
+        reg = make(L, M, slices_log2=int(rs.randint(0, 3)), max_queue=int(rs.choice([7, 8192])), fusion=bool(seed % 2))
         reg.fill_random(seed)
         want = ob.fill_random(n, seed)
         for _ in range(60):

@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=int, default=4)
     ap.add_argument("--n", type=int, default=0)
+    ap.add_argument("--fused", action="store_true", help="run gate lists through the fused-pass scheduler")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -54,7 +55,7 @@ def main():
             out["exchange_GBps_per_gpu"] = shard_bytes * (world - 1) / world / ((min(g) - res["local_h_ms"]) * 1e-3) / 1e9
     else:
         L, M, Cn, aa = 25, 5, 21, 2
-        reg = ShardedRegister(L, M)
+        reg = ShardedRegister(L, M, fusion=a.fused)
 
         def circuit():
             reg.reset_register(); reg.quantum_computation(Cn, aa); reg.synchronize()
@@ -68,7 +69,7 @@ def main():
             xt |= ((idx >> (L + M - 1 - p)) & 1) << p
         w = xt / float(1 << L)
         gates = 3 * L + L * (L - 1) // 2
-        out.update(n=L + M, gates=gates, circuit_seconds=dt, amplitude_updates_per_s=gates * 2.0 ** (L + M) / dt,
+        out.update(n=L + M, gates=gates, fused=bool(a.fused), circuit_seconds=dt, amplitude_updates_per_s=gates * 2.0 ** (L + M) / dt,
                    exchanges=reg.exchanges, measure_seconds=tm, measured_index=idx, omega=w,
                    nearest_sixth=min((abs(w - j / 6.0), j) for j in range(7))[1], total_probability=nrm)
     if rank == 0:

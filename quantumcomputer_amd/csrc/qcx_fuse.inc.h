@@ -118,13 +118,18 @@ static void to_rounds(const std::vector<FuseOp> &legacy, unsigned T, std::vector
             if (std::find(rb.begin(), rb.end(), b) == rb.end()) rb.push_back(b);
         std::sort(rb.begin(), rb.end());
         FuseOp hdr; memset(&hdr, 0, sizeof hdr);
-        hdr.type = FUSE_ROUND; hdr.a = rb[0] | (rb[1] << 8);
+        bool has_h = false;
+        for (const FuseOp &o : cur) has_h |= (o.type == FUSE_H);
+        hdr.type = FUSE_ROUND; hdr.a = rb[0] | (rb[1] << 8) | ((has_h ? 1u : 0u) << 16);
         out.push_back(hdr);
         const size_t hdr_at = out.size() - 1;
         const uint32_t regmask = (1u << rb[0]) | (1u << rb[1]);
         size_t run_hdr = (size_t)-1; uint32_t run_rsel = 0;
         for (FuseOp o : cur) {
-            if (o.type == FUSE_H) { o.a = (o.a == rb[0]) ? 0u : 1u; run_hdr = (size_t)-1; out.push_back(o); continue; }
+            if (o.type == FUSE_H) {          // item headers carry everything in their first dword (one scalar load per item)
+                o.a = (o.a == rb[0]) ? 0u : 1u; o.type = FUSE_H | ((32u | o.a) << 8);
+                run_hdr = (size_t)-1; out.push_back(o); continue;
+            }
             const uint32_t mr = o.a & regmask;
             uint32_t rsel = 0;
             for (unsigned q = 0; q < 4; q++) {
@@ -133,14 +138,15 @@ static void to_rounds(const std::vector<FuseOp> &legacy, unsigned T, std::vector
             }
             o.a &= ~regmask;
             o.type = FUSE_PHASE | (rsel << 8);
-            if (g_tune.fuse_pruns) {
-                if (run_hdr == (size_t)-1 || rsel != run_rsel) {
+            {
+                if (run_hdr == (size_t)-1 || rsel != run_rsel || out[run_hdr].mask >= 64u) {
                     FuseOp rh; memset(&rh, 0, sizeof rh);
-                    rh.type = FUSE_PRUN; rh.a = rsel;
+                    rh.type = FUSE_PRUN | (rsel << 8); rh.a = rsel;
                     run_hdr = out.size(); run_rsel = rsel;
                     out.push_back(rh);
                 }
                 out[run_hdr].mask++;
+                out[run_hdr].type += 1u << 16;           // gates of the run, next to the kind and rsel
             }
             out.push_back(o);
         }
@@ -186,27 +192,33 @@ static void to_rounds(const std::vector<FuseOp> &legacy, unsigned T, std::vector
     close_round();
 }
 
-static int launch_pass(qcx_register *r, const FusePass &P, const FuseOp *d_ops)
+static int launch_pass(qcx_register *r, const FusePass &P_in, const FuseOp *d_ops)
 {
+    FusePass P = P_in;
     const unsigned n = r->n;
     const uint64_t ntiles = (uint64_t)1 << (n - P.T);
     const unsigned grid = grid_for(ntiles, 1, g_tune.fuse_grid_cap);
     const size_t lut_only = ((size_t)2 << std::min(12u, (unsigned)r->M)) + 16;    // source table of a modular-multiply step
-    const size_t lut_bytes = lut_only + (size_t)P.cam_ctl_local[1];                // + tables of folded multiply runs
+    size_t lut_bytes = lut_only + (size_t)P.cam_ctl_local[1];                      // + tables of folded multiply runs
+    P.xm_off = 0;
+    if (P.xm_cnt) {                                                                // + the records' outside-tile masks (phase runs)
+        P.xm_off = (uint32_t)((lut_bytes + 7) & ~(size_t)7);
+        lut_bytes = P.xm_off + 8 * (size_t)P.xm_cnt;
+    }
     const size_t lds = ((size_t)16 << P.T) + lut_bytes;
     // 4 amplitudes per thread (all loads of a tile in flight at once, few registers): block = 2^T / 4
 #define QCX_FUSE_LAUNCH(B, TTv) do { \
         if (g_tune.fuse_pipe && ntiles >= 4096) { \
             const unsigned pg = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)g_tune.fuse_pipe_grid); \
-            hipLaunchKernelGGL((k_fused_pipe<B, TTv>), dim3(pg), dim3(B), 2 * ((size_t)16 << P.T) + lut_bytes, r->stream, r->amp, n, P, d_ops, ntiles); \
-        } else if (g_tune.fuse_ldsdma) hipLaunchKernelGGL((k_fused<B, TTv, true>), dim3(grid), dim3(B), lds, r->stream, r->amp, n, P, d_ops, ntiles); \
-        else hipLaunchKernelGGL((k_fused<B, TTv, false>), dim3(grid), dim3(B), lds, r->stream, r->amp, n, P, d_ops, ntiles); } while (0)
+            hipLaunchKernelGGL((k_fused_pipe<B, TTv>), dim3(pg), dim3(B), 2 * ((size_t)16 << P.T) + lut_bytes, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); \
+        } else if (g_tune.fuse_ldsdma) hipLaunchKernelGGL((k_fused<B, TTv, true>), dim3(grid), dim3(B), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); \
+        else hipLaunchKernelGGL((k_fused<B, TTv, false>), dim3(grid), dim3(B), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); } while (0)
     switch (P.T) {
     case 12: QCX_FUSE_LAUNCH(1024, 12); break;
     case 11: QCX_FUSE_LAUNCH(512, 11); break;
     case 10: QCX_FUSE_LAUNCH(256, 10); break;
     case 9:  QCX_FUSE_LAUNCH(256, 9); break;
-    default: hipLaunchKernelGGL((k_fused<256, 0, false>), dim3(grid), dim3(256), lds, r->stream, r->amp, n, P, d_ops, ntiles); break;
+    default: hipLaunchKernelGGL((k_fused<256, 0, false>), dim3(grid), dim3(256), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); break;
     }
 #undef QCX_FUSE_LAUNCH
     HIP_TRY(hipGetLastError());
@@ -267,23 +279,52 @@ static int fuse_flush(qcx_register *r)
         legacy.clear();
         build_pass_ops(r, gates, first, i, c, hbits, legacy);
         act.op_off = all_ops.size();
-        if (g_tune.fuse_rounds && act.P.T >= 10 && act.P.T <= 12) {
+        bool rounds = g_tune.fuse_rounds && act.P.T >= 10 && act.P.T <= 12;
+        if (rounds) {
+            // ROUNDS form: phases run as "phase runs", which need the records' outside-tile masks in LDS next to the
+            // tiles (8 B per record); when that would cost a resident workgroup the pass uses the plain gate list
             std::vector<unsigned char> blob;
             to_rounds(legacy, act.P.T, all_ops, blob);
-            act.P.cam_ctl_local[0] = 1;
-            if (!blob.empty()) {                 // the tables ride behind the pass's records, padded to whole records
-                blob.resize((blob.size() + sizeof(FuseOp) - 1) / sizeof(FuseOp) * sizeof(FuseOp), 0);
-                act.P.cam_ctl_local[1] = (int32_t)blob.size();
-                act.P.cam_ctl_local[2] = (int32_t)(all_ops.size() - act.op_off);
-                const size_t at = all_ops.size();
-                all_ops.resize(at + blob.size() / sizeof(FuseOp));
-                memcpy(&all_ops[at], blob.data(), blob.size());
+            const size_t nrec = all_ops.size() - act.op_off;
+            const size_t lds = 2 * ((size_t)16 << act.P.T) + (size_t)act.P.cam_ctl_local[3] + blob.size() + 64 + 8 * nrec;
+            const size_t limit = (size_t)160 * 1024 / (act.P.T == 12 ? 1 : act.P.T == 11 ? 2 : 4);
+            if (lds > limit) { all_ops.resize(act.op_off); rounds = false; }
+            else {
+                act.P.xm_cnt = (uint32_t)nrec;
+                act.P.cam_ctl_local[0] = 1;
+                if (!blob.empty()) {             // the tables ride behind the pass's records, padded to whole records
+                    blob.resize((blob.size() + sizeof(FuseOp) - 1) / sizeof(FuseOp) * sizeof(FuseOp), 0);
+                    act.P.cam_ctl_local[1] = (int32_t)blob.size();
+                    act.P.cam_ctl_local[2] = (int32_t)(all_ops.size() - act.op_off);
+                    const size_t at = all_ops.size();
+                    all_ops.resize(at + blob.size() / sizeof(FuseOp));
+                    memcpy(&all_ops[at], blob.data(), blob.size());
+                }
             }
-        } else {
-            all_ops.insert(all_ops.end(), legacy.begin(), legacy.end());
         }
+        if (!rounds) all_ops.insert(all_ops.end(), legacy.begin(), legacy.end());
         act.op_cnt = all_ops.size() - act.op_off;
         act.P.nops = (uint32_t)(act.P.cam_ctl_local[1] ? (size_t)act.P.cam_ctl_local[2] : act.op_cnt);
+        static const bool dump = getenv("QCX_FUSE_DUMP") != nullptr;      // planner diagnostics (tools/probe_fuse3.py)
+        if (dump) {
+            unsigned nround = 0, nh = 0, nrun = 0, nsingle = 0, ncam = 0, run_gates[16] = {0}, ext = 0, loc = 0;
+            for (size_t q = act.op_off; q < act.op_off + act.P.nops; q++) {
+                const FuseOp &o = all_ops[q];
+                switch (o.type & 0xffu) {
+                case FUSE_ROUND: nround++; break;
+                case FUSE_H: nh++; break;
+                case FUSE_PRUN: nrun++; run_gates[o.a & 15u] += (unsigned)o.mask; break;
+                case FUSE_PHASE: nsingle++; if (o.mask) ext++; if (o.a) loc++; break;
+                default: ncam++; break;
+                }
+            }
+            fprintf(stderr, "[qcx fuse] pass T=%u c=%u hot=", act.P.T, act.P.c);
+            for (unsigned j = 0; j < act.P.nh; j++) fprintf(stderr, "%u,", act.P.hbit[j]);
+            fprintf(stderr, " gates=%zu records=%u rounds=%u H=%u runs=%u phases=%u (ext-ctl %u, lane-ctl %u) other=%u run gates by rsel:",
+                    act.ngates, act.P.nops, nround, nh, nrun, nsingle, ext, loc, ncam);
+            for (unsigned q = 1; q < 16; q++) if (run_gates[q]) fprintf(stderr, " %x:%u", q, run_gates[q]);
+            fprintf(stderr, "\n");
+        }
         acts.push_back(act);
     }
 

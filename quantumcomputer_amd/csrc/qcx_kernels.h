@@ -633,6 +633,7 @@ struct FusePass {
     int32_t  cam_ctl_local[4];  // [0]: 1 = ROUNDS form; [1]: bytes of folded-multiply tables, [2]: their record offset in ops,
                                 // [3]: byte offset of the table area behind the lut in LDS
     uint8_t  hbit[16];          // global bit carried by tile-local bit c + j, ascending
+    uint32_t xm_off, xm_cnt;    // LDS copy of the records' outside-tile masks: byte offset behind the lut, entries (0 = none)
 };
 
 // One controlled modular multiply on an LDS-resident tile whose low M local bits are the M register.
@@ -768,35 +769,193 @@ __device__ __forceinline__ void rotate_amp(amp_t &v, double cc, double ss)
     v = w;
 }
 
-// A run of consecutive controlled phases that rotate the same registers (RSEL): branch-free body.
-// Lanes (or whole tiles) whose mask test fails rotate by (1, 0) instead, which is exact: (1*x - 0*y) + 0 == x
-// and (1*y + 0*x) + 0 == y for every finite canonical (+0) value, so no control-flow merges and no register
-// copies are needed; the next gate's record is fetched while the current one is applied.
+// A run of consecutive controlled phases that rotate the same registers (RSEL).
+//  * Which gates of the run act on this TILE (their controls outside the tile are all 1) is found 64 gates at a
+//    time: lane l tests gate l, one ballot gives the live set, and only live gates are walked.  A skipped gate
+//    costs nothing.
+//  * The walk is hand-scheduled (phase_chunk): measured, the compiler's version of this loop is bound by the
+//    scalar-ALU issue port (about 20 s_* instructions per gate for mask iteration, record address, select and
+//    EXEC bookkeeping), not by the FP64 work.  Here a gate costs ~9 scalar instructions: find/clear its bit, three
+//    scalar loads of its record (the next gate's record is in flight while the current one is applied), a
+//    v_cmpx that masks the lanes whose tile-local control bits are not all set, and the EXEC restore.
+//  * A rotation is the same four products and two sums as rotate_amp, in place, without FMA.
+//  * The reference's result of every rotation is canonical (its "0 + ..." turns -0 into +0).  The sign of a zero
+//    never changes a later non-zero result and every zero result is canonicalised anyway, so the "+ 0.0" is
+//    applied ONCE at the end of the run, to the lanes that were rotated at least once (tch collects their EXEC
+//    masks); untouched lanes keep their bits.  Same values, bit for bit, as rotate_amp per gate.
 enum : uint32_t { FUSE_PRUN = 4 };
 
-template <unsigned RSEL>
-__device__ __forceinline__ void fuse_phase_run(amp_t &v0, amp_t &v1, amp_t &v2, amp_t &v3, const FuseOp *__restrict__ rec,
-                                               unsigned count, uint64_t base, unsigned p)
+#define QCX_LOADREC(M, C, S)                                         \
+    "s_ff1_i32_b64 %[b], %[live]\n\t"                                \
+    "s_bitset0_b64 %[live], %[b]\n\t"                                \
+    "s_lshl_b32 %[b], %[b], 5\n\t"                                   \
+    "s_load_dword %[" M "], %[base], %[b] offset:0x24\n\t"           \
+    "s_load_dwordx2 %[" C "], %[base], %[b] offset:0x30\n\t"         \
+    "s_load_dwordx2 %[" S "], %[base], %[b] offset:0x38\n\t"
+#define QCX_ROT1(C, S, X, Y)                                         \
+    "v_mul_f64 %[t0], %[" C "], %[" X "]\n\t"                        \
+    "v_mul_f64 %[t1], %[" S "], %[" Y "]\n\t"                        \
+    "v_mul_f64 %[t2], %[" C "], %[" Y "]\n\t"                        \
+    "v_mul_f64 %[t3], %[" S "], %[" X "]\n\t"                        \
+    "v_add_f64 %[" X "], %[t0], -%[t1]\n\t"                          \
+    "v_add_f64 %[" Y "], %[t2], %[t3]\n\t"
+#define QCX_ROT2(C, S, X0, Y0, X1, Y1)                               \
+    "v_mul_f64 %[t0], %[" C "], %[" X0 "]\n\t"                       \
+    "v_mul_f64 %[t1], %[" S "], %[" Y0 "]\n\t"                       \
+    "v_mul_f64 %[t2], %[" C "], %[" Y0 "]\n\t"                       \
+    "v_mul_f64 %[t3], %[" S "], %[" X0 "]\n\t"                       \
+    "v_add_f64 %[" X0 "], %[t0], -%[t1]\n\t"                         \
+    "v_mul_f64 %[t0], %[" C "], %[" X1 "]\n\t"                       \
+    "v_mul_f64 %[t1], %[" S "], %[" Y1 "]\n\t"                       \
+    "v_add_f64 %[" Y0 "], %[t2], %[t3]\n\t"                          \
+    "v_mul_f64 %[t2], %[" C "], %[" Y1 "]\n\t"                       \
+    "v_mul_f64 %[t3], %[" S "], %[" X1 "]\n\t"                       \
+    "v_add_f64 %[" X1 "], %[t0], -%[t1]\n\t"                         \
+    "v_add_f64 %[" Y1 "], %[t2], %[t3]\n\t"
+#define QCX_R1(C, S, i) QCX_ROT1(C, S, "x" #i, "y" #i)
+#define QCX_R2(C, S, i, j) QCX_ROT2(C, S, "x" #i, "y" #i, "x" #j, "y" #j)
+// the rotations of one gate for every register selection RSEL (bit q set: amplitude register q is rotated)
+#define QCX_ROTS_1(C, S)  QCX_R1(C, S, 0)
+#define QCX_ROTS_2(C, S)  QCX_R1(C, S, 1)
+#define QCX_ROTS_3(C, S)  QCX_R2(C, S, 0, 1)
+#define QCX_ROTS_4(C, S)  QCX_R1(C, S, 2)
+#define QCX_ROTS_5(C, S)  QCX_R2(C, S, 0, 2)
+#define QCX_ROTS_6(C, S)  QCX_R2(C, S, 1, 2)
+#define QCX_ROTS_7(C, S)  QCX_R2(C, S, 0, 1) QCX_R1(C, S, 2)
+#define QCX_ROTS_8(C, S)  QCX_R1(C, S, 3)
+#define QCX_ROTS_9(C, S)  QCX_R2(C, S, 0, 3)
+#define QCX_ROTS_10(C, S) QCX_R2(C, S, 1, 3)
+#define QCX_ROTS_11(C, S) QCX_R2(C, S, 0, 1) QCX_R1(C, S, 3)
+#define QCX_ROTS_12(C, S) QCX_R2(C, S, 2, 3)
+#define QCX_ROTS_13(C, S) QCX_R2(C, S, 0, 2) QCX_R1(C, S, 3)
+#define QCX_ROTS_14(C, S) QCX_R2(C, S, 1, 2) QCX_R1(C, S, 3)
+#define QCX_ROTS_15(C, S) QCX_R2(C, S, 0, 1) QCX_R2(C, S, 2, 3)
+#define QCX_Z1(i) "v_add_f64 %[x" #i "], %[x" #i "], 0\n\t" "v_add_f64 %[y" #i "], %[y" #i "], 0\n\t"
+#define QCX_ZERO_1  QCX_Z1(0)
+#define QCX_ZERO_2  QCX_Z1(1)
+#define QCX_ZERO_3  QCX_Z1(0) QCX_Z1(1)
+#define QCX_ZERO_4  QCX_Z1(2)
+#define QCX_ZERO_5  QCX_Z1(0) QCX_Z1(2)
+#define QCX_ZERO_6  QCX_Z1(1) QCX_Z1(2)
+#define QCX_ZERO_7  QCX_Z1(0) QCX_Z1(1) QCX_Z1(2)
+#define QCX_ZERO_8  QCX_Z1(3)
+#define QCX_ZERO_9  QCX_Z1(0) QCX_Z1(3)
+#define QCX_ZERO_10 QCX_Z1(1) QCX_Z1(3)
+#define QCX_ZERO_11 QCX_Z1(0) QCX_Z1(1) QCX_Z1(3)
+#define QCX_ZERO_12 QCX_Z1(2) QCX_Z1(3)
+#define QCX_ZERO_13 QCX_Z1(0) QCX_Z1(2) QCX_Z1(3)
+#define QCX_ZERO_14 QCX_Z1(1) QCX_Z1(2) QCX_Z1(3)
+#define QCX_ZERO_15 QCX_Z1(0) QCX_Z1(1) QCX_Z1(2) QCX_Z1(3)
+// one gate: mask the lanes, rotate, restore EXEC
+#define QCX_GATE(M, ROTS)                                            \
+    "v_and_b32 %[t], %[" M "], %[p]\n\t"                             \
+    "v_cmpx_eq_u32_e32 vcc, %[" M "], %[t]\n\t"                      \
+    "s_or_b64 %[tch], %[tch], exec\n\t"                              \
+    "s_cbranch_execz 1f\n\t"                                         \
+    ROTS                                                             \
+    "1:\n\t"                                                         \
+    "s_mov_b64 exec, %[ex]\n\t"
+// H on one of the round's two register bits, in place and without the final "+ 0.0" (the round canonicalises once at
+// its end): the same four products and four sums as h_butterfly
+#define QCX_HBF(AX, AY, BX, BY)                                      \
+    "v_mul_f64 %[t0], %[hs], %[" AX "]\n\t"                          \
+    "v_mul_f64 %[t1], %[hs], %[" AY "]\n\t"                          \
+    "v_mul_f64 %[t2], %[hs], %[" BX "]\n\t"                          \
+    "v_mul_f64 %[t3], %[hs], %[" BY "]\n\t"                          \
+    "v_add_f64 %[" AX "], %[t0], %[t2]\n\t"                          \
+    "v_add_f64 %[" AY "], %[t1], %[t3]\n\t"                          \
+    "v_add_f64 %[" BX "], %[t0], -%[t2]\n\t"                         \
+    "v_add_f64 %[" BY "], %[t1], -%[t3]\n\t"
+// all live gates of one run for register selection R (live != 0 on entry, 0 on exit); records ping-pong between
+// sets A and B; then the canonical zeros for the rotated lanes if bit 4 of rsel asks for them
+#define QCX_RUN_BODY(R)                                              \
+    QCX_LOADREC("mA", "cA", "sA")                                    \
+    "2:\n\t"                                                         \
+    "s_waitcnt lgkmcnt(0)\n\t"                                       \
+    "s_cmp_eq_u64 %[live], 0\n\t"                                    \
+    "s_cbranch_scc1 3f\n\t"                                          \
+    QCX_LOADREC("mB", "cB", "sB")                                    \
+    QCX_GATE("mA", QCX_ROTS_##R("cA", "sA"))                         \
+    "s_waitcnt lgkmcnt(0)\n\t"                                       \
+    "s_cmp_eq_u64 %[live], 0\n\t"                                    \
+    "s_cbranch_scc1 4f\n\t"                                          \
+    QCX_LOADREC("mA", "cA", "sA")                                    \
+    QCX_GATE("mB", QCX_ROTS_##R("cB", "sB"))                         \
+    "s_branch 2b\n\t"                                                \
+    "3:\n\t"                                                         \
+    QCX_GATE("mA", QCX_ROTS_##R("cA", "sA"))                         \
+    "s_branch 5f\n\t"                                                \
+    "4:\n\t"                                                         \
+    QCX_GATE("mB", QCX_ROTS_##R("cB", "sB"))                         \
+    "5:\n\t"                                                         \
+    "s_bitcmp1_b32 %[rsel], 4\n\t"                                   \
+    "s_cbranch_scc0 99f\n\t"                                         \
+    "s_mov_b64 exec, %[tch]\n\t"                                     \
+    QCX_ZERO_##R                                                     \
+    "s_mov_b64 exec, %[ex]\n\t"                                      \
+    "s_branch 99f\n\t"
+// ONE asm statement for every register selection (entry 20 + R, binary dispatch on rsel & 15): with one statement
+// per selection behind a C++ switch the compiler copied all four amplitudes into fresh VGPRs at every run
+#define QCX_ITEM_ALL                                                 \
+    "s_bitcmp1_b32 %[rsel], 5\n\t"                                   \
+    "s_cbranch_scc1 50f\n\t"                                         \
+    "s_mov_b64 %[ex], exec\n\t"                                      \
+    "s_mov_b64 %[tch], 0\n\t"                                        \
+    "s_cmp_eq_u64 %[live], 0\n\t"                                    \
+    "s_cbranch_scc1 99f\n\t"                                         \
+    "s_and_b32 %[b], %[rsel], 15\n\t"                                \
+    "s_cmp_lt_u32 %[b], 8\n\t s_cbranch_scc1 40f\n\t"                \
+    "s_cmp_lt_u32 %[b], 12\n\t s_cbranch_scc1 41f\n\t"               \
+    "s_cmp_lt_u32 %[b], 14\n\t s_cbranch_scc1 42f\n\t"               \
+    "s_cmp_eq_u32 %[b], 14\n\t s_cbranch_scc1 34f\n\t s_branch 35f\n\t" \
+    "42:\n\t s_cmp_eq_u32 %[b], 12\n\t s_cbranch_scc1 32f\n\t s_branch 33f\n\t" \
+    "41:\n\t s_cmp_lt_u32 %[b], 10\n\t s_cbranch_scc1 43f\n\t s_cmp_eq_u32 %[b], 10\n\t s_cbranch_scc1 30f\n\t s_branch 31f\n\t" \
+    "43:\n\t s_cmp_eq_u32 %[b], 8\n\t s_cbranch_scc1 28f\n\t s_branch 29f\n\t" \
+    "40:\n\t s_cmp_lt_u32 %[b], 4\n\t s_cbranch_scc1 44f\n\t"        \
+    "s_cmp_lt_u32 %[b], 6\n\t s_cbranch_scc1 45f\n\t s_cmp_eq_u32 %[b], 6\n\t s_cbranch_scc1 26f\n\t s_branch 27f\n\t" \
+    "45:\n\t s_cmp_eq_u32 %[b], 4\n\t s_cbranch_scc1 24f\n\t s_branch 25f\n\t" \
+    "44:\n\t s_cmp_lt_u32 %[b], 2\n\t s_cbranch_scc1 21f\n\t s_cmp_eq_u32 %[b], 2\n\t s_cbranch_scc1 22f\n\t s_branch 23f\n\t" \
+    "21:\n\t" QCX_RUN_BODY(1)  "22:\n\t" QCX_RUN_BODY(2)  "23:\n\t" QCX_RUN_BODY(3)  "24:\n\t" QCX_RUN_BODY(4)  \
+    "25:\n\t" QCX_RUN_BODY(5)  "26:\n\t" QCX_RUN_BODY(6)  "27:\n\t" QCX_RUN_BODY(7)  "28:\n\t" QCX_RUN_BODY(8)  \
+    "29:\n\t" QCX_RUN_BODY(9)  "30:\n\t" QCX_RUN_BODY(10) "31:\n\t" QCX_RUN_BODY(11) "32:\n\t" QCX_RUN_BODY(12) \
+    "33:\n\t" QCX_RUN_BODY(13) "34:\n\t" QCX_RUN_BODY(14) "35:\n\t" QCX_RUN_BODY(15) \
+    "50:\n\t"                                                        \
+    "s_bitcmp1_b32 %[rsel], 0\n\t"                                   \
+    "s_cbranch_scc1 51f\n\t"                                         \
+    QCX_HBF("x0", "y0", "x1", "y1") QCX_HBF("x2", "y2", "x3", "y3")  \
+    "s_branch 99f\n\t"                                               \
+    "51:\n\t"                                                        \
+    QCX_HBF("x0", "y0", "x2", "y2") QCX_HBF("x1", "y1", "x3", "y3")  \
+    "99:\n\t"
+
+// the four amplitudes a thread holds during a round, as eight separate doubles
+struct Quad { double x0, y0, x1, y1, x2, y2, x3, y3; };
+
+// One item of a round: an H on one of the round's register bits, or a phase run (at most 64 gates: the host cuts
+// longer ones).  code: bit 5 = H (bit 0: which register bit); otherwise bits 0-3 = which amplitude registers the run
+// rotates, bit 4 = apply the canonical zeros (the reference's "+ 0") to the rotated lanes at its end -- clear when the
+// round canonicalises everything at its end anyway (it contains an H).  item = the item's header record, the gates of
+// a run follow it; live = the run's gates whose outside-tile controls are all 1 for this tile.
+// ONE asm statement for everything that touches the amplitudes inside the round's item loop: with separate
+// statements (or C++ butterflies) the compiler keeps two sets of VGPRs for the four amplitudes and copies between
+// them at every item, which costs more than a gate.
+__device__ __forceinline__ void fuse_round_item(Quad &q, const FuseOp *item, uint64_t live, unsigned p, uint32_t code)
 {
-    uint64_t mext = rec[0].mask;
-    uint32_t mloc = rec[0].a;
-    double cc = rec[0].c, ss = rec[0].s;
-    for (unsigned o = 0; o < count; o++) {
-        const uint64_t mext_c = mext; const uint32_t mloc_c = mloc; const double cc_c = cc, ss_c = ss;
-        if (o + 1 < count) { mext = rec[o + 1].mask; mloc = rec[o + 1].a; cc = rec[o + 1].c; ss = rec[o + 1].s; }
-        if ((base & mext_c) != mext_c) continue;          // wave-uniform (scalar): a control outside the tile is 0
-        const bool go = (p & mloc_c) == mloc_c;
-        const double c = go ? cc_c : 1.0, s2 = go ? ss_c : 0.0;
-        if (RSEL & 1u) rotate_amp(v0, c, s2);
-        if (RSEL & 2u) rotate_amp(v1, c, s2);
-        if (RSEL & 4u) rotate_amp(v2, c, s2);
-        if (RSEL & 8u) rotate_amp(v3, c, s2);
-    }
+    uint64_t ex, tch; uint32_t bidx, mA, mB, tv; double cA, sA, cB, sB;
+    double t0, t1, t2, t3;
+    const double hs = QCX_SQRT1_2;
+    asm(QCX_ITEM_ALL
+        : [live] "+s"(live), [tch] "=&s"(tch), [ex] "=&s"(ex), [b] "=&s"(bidx), [mA] "=&s"(mA), [cA] "=&s"(cA), [sA] "=&s"(sA),
+          [mB] "=&s"(mB), [cB] "=&s"(cB), [sB] "=&s"(sB), [t] "=&v"(tv),
+          [x0] "+v"(q.x0), [y0] "+v"(q.y0), [x1] "+v"(q.x1), [y1] "+v"(q.y1), [x2] "+v"(q.x2), [y2] "+v"(q.y2), [x3] "+v"(q.x3), [y3] "+v"(q.y3),
+          [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+        : [base] "s"(item), [p] "v"(p), [rsel] "s"(code), [hs] "s"(hs) : "vcc", "scc");
 }
 
 template <int BLOCK, int TT>
 __device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, unsigned short *lut, const unsigned char *camtab,
-                                                  const FusePass &P, const FuseOp *__restrict__ ops, uint64_t base)
+                                                  const uint64_t *xm, const FusePass &P, const FuseOp *__restrict__ ops,
+                                                  const FuseOp *ops_asm, uint64_t base)
 {
     static_assert((1u << TT) == 4u * BLOCK, "rounds form needs 4 amplitudes per thread");
     unsigned i = 0;
@@ -807,48 +966,39 @@ __device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, unsigned short *l
             const unsigned cnt = (unsigned)ops[i].mask;
             const unsigned p = (unsigned)insert_zero(insert_zero(threadIdx.x, rb0), rb1);
             const unsigned e1 = p | (1u << rb0), e2 = p | (1u << rb1), e3 = e1 | (1u << rb1);
-            amp_t v0 = tile[p], v1 = tile[e1], v2 = tile[e2], v3 = tile[e3];
-            for (unsigned o = i + 1; o <= i + cnt; o++) {
+            Quad q;
+            { const amp_t v0 = tile[p], v1 = tile[e1], v2 = tile[e2], v3 = tile[e3];
+              q.x0 = v0.x; q.y0 = v0.y; q.x1 = v1.x; q.y1 = v1.y; q.x2 = v2.x; q.y2 = v2.y; q.x3 = v3.x; q.y3 = v3.y; }
+            // bit 16 of the header: the round contains an H.  It then canonicalises all amplitudes once at its end and
+            // its phase runs skip their own canonical zeros (canon_bit clear).
+            const bool has_h = (ops[i].a >> 16) & 1u;
+            const uint32_t canon_bit = has_h ? 0u : 16u;
+            // items: the header's first dword says everything (one scalar load per item): type | code << 8 | gates << 16,
+            // code as in fuse_round_item.  The records of a run's gates follow its header.
+            // The walk reads the records through ops_asm, a second (non-restrict) kernel argument with the same value:
+            // handing `ops` itself to an asm statement would count as a capture, after which the memory-clobbering
+            // s_waitcnt statements of the pipeline could "modify" the records and every ops[] access in this function
+            // would turn from a scalar load into a vector load.
+            unsigned o = i + 1;
+            const unsigned oend = i + cnt;
+            const unsigned lane = threadIdx.x & 63u;
+            do {        // a round has at least one item
                 const uint32_t t = ops[o].type;
-                if ((t & 0xffu) == FUSE_H) {
-                    if (ops[o].a == 0) { h_butterfly(v0, v1); h_butterfly(v2, v3); }
-                    else               { h_butterfly(v0, v2); h_butterfly(v1, v3); }
-                } else if ((t & 0xffu) == FUSE_PRUN) {
-                    const unsigned rc = (unsigned)ops[o].mask;
-                    const FuseOp *rec = ops + o + 1;
-                    switch (ops[o].a & 0xfu) {
-                    case 1:  fuse_phase_run<1>(v0, v1, v2, v3, rec, rc, base, p); break;
-                    case 2:  fuse_phase_run<2>(v0, v1, v2, v3, rec, rc, base, p); break;
-                    case 3:  fuse_phase_run<3>(v0, v1, v2, v3, rec, rc, base, p); break;
-                    case 4:  fuse_phase_run<4>(v0, v1, v2, v3, rec, rc, base, p); break;
-                    case 5:  fuse_phase_run<5>(v0, v1, v2, v3, rec, rc, base, p); break;
-                    case 6:  fuse_phase_run<6>(v0, v1, v2, v3, rec, rc, base, p); break;
-                    case 7:  fuse_phase_run<7>(v0, v1, v2, v3, rec, rc, base, p); break;
-                    case 8:  fuse_phase_run<8>(v0, v1, v2, v3, rec, rc, base, p); break;
-                    case 9:  fuse_phase_run<9>(v0, v1, v2, v3, rec, rc, base, p); break;
-                    case 10: fuse_phase_run<10>(v0, v1, v2, v3, rec, rc, base, p); break;
-                    case 11: fuse_phase_run<11>(v0, v1, v2, v3, rec, rc, base, p); break;
-                    case 12: fuse_phase_run<12>(v0, v1, v2, v3, rec, rc, base, p); break;
-                    case 13: fuse_phase_run<13>(v0, v1, v2, v3, rec, rc, base, p); break;
-                    case 14: fuse_phase_run<14>(v0, v1, v2, v3, rec, rc, base, p); break;
-                    case 15: fuse_phase_run<15>(v0, v1, v2, v3, rec, rc, base, p); break;
-                    default: break;
-                    }
-                    o += rc;                                              // skip the run's records
-                } else {
-                    const uint64_t mext = ops[o].mask;
-                    if ((base & mext) != mext) continue;                 // scalar: bits outside the tile
-                    const uint32_t mloc = ops[o].a;
-                    if ((p & mloc) != mloc) continue;                    // one vector test per thread
-                    const uint32_t rsel = (t >> 8) & 0xfu;
-                    const double cc = ops[o].c, ss = ops[o].s;
-                    if (rsel & 1u) rotate_amp(v0, cc, ss);
-                    if (rsel & 2u) rotate_amp(v1, cc, ss);
-                    if (rsel & 4u) rotate_amp(v2, cc, ss);
-                    if (rsel & 8u) rotate_amp(v3, cc, ss);
+                const unsigned rc = t >> 16;
+                uint64_t live = 0;
+                if (rc) {       // uniform; xm: the records' outside-tile masks staged in LDS
+                    const uint64_t m = ((const __attribute__((address_space(3))) uint64_t *)xm)[o + 1 + (lane < rc ? lane : 0)];
+                    live = __builtin_amdgcn_ballot_w64((base & m) == m) & (rc >= 64 ? ~(uint64_t)0 : ((uint64_t)1 << rc) - 1);
                 }
+                fuse_round_item(q, ops_asm + o, live, p, ((t >> 8) & 0xffu) | canon_bit);
+                o += 1 + rc;
+            } while (o <= oend);
+            if (has_h) {
+                q.x0 += 0.0; q.y0 += 0.0; q.x1 += 0.0; q.y1 += 0.0; q.x2 += 0.0; q.y2 += 0.0; q.x3 += 0.0; q.y3 += 0.0;
             }
-            tile[p] = v0; tile[e1] = v1; tile[e2] = v2; tile[e3] = v3;
+            { amp_t v0, v1, v2, v3;
+              v0.x = q.x0; v0.y = q.y0; v1.x = q.x1; v1.y = q.y1; v2.x = q.x2; v2.y = q.y2; v3.x = q.x3; v3.y = q.y3;
+              tile[p] = v0; tile[e1] = v1; tile[e2] = v2; tile[e3] = v3; }
             __syncthreads();
             i += 1 + cnt;
         } else if (type == FUSE_CAMRUN) {
@@ -901,7 +1051,7 @@ __device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, unsigned short *l
 
 template <int BLOCK, int TT, bool LDSDMA>   // TT = tile bits when known at compile time (loops unroll, loads batch); 0 = generic
 __global__ __launch_bounds__(BLOCK) void k_fused(amp_t *__restrict__ amp, unsigned n, FusePass P,
-                                                   const FuseOp *__restrict__ ops, uint64_t ntiles)
+                                                   const FuseOp *__restrict__ ops, uint64_t ntiles, const FuseOp *ops_asm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char qcx_lds_raw[];
     amp_t *tile = reinterpret_cast<amp_t *>(qcx_lds_raw);
@@ -911,6 +1061,8 @@ __global__ __launch_bounds__(BLOCK) void k_fused(amp_t *__restrict__ amp, unsign
     unsigned char *camtab = reinterpret_cast<unsigned char *>(lut) + P.cam_ctl_local[3];   // tables of folded multiply runs
     for (unsigned b = threadIdx.x; b < (unsigned)P.cam_ctl_local[1]; b += BLOCK)
         camtab[b] = reinterpret_cast<const unsigned char *>(ops + P.cam_ctl_local[2])[b];
+    uint64_t *xm = P.xm_cnt ? reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(lut) + P.xm_off) : nullptr;
+    for (unsigned b = threadIdx.x; b < P.xm_cnt; b += BLOCK) xm[b] = ops[b].mask;
     __syncthreads();
     constexpr unsigned EPT = TT ? ((1u << TT) + BLOCK - 1) / BLOCK : 16;      // elements per thread (<= 16)
     const unsigned ept = TT ? EPT : (tsize + BLOCK - 1) / BLOCK;
@@ -953,7 +1105,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(amp_t *__restrict__ amp, unsign
         __syncthreads();
 
         if constexpr (TT != 0 && (1u << TT) == 4u * BLOCK) {
-            if (P.cam_ctl_local[0]) fuse_apply_rounds<BLOCK, TT>(tile, lut, camtab, P, ops, base);
+            if (P.cam_ctl_local[0]) fuse_apply_rounds<BLOCK, TT>(tile, lut, camtab, xm, P, ops, ops_asm, base);
             else fuse_apply_ops<BLOCK, TT, EPT>(tile, lut, P, ops, base, off_t, off_k, tsize, ept);
         } else {
             fuse_apply_ops<BLOCK, TT, EPT>(tile, lut, P, ops, base, off_t, off_k, tsize, ept);
@@ -978,7 +1130,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(amp_t *__restrict__ amp, unsign
 // previous tile, issued after the fill).
 template <int BLOCK, int TT>
 __global__ __launch_bounds__(BLOCK, 4) void k_fused_pipe(amp_t *__restrict__ amp, unsigned n, FusePass P,
-                                                        const FuseOp *__restrict__ ops, uint64_t ntiles)
+                                                        const FuseOp *__restrict__ ops, uint64_t ntiles, const FuseOp *ops_asm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char qcx_lds_raw[];
     amp_t *buf0 = reinterpret_cast<amp_t *>(qcx_lds_raw);
@@ -989,6 +1141,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fused_pipe(amp_t *__restrict__ amp
     unsigned char *camtab = reinterpret_cast<unsigned char *>(lut) + P.cam_ctl_local[3];   // tables of folded multiply runs
     for (unsigned b = threadIdx.x; b < (unsigned)P.cam_ctl_local[1]; b += BLOCK)
         camtab[b] = reinterpret_cast<const unsigned char *>(ops + P.cam_ctl_local[2])[b];
+    uint64_t *xm = P.xm_cnt ? reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(lut) + P.xm_off) : nullptr;
+    for (unsigned b = threadIdx.x; b < P.xm_cnt; b += BLOCK) xm[b] = ops[b].mask;
     __syncthreads();
     const unsigned c = P.c, nh = P.nh;
     const unsigned lowmask = (1u << c) - 1u;
@@ -1035,7 +1189,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fused_pipe(amp_t *__restrict__ amp
         if (tn < ntiles) fill(buf0 + (cur ^ 1) * tsize, tile_base(tn));
 
         if constexpr ((1u << TT) == 4u * BLOCK) {
-            if (P.cam_ctl_local[0]) fuse_apply_rounds<BLOCK, TT>(tile, lut, camtab, P, ops, base);
+            if (P.cam_ctl_local[0]) fuse_apply_rounds<BLOCK, TT>(tile, lut, camtab, xm, P, ops, ops_asm, base);
             else fuse_apply_ops<BLOCK, TT, EPT>(tile, lut, P, ops, base, off_t, off_k, tsize, EPT);
         } else {
             fuse_apply_ops<BLOCK, TT, EPT>(tile, lut, P, ops, base, off_t, off_k, tsize, EPT);

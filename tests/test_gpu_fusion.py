@@ -179,3 +179,82 @@ def test_runs_of_modular_multiplies_fold_exactly(qc, ob, tune_guard, camruns):
             qc.c_phase_shift_gate(n - 1, M, 0.3, reg); ob.cphase(want, n, n - 1, M, 0.3)
             got = reg.read()
         assert np.array_equal(bits(got), bits(want)), (L, M, Cn)
+
+
+def _run_gpu(qc, L, M, Cn, state, prog, fusion):
+    with qc.Register(L, M) as reg:
+        reg.write(state)
+        reg.set_fusion(fusion)
+        for g in prog:
+            if g[0] == "h":
+                qc.hadamard_gate(g[1], reg)
+            elif g[0] == "p":
+                qc.c_phase_shift_gate(g[1], g[2], g[3], reg)
+            else:
+                qc.c_amodc_gate(Cn, g[1], g[2], reg)
+        return reg.read()
+
+
+def _run_oracle(ob, n, M, Cn, state, prog):
+    want = state.copy()
+    for g in prog:
+        if g[0] == "h":
+            ob.hadamard(want, n, g[1])
+        elif g[0] == "p":
+            ob.cphase(want, n, g[1], g[2], g[3])
+        else:
+            ob.camodc(want, n, M, Cn, g[1], g[2])
+    return want
+
+
+def _sparse_state_with_negative_zeros(ob, rs, n, seed):
+    st = ob.random_state(n, seed)
+    v = st.reshape(-1, 2)
+    v[rs.rand(v.shape[0]) < 0.6] = 0.0                      # most amplitudes exactly zero ...
+    neg = rs.rand(v.shape[0], 2) < 0.3                      # ... and a third of the zero components are -0
+    v[(v == 0.0) & neg] = -0.0
+    assert np.signbit(v[v == 0.0]).any()
+    return st
+
+
+@pytest.mark.parametrize("L,M,Cn", [(9, 4, 15), (13, 5, 21), (14, 0, 1)])
+def test_sparse_and_negative_zero_states(qc, ob, L, M, Cn):
+    """States with exact zeros and -0 entries (a caller can write them).  Fused passes give the same BITS as the per-gate
+    kernels; against the oracle every non-zero value is bit-identical and every zero is a zero.  (Sign of zero: the
+    reference's mat-vec rewrites -- and so canonicalises -- every amplitude at every gate, the GPU paths only the
+    amplitudes a gate touches; the two agree as soon as an H has run.)"""
+    n = L + M
+    rs = np.random.RandomState(1000 + n)
+    for trial in range(4):
+        st = _sparse_state_with_negative_zeros(ob, rs, n, 300 + trial)
+        prog = random_program(rs, n, M, Cn, 12 if trial < 2 else 70)     # short programs keep untouched amplitudes around
+        plain = _run_gpu(qc, L, M, Cn, st, prog, False)
+        fused = _run_gpu(qc, L, M, Cn, st, prog, True)
+        want = _run_oracle(ob, n, M, Cn, st, prog)
+        assert np.array_equal(bits(fused), bits(plain)), f"L={L} M={M} trial {trial}: fused != per-gate"
+        nz = want != 0.0
+        assert np.array_equal(bits(plain)[nz], bits(want)[nz]) and np.array_equal(plain, want)
+        if any(g[0] == "h" for g in prog):
+            assert np.array_equal(bits(plain), bits(want))
+
+
+def test_phase_only_programs_keep_untouched_negative_zeros(qc, ob):
+    """no H in the program: a round without an H canonicalises only the lanes its phase runs rotated, like the per-gate
+    kernel, which only writes the quarter of the amplitudes the gate acts on"""
+    n = 13
+    rs = np.random.RandomState(77)
+    st = ob.random_state(n, 5)
+    v = st.reshape(-1, 2)
+    v[rs.rand(v.shape[0]) < 0.5] = -0.0
+    prog = []
+    for _ in range(40):
+        c, t = rs.choice(n, 2, replace=False)
+        prog.append(("p", int(c), int(t), float(rs.uniform(-3, 3))))
+    plain = _run_gpu(qc, n, 0, 1, st, prog, False)
+    fused = _run_gpu(qc, n, 0, 1, st, prog, True)
+    want = _run_oracle(ob, n, 0, 1, st, prog)
+    z = plain == 0.0
+    assert np.signbit(plain[z]).any() and not np.signbit(plain[z]).all()      # some zeros were rotated, some never touched
+    assert np.array_equal(bits(fused), bits(plain))
+    nz = want != 0.0
+    assert np.array_equal(bits(plain)[nz], bits(want)[nz]) and np.array_equal(plain, want)

@@ -52,6 +52,7 @@ struct FuseAction {
     size_t   gate;
     FusePass P;
     size_t   op_off, op_cnt, ngates;
+    int      nopipe;         // phase-heavy pass: the one-tile-per-workgroup kernel (more resident waves) instead of the pipelined one
 };
 
 static int launch_standalone(qcx_register *r, const QGate &g)
@@ -141,7 +142,7 @@ static void to_rounds(const std::vector<FuseOp> &legacy, unsigned T, std::vector
             {
                 if (run_hdr == (size_t)-1 || rsel != run_rsel || out[run_hdr].mask >= 64u) {
                     FuseOp rh; memset(&rh, 0, sizeof rh);
-                    rh.type = FUSE_PRUN | (rsel << 8); rh.a = rsel;
+                    rh.type = FUSE_PRUN | ((rsel | (has_h ? 0u : 16u)) << 8); rh.a = rsel;     // bit 4: the run canonicalises its zeros
                     run_hdr = out.size(); run_rsel = rsel;
                     out.push_back(rh);
                 }
@@ -192,7 +193,7 @@ static void to_rounds(const std::vector<FuseOp> &legacy, unsigned T, std::vector
     close_round();
 }
 
-static int launch_pass(qcx_register *r, const FusePass &P_in, const FuseOp *d_ops)
+static int launch_pass(qcx_register *r, const FusePass &P_in, const FuseOp *d_ops, bool nopipe)
 {
     FusePass P = P_in;
     const unsigned n = r->n;
@@ -203,12 +204,12 @@ static int launch_pass(qcx_register *r, const FusePass &P_in, const FuseOp *d_op
     P.xm_off = 0;
     if (P.xm_cnt) {                                                                // + the records' outside-tile masks (phase runs)
         P.xm_off = (uint32_t)((lut_bytes + 7) & ~(size_t)7);
-        lut_bytes = P.xm_off + 8 * (size_t)P.xm_cnt;
+        lut_bytes = P.xm_off + 8 * ((size_t)P.xm_cnt + 66);          // padded: lanes look up to 64 entries past a run
     }
     const size_t lds = ((size_t)16 << P.T) + lut_bytes;
     // 4 amplitudes per thread (all loads of a tile in flight at once, few registers): block = 2^T / 4
 #define QCX_FUSE_LAUNCH(B, TTv) do { \
-        if (g_tune.fuse_pipe && ntiles >= 4096) { \
+        if (g_tune.fuse_pipe && !nopipe && ntiles >= 4096) { \
             const unsigned pg = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)g_tune.fuse_pipe_grid); \
             hipLaunchKernelGGL((k_fused_pipe<B, TTv>), dim3(pg), dim3(B), 2 * ((size_t)16 << P.T) + lut_bytes, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); \
         } else if (g_tune.fuse_ldsdma) hipLaunchKernelGGL((k_fused<B, TTv, true>), dim3(grid), dim3(B), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); \
@@ -232,12 +233,11 @@ static int fuse_flush(qcx_register *r)
     GateQueue *gq = r->queue;
     if (!gq || gq->gates.empty()) return QCX_NO_ERROR;
     const unsigned n = r->n;
-    unsigned T = (unsigned)g_tune.fuse_T, c = (unsigned)g_tune.fuse_c;
+    unsigned T = (unsigned)g_tune.fuse_T, c_def = (unsigned)g_tune.fuse_c;
     if (T > 12) T = 12;
     if (T < 1) T = 1;
     if (T > n) T = n;
-    if (c > T) c = T;
-    const unsigned budget = T - c;
+    if (c_def > T) c_def = T;
 
     std::vector<QGate> gates;
     gates.swap(gq->gates);                       // the queue is empty from here on (re-entrancy safe)
@@ -253,16 +253,33 @@ static int fuse_flush(qcx_register *r)
         // ---- grow one pass: a gate joins while the bits it needs inside the tile still fit ----------------
         std::vector<unsigned> hbits;
         const size_t first = i;
-        while (i < gates.size() && gates[i].type != 99) {
-            const QGate &g = gates[i];
-            need.clear();
-            if (g.type == FUSE_H) { if (g.q >= c) need.push_back(g.q); }
-            else if (g.type == FUSE_CAMODC) { for (unsigned b = c; b < (unsigned)r->M; b++) need.push_back(b); }
-            std::vector<unsigned> merged = hbits;
-            for (unsigned b : need) if (std::find(merged.begin(), merged.end(), b) == merged.end()) merged.push_back(b);
-            if (merged.size() > budget) break;
-            hbits.swap(merged);
-            i++;
+        size_t n_h = 0, n_ph = 0, n_other = 0;
+        auto grow = [&](unsigned cc, unsigned bud) {
+            hbits.clear(); i = first; n_h = n_ph = n_other = 0;
+            while (i < gates.size() && gates[i].type != 99) {
+                const QGate &g = gates[i];
+                need.clear();
+                if (g.type == FUSE_H) { if (g.q >= cc) need.push_back(g.q); }
+                else if (g.type == FUSE_CAMODC) { for (unsigned b = cc; b < (unsigned)r->M; b++) need.push_back(b); }
+                std::vector<unsigned> merged = hbits;
+                for (unsigned b : need) if (std::find(merged.begin(), merged.end(), b) == merged.end()) merged.push_back(b);
+                if (merged.size() > bud) break;
+                hbits.swap(merged);
+                if (g.type == FUSE_H) n_h++; else if (g.type == FUSE_PHASE) n_ph++; else n_other++;
+                i++;
+            }
+        };
+        unsigned c = c_def, budget = T - c_def;
+        grow(c, budget);
+        // A pass dominated by controlled phases is bound by FP64 issue and latency, not by HBM: it runs better on
+        // smaller tiles with one tile per workgroup (more resident waves, smaller barrier domains) than on the
+        // pipelined kernel, at the price of fewer hot bits per pass.
+        const unsigned Tp = (unsigned)g_tune.fuse_T_phase;
+        if (Tp >= 9 && Tp <= 12 && Tp <= n && g_tune.fuse_rounds && n_other == 0 &&
+            n_ph >= (size_t)g_tune.fuse_phase_ratio * std::max<size_t>(n_h, 1)) {
+            c = std::min((unsigned)g_tune.fuse_c_phase, Tp); budget = Tp - c;
+            grow(c, budget);
+            act.nopipe = 1;
         }
         if (i == first) { act.gate = i++; acts.push_back(act); continue; }             // does not fit a tile at all
         if (i - first == 1) { act.gate = first; acts.push_back(act); continue; }       // alone: its tuned kernel
@@ -286,7 +303,7 @@ static int fuse_flush(qcx_register *r)
             std::vector<unsigned char> blob;
             to_rounds(legacy, act.P.T, all_ops, blob);
             const size_t nrec = all_ops.size() - act.op_off;
-            const size_t lds = 2 * ((size_t)16 << act.P.T) + (size_t)act.P.cam_ctl_local[3] + blob.size() + 64 + 8 * nrec;
+            const size_t lds = 2 * ((size_t)16 << act.P.T) + (size_t)act.P.cam_ctl_local[3] + blob.size() + 64 + 8 * (nrec + 66);
             const size_t limit = (size_t)160 * 1024 / (act.P.T == 12 ? 1 : act.P.T == 11 ? 2 : 4);
             if (lds > limit) { all_ops.resize(act.op_off); rounds = false; }
             else {
@@ -330,7 +347,7 @@ static int fuse_flush(qcx_register *r)
 
     if (!all_ops.empty()) {
         if (gq->ev_valid) HIP_TRY(hipEventSynchronize(gq->ev));       // the previous flush may still read the buffers
-        const size_t need_ops = all_ops.size();
+        const size_t need_ops = all_ops.size() + 1;                  // + 1: the walk prefetches one header past the last item
         if (gq->h_cap < need_ops) {
             if (gq->h_ops) HIP_TRY(hipHostFree(gq->h_ops));
             gq->h_ops = nullptr; gq->h_cap = 0;
@@ -343,12 +360,13 @@ static int fuse_flush(qcx_register *r)
             HIP_TRY(hipMalloc(&gq->d_ops, need_ops * sizeof(FuseOp)));
             gq->d_cap = need_ops;
         }
-        memcpy(gq->h_ops, all_ops.data(), need_ops * sizeof(FuseOp));
+        memcpy(gq->h_ops, all_ops.data(), all_ops.size() * sizeof(FuseOp));
+        memset(gq->h_ops + all_ops.size(), 0, sizeof(FuseOp));
         HIP_TRY(hipMemcpyAsync(gq->d_ops, gq->h_ops, need_ops * sizeof(FuseOp), hipMemcpyHostToDevice, r->stream));
     }
     for (const FuseAction &act : acts) {
         if (!act.fused) { QCX_TRY(launch_standalone(r, gates[act.gate])); continue; }
-        QCX_TRY(launch_pass(r, act.P, gq->d_ops + act.op_off));
+        QCX_TRY(launch_pass(r, act.P, gq->d_ops + act.op_off, act.nopipe != 0));
         gq->passes_launched++;
         gq->gates_fused += act.ngates;
     }

@@ -888,7 +888,7 @@ enum : uint32_t { FUSE_PRUN = 4 };
     "4:\n\t"                                                         \
     QCX_GATE("mB", QCX_ROTS_##R("cB", "sB"))                         \
     "5:\n\t"                                                         \
-    "s_bitcmp1_b32 %[rsel], 4\n\t"                                   \
+    "s_bitcmp1_b32 %[rsel], 12\n\t"                                  \
     "s_cbranch_scc0 99f\n\t"                                         \
     "s_mov_b64 exec, %[tch]\n\t"                                     \
     QCX_ZERO_##R                                                     \
@@ -897,13 +897,20 @@ enum : uint32_t { FUSE_PRUN = 4 };
 // ONE asm statement for every register selection (entry 20 + R, binary dispatch on rsel & 15): with one statement
 // per selection behind a C++ switch the compiler copied all four amplitudes into fresh VGPRs at every run
 #define QCX_ITEM_ALL                                                 \
-    "s_bitcmp1_b32 %[rsel], 5\n\t"                                   \
+    /* prefetch for the NEXT item (1 + gates records further on): its header dword and its lanes' outside-tile masks */ \
+    "s_lshr_b32 %[b], %[rsel], 16\n\t"                               \
+    "s_add_u32 %[b], %[b], 1\n\t"                                    \
+    "s_lshl_b32 %[tn], %[b], 5\n\t"                                  \
+    "s_load_dword %[tn], %[base], %[tn]\n\t"                         \
+    "v_lshl_add_u32 %[xa], %[b], 3, %[xa]\n\t"                       \
+    "ds_read_b64 %[mn], %[xa]\n\t"                                   \
+    "s_bitcmp1_b32 %[rsel], 13\n\t"                                  \
     "s_cbranch_scc1 50f\n\t"                                         \
     "s_mov_b64 %[ex], exec\n\t"                                      \
     "s_mov_b64 %[tch], 0\n\t"                                        \
     "s_cmp_eq_u64 %[live], 0\n\t"                                    \
     "s_cbranch_scc1 99f\n\t"                                         \
-    "s_and_b32 %[b], %[rsel], 15\n\t"                                \
+    "s_bfe_u32 %[b], %[rsel], 0x40008\n\t"                           \
     "s_cmp_lt_u32 %[b], 8\n\t s_cbranch_scc1 40f\n\t"                \
     "s_cmp_lt_u32 %[b], 12\n\t s_cbranch_scc1 41f\n\t"               \
     "s_cmp_lt_u32 %[b], 14\n\t s_cbranch_scc1 42f\n\t"               \
@@ -920,26 +927,32 @@ enum : uint32_t { FUSE_PRUN = 4 };
     "29:\n\t" QCX_RUN_BODY(9)  "30:\n\t" QCX_RUN_BODY(10) "31:\n\t" QCX_RUN_BODY(11) "32:\n\t" QCX_RUN_BODY(12) \
     "33:\n\t" QCX_RUN_BODY(13) "34:\n\t" QCX_RUN_BODY(14) "35:\n\t" QCX_RUN_BODY(15) \
     "50:\n\t"                                                        \
-    "s_bitcmp1_b32 %[rsel], 0\n\t"                                   \
+    "s_bitcmp1_b32 %[rsel], 8\n\t"                                   \
     "s_cbranch_scc1 51f\n\t"                                         \
     QCX_HBF("x0", "y0", "x1", "y1") QCX_HBF("x2", "y2", "x3", "y3")  \
     "s_branch 99f\n\t"                                               \
     "51:\n\t"                                                        \
     QCX_HBF("x0", "y0", "x2", "y2") QCX_HBF("x1", "y1", "x3", "y3")  \
-    "99:\n\t"
+    "99:\n\t"                                                        \
+    "s_waitcnt lgkmcnt(0)\n\t"
 
 // the four amplitudes a thread holds during a round, as eight separate doubles
 struct Quad { double x0, y0, x1, y1, x2, y2, x3, y3; };
 
 // One item of a round: an H on one of the round's register bits, or a phase run (at most 64 gates: the host cuts
-// longer ones).  code: bit 5 = H (bit 0: which register bit); otherwise bits 0-3 = which amplitude registers the run
-// rotates, bit 4 = apply the canonical zeros (the reference's "+ 0") to the rotated lanes at its end -- clear when the
-// round canonicalises everything at its end anyway (it contains an H).  item = the item's header record, the gates of
-// a run follow it; live = the run's gates whose outside-tile controls are all 1 for this tile.
+// longer ones).  hdr = the item's header dword: type | code << 8 | gates << 16 with code bit 5 = H (bit 0: which
+// register bit); otherwise code bits 0-3 = which amplitude registers the run rotates, bit 4 = apply the canonical
+// zeros (the reference's "+ 0") to the rotated lanes at its end -- clear when the round canonicalises everything at
+// its end anyway (it contains an H).  item = the item's header record, the gates of a run follow it; live = the run's
+// gates whose outside-tile controls are all 1 for this tile.
+// The statement also fetches what the NEXT item needs first -- its header dword (hdr_next) and this lane's entry of
+// its outside-tile masks (mask_next; xaddr = LDS byte address of the current item's entry, advanced in place) -- so
+// that those two latencies overlap this item's work instead of starting the next one.
 // ONE asm statement for everything that touches the amplitudes inside the round's item loop: with separate
 // statements (or C++ butterflies) the compiler keeps two sets of VGPRs for the four amplitudes and copies between
 // them at every item, which costs more than a gate.
-__device__ __forceinline__ void fuse_round_item(Quad &q, const FuseOp *item, uint64_t live, unsigned p, uint32_t code)
+__device__ __forceinline__ void fuse_round_item(Quad &q, const FuseOp *item, uint64_t live, unsigned p, uint32_t hdr,
+                                                uint32_t &xaddr, uint32_t &hdr_next, uint64_t &mask_next)
 {
     uint64_t ex, tch; uint32_t bidx, mA, mB, tv; double cA, sA, cB, sB;
     double t0, t1, t2, t3;
@@ -948,8 +961,9 @@ __device__ __forceinline__ void fuse_round_item(Quad &q, const FuseOp *item, uin
         : [live] "+s"(live), [tch] "=&s"(tch), [ex] "=&s"(ex), [b] "=&s"(bidx), [mA] "=&s"(mA), [cA] "=&s"(cA), [sA] "=&s"(sA),
           [mB] "=&s"(mB), [cB] "=&s"(cB), [sB] "=&s"(sB), [t] "=&v"(tv),
           [x0] "+v"(q.x0), [y0] "+v"(q.y0), [x1] "+v"(q.x1), [y1] "+v"(q.y1), [x2] "+v"(q.x2), [y2] "+v"(q.y2), [x3] "+v"(q.x3), [y3] "+v"(q.y3),
-          [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
-        : [base] "s"(item), [p] "v"(p), [rsel] "s"(code), [hs] "s"(hs) : "vcc", "scc");
+          [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),
+          [tn] "=&s"(hdr_next), [mn] "=&v"(mask_next), [xa] "+v"(xaddr)
+        : [base] "s"(item), [p] "v"(p), [rsel] "s"(hdr), [hs] "s"(hs) : "vcc", "scc");
 }
 
 template <int BLOCK, int TT>
@@ -972,7 +986,6 @@ __device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, unsigned short *l
             // bit 16 of the header: the round contains an H.  It then canonicalises all amplitudes once at its end and
             // its phase runs skip their own canonical zeros (canon_bit clear).
             const bool has_h = (ops[i].a >> 16) & 1u;
-            const uint32_t canon_bit = has_h ? 0u : 16u;
             // items: the header's first dword says everything (one scalar load per item): type | code << 8 | gates << 16,
             // code as in fuse_round_item.  The records of a run's gates follow its header.
             // The walk reads the records through ops_asm, a second (non-restrict) kernel argument with the same value:
@@ -982,16 +995,17 @@ __device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, unsigned short *l
             unsigned o = i + 1;
             const unsigned oend = i + cnt;
             const unsigned lane = threadIdx.x & 63u;
+            // xm: the records' outside-tile masks staged in LDS (padded: a lane may look up to 64 entries past a run)
+            const __attribute__((address_space(3))) uint64_t *xl = (const __attribute__((address_space(3))) uint64_t *)xm + o + 1 + lane;
+            uint32_t xaddr = (uint32_t)(uintptr_t)xl;
+            uint32_t t = ops[o].type;
+            uint64_t m = *xl;
             do {        // a round has at least one item
-                const uint32_t t = ops[o].type;
-                const unsigned rc = t >> 16;
-                uint64_t live = 0;
-                if (rc) {       // uniform; xm: the records' outside-tile masks staged in LDS
-                    const uint64_t m = ((const __attribute__((address_space(3))) uint64_t *)xm)[o + 1 + (lane < rc ? lane : 0)];
-                    live = __builtin_amdgcn_ballot_w64((base & m) == m) & (rc >= 64 ? ~(uint64_t)0 : ((uint64_t)1 << rc) - 1);
-                }
-                fuse_round_item(q, ops_asm + o, live, p, ((t >> 8) & 0xffu) | canon_bit);
-                o += 1 + rc;
+                const unsigned rc = t >> 16;                             // 0 for an H: no live gates
+                const uint64_t live = __builtin_amdgcn_ballot_w64((base & m) == m) & (rc >= 64 ? ~(uint64_t)0 : ((uint64_t)1 << rc) - 1);
+                uint32_t tn; uint64_t mn;
+                fuse_round_item(q, ops_asm + o, live, p, t, xaddr, tn, mn);
+                o += 1 + rc; t = tn; m = mn;
             } while (o <= oend);
             if (has_h) {
                 q.x0 += 0.0; q.y0 += 0.0; q.x1 += 0.0; q.y1 += 0.0; q.x2 += 0.0; q.y2 += 0.0; q.x3 += 0.0; q.y3 += 0.0;
@@ -1050,7 +1064,7 @@ __device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, unsigned short *l
 }
 
 template <int BLOCK, int TT, bool LDSDMA>   // TT = tile bits when known at compile time (loops unroll, loads batch); 0 = generic
-__global__ __launch_bounds__(BLOCK) void k_fused(amp_t *__restrict__ amp, unsigned n, FusePass P,
+__global__ __launch_bounds__(BLOCK, 1536 / BLOCK) void k_fused(amp_t *__restrict__ amp, unsigned n, FusePass P,
                                                    const FuseOp *__restrict__ ops, uint64_t ntiles, const FuseOp *ops_asm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char qcx_lds_raw[];
@@ -1062,7 +1076,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(amp_t *__restrict__ amp, unsign
     for (unsigned b = threadIdx.x; b < (unsigned)P.cam_ctl_local[1]; b += BLOCK)
         camtab[b] = reinterpret_cast<const unsigned char *>(ops + P.cam_ctl_local[2])[b];
     uint64_t *xm = P.xm_cnt ? reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(lut) + P.xm_off) : nullptr;
-    for (unsigned b = threadIdx.x; b < P.xm_cnt; b += BLOCK) xm[b] = ops[b].mask;
+    for (unsigned b = threadIdx.x; b < P.xm_cnt + 66u && P.xm_cnt; b += BLOCK) xm[b] = b < P.xm_cnt ? ops[b].mask : 0;    // + padding
     __syncthreads();
     constexpr unsigned EPT = TT ? ((1u << TT) + BLOCK - 1) / BLOCK : 16;      // elements per thread (<= 16)
     const unsigned ept = TT ? EPT : (tsize + BLOCK - 1) / BLOCK;
@@ -1142,7 +1156,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fused_pipe(amp_t *__restrict__ amp
     for (unsigned b = threadIdx.x; b < (unsigned)P.cam_ctl_local[1]; b += BLOCK)
         camtab[b] = reinterpret_cast<const unsigned char *>(ops + P.cam_ctl_local[2])[b];
     uint64_t *xm = P.xm_cnt ? reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(lut) + P.xm_off) : nullptr;
-    for (unsigned b = threadIdx.x; b < P.xm_cnt; b += BLOCK) xm[b] = ops[b].mask;
+    for (unsigned b = threadIdx.x; b < P.xm_cnt + 66u && P.xm_cnt; b += BLOCK) xm[b] = b < P.xm_cnt ? ops[b].mask : 0;    // + padding
     __syncthreads();
     const unsigned c = P.c, nh = P.nh;
     const unsigned lowmask = (1u << c) - 1u;

@@ -5,7 +5,9 @@
  * [-a trial_int] [-v] [-V]; additionally -f is accepted as a synonym of -a (the reference documents
  * -f but parses -a), -s seeds the MT19937 stream (the reference uses time(NULL)),
  * -Q turns on the reference's 32-bit INT_POW behaviour for differential runs, -j prints a one-line
- * JSON performance summary, -F enables gate fusion (qcx_set_fusion).  Exit code = the reference's ErrorCode (Q:164-170, Q:1340-1347).
+ * JSON performance summary.  The circuit (qcx_quantum_computation) runs as fused passes by default; -G forces one kernel
+ * launch per gate (qcx_set_fusion(reg, -1)), -F queues every gate call (qcx_set_fusion(reg, 1)); the results are the same
+ * bits in all three modes.  Exit code = the reference's ErrorCode (Q:164-170, Q:1340-1347).
  *
  * The quantum part (reset, circuit, measurement) runs on the GPU through include/qcx.h; everything
  * here is host-side control flow written from scratch after the behaviour of find_period
@@ -28,7 +30,7 @@ typedef struct {
     unsigned C, forced_a;
     int L, M;
     unsigned long seed;
-    bool seed_given, ref_quirks, json, fusion;
+    bool seed_given, ref_quirks, json, fusion, per_gate;
 } Options;
 
 typedef struct {
@@ -37,7 +39,7 @@ typedef struct {
 } Stats;
 
 static const char *USAGE =
-    "Usage: qcx_shor -C num -L L_reg_size -M M_reg_size [-a trial_int | -f trial_int] [-v] [-V] [-s seed] [-Q] [-j] [-F]\n";
+    "Usage: qcx_shor -C num -L L_reg_size -M M_reg_size [-a trial_int | -f trial_int] [-v] [-V] [-s seed] [-Q] [-j] [-F | -G]\n";
 
 static double now_seconds(void)
 {
@@ -51,7 +53,7 @@ static int parse_args(int argc, char **argv, Options *o)
     bool haveC = false, haveL = false, haveM = false;
     int ch;
     memset(o, 0, sizeof *o);
-    while ((ch = getopt(argc, argv, "C:L:M:a:f:s:vVQjF")) != -1) {
+    while ((ch = getopt(argc, argv, "C:L:M:a:f:s:vVQjFG")) != -1) {
         switch (ch) {
         case 'C': o->C = (unsigned)atoi(optarg); haveC = true; break;
         case 'L': o->L = atoi(optarg); haveL = true; break;
@@ -63,6 +65,7 @@ static int parse_args(int argc, char **argv, Options *o)
         case 'Q': o->ref_quirks = true; break;
         case 'j': o->json = true; break;
         case 'F': o->fusion = true; break;
+        case 'G': o->per_gate = true; break;
         default: fputs(USAGE, stdout); return QCX_BAD_ARGUMENTS;
         }
     }
@@ -188,7 +191,8 @@ int main(int argc, char **argv)
         return s == QCX_INSUFFICIENT_MEMORY ? QCX_INSUFFICIENT_MEMORY : QCX_UNKNOWN_ERROR;
     }
 
-    if (o.fusion) qcx_set_fusion(reg, 1);        /* -F: gates are queued and run as fused passes (same bits) */
+    if (o.fusion) qcx_set_fusion(reg, 1);        /* -F: every gate call is queued and run as fused passes (same bits) */
+    if (o.per_gate) qcx_set_fusion(reg, -1);     /* -G: one kernel launch per gate, also inside the circuit call */
     const double t0 = now_seconds();
     s = shors_algorithm(factors, &o, reg, rng, &st);
     qcx_synchronize(reg);

@@ -91,9 +91,13 @@ void qcx_polar(double theta, double *cos_out, double *sin_out);
 unsigned qcx_ref_int_pow(double base, double power);
 
 /* ---- gate fusion (no reference counterpart) ------------
- * enable = 1: gate calls are queued and executed as fused passes (one HBM round trip applies many
- * gates to LDS-resident tiles).  Results are bit-identical to the per-gate kernels.  Every call that
- * observes the state flushes the queue; qcx_flush does so explicitly. */
+ * Queued gates are executed as fused passes (one HBM round trip applies many gates to LDS-resident
+ * tiles); results are bit-identical to the per-gate kernels.  Every call that observes the state
+ * flushes the queue; qcx_flush does so explicitly.
+ *   enable =  0 (default): a gate call launches its own kernel; the whole-circuit entry points
+ *                (qcx_inverse_QFT, qcx_quantum_computation) hand their complete gate list to the pass scheduler
+ *   enable =  1: every gate call is queued
+ *   enable = -1: strictly one kernel launch per gate, inside the whole-circuit entry points too */
 int  qcx_set_fusion(qcx_register *reg, int enable);
 int  qcx_flush(qcx_register *reg);
 int  qcx_fusion_stats(qcx_register *reg, unsigned long *passes_launched, unsigned long *gates_fused);

@@ -616,7 +616,8 @@ struct qcx_register {
     hipEvent_t *events;
     unsigned   n_events;
     amp_t     *scratch;         // second buffer, allocated on first use (M > 12 modular multiply only)
-    int        fusion;          // 1: gate calls are queued and executed as fused passes (qcx_fuse.inc.h)
+    int        fusion;          // 1: every gate call is queued (fused passes, qcx_fuse.inc.h); 0: only the whole-circuit entry points; -1: nothing
+    int        composite;       // > 0 while a whole-circuit entry point is queueing its gates
     struct GateQueue *queue;
 };
 
@@ -779,7 +780,7 @@ extern "C" int qcx_set_fusion(qcx_register *r, int enable)
 {
     if (!r) return QCX_BAD_ARGUMENTS;
     FLUSH(r);
-    r->fusion = enable ? 1 : 0;
+    r->fusion = enable > 0 ? 1 : (enable < 0 ? -1 : 0);
     return QCX_NO_ERROR;
 }
 
@@ -826,7 +827,7 @@ extern "C" int qcx_hadamard_gate(unsigned q, qcx_register *r)
 {
     if (!r) return QCX_BAD_ARGUMENTS;
     if (q >= r->n) return QCX_BAD_QUBIT;
-    if (r->fusion) { QGate g; memset(&g, 0, sizeof g); g.type = FUSE_H; g.q = q; return fuse_push(r, g); }
+    if (r->fusion > 0 || r->composite) { QGate g; memset(&g, 0, sizeof g); g.type = FUSE_H; g.q = q; return fuse_push(r, g); }
     return qcx_shard_hadamard(r->amp, r->n, q, r->stream);
 }
 
@@ -848,7 +849,7 @@ extern "C" int qcx_c_phase_shift_gate(unsigned c, unsigned t, double theta, qcx_
     if (c >= r->n || t >= r->n || c == t) return QCX_BAD_QUBIT;
     double er, ei;
     qcx_polar(theta, &er, &ei);
-    if (r->fusion) {
+    if (r->fusion > 0 || r->composite) {
         QGate g; memset(&g, 0, sizeof g);
         g.type = FUSE_PHASE; g.mask = ((uint64_t)1 << c) | ((uint64_t)1 << t); g.c = er; g.s = ei;
         return fuse_push(r, g);
@@ -860,7 +861,7 @@ extern "C" int qcx_c_amodc_gate(unsigned C, unsigned long long atox, unsigned c,
 {
     if (!r || C == 0) return QCX_BAD_ARGUMENTS;
     if (c >= r->n) return QCX_BAD_QUBIT;
-    if (r->fusion) {
+    if (r->fusion > 0 || r->composite) {
         QGate g; memset(&g, 0, sizeof g);
         g.q = c; g.C = C; g.A = (unsigned)(atox % C);
         g.type = ((unsigned)r->M <= 12 && camodc_closed_form(r->n, (unsigned)r->M, C, g.A, c)) ? (uint32_t)FUSE_CAMODC : 99u;
@@ -871,9 +872,25 @@ extern "C" int qcx_c_amodc_gate(unsigned C, unsigned long long atox, unsigned c,
 
 extern "C" int qcx_swap_states(qcx_register *r) { return r ? QCX_NO_ERROR : QCX_BAD_ARGUMENTS; }
 
-extern "C" int qcx_inverse_QFT(qcx_register *r)
+// The whole-circuit entry points know their complete gate list, so unless the register is in strict per-gate mode
+// (qcx_set_fusion(reg, -1)) they hand it to the pass scheduler in one piece: same bits, one HBM round trip per pass
+// instead of one per gate.  Nested use (quantum_computation -> inverse_QFT) flushes once, at the outermost exit.
+struct CircuitScope {
+    qcx_register *r;
+    bool mine;
+    explicit CircuitScope(qcx_register *r_) : r(r_), mine(r_->fusion == 0) { if (mine) r->composite++; }
+    int done(int status)
+    {
+        if (!mine) return status;
+        mine = false;
+        if (--r->composite == 0) { const int f = fuse_flush(r); if (status == QCX_NO_ERROR) status = f; }
+        return status;
+    }
+    ~CircuitScope() { (void)done(QCX_NO_ERROR); }
+};
+
+static int inverse_qft_body(qcx_register *r)
 {
-    if (!r) return QCX_BAD_ARGUMENTS;
     for (int l = r->L + r->M - 1; l >= r->M; l--) {
         QCX_TRY(qcx_hadamard_gate((unsigned)l, r));
         for (int k = l - 1; k >= r->M; k--) {
@@ -882,6 +899,13 @@ extern "C" int qcx_inverse_QFT(qcx_register *r)
         }
     }
     return QCX_NO_ERROR;
+}
+
+extern "C" int qcx_inverse_QFT(qcx_register *r)
+{
+    if (!r) return QCX_BAD_ARGUMENTS;
+    CircuitScope scope(r);
+    return scope.done(inverse_qft_body(r));
 }
 
 // the reference's INT_POW (Q:158-159) as x86-64 gcc evaluates it: pow, +0.5, truncation to a
@@ -893,9 +917,17 @@ extern "C" unsigned qcx_ref_int_pow(double base, double power)
     return (unsigned)(unsigned long long)(long long)d;
 }
 
+static int quantum_computation_body(unsigned C, unsigned a, int intpow_mode, qcx_register *r);
+
 extern "C" int qcx_quantum_computation(unsigned C, unsigned a, int intpow_mode, qcx_register *r)
 {
     if (!r || C == 0) return QCX_BAD_ARGUMENTS;
+    CircuitScope scope(r);
+    return scope.done(quantum_computation_body(C, a, intpow_mode, r));
+}
+
+static int quantum_computation_body(unsigned C, unsigned a, int intpow_mode, qcx_register *r)
+{
     const unsigned lo = r->n - (unsigned)r->L;
     for (unsigned l = lo; l < r->n; l++) QCX_TRY(qcx_hadamard_gate(l, r));
     unsigned x = 1;                                   // Q:714
@@ -906,7 +938,7 @@ extern "C" int qcx_quantum_computation(unsigned C, unsigned a, int intpow_mode, 
         x *= 2;                                       // Q:730
         exact = (exact * exact) % C;
     }
-    return qcx_inverse_QFT(r);
+    return inverse_qft_body(r);
 }
 
 extern "C" int qcx_measure_state_r(qcx_register *r, double rnd, unsigned long *state_num)

@@ -115,8 +115,11 @@ class Register:
         return out.value
 
     def set_fusion(self, enable=True):
-        """queue gates and run them as fused LDS-tile passes (bit-identical results)"""
-        check(lib().qcx_set_fusion(self._h, int(bool(enable))), "qcx_set_fusion")
+        """Fused LDS-tile passes (bit-identical results).  True/1: every gate call is queued; False/0 (default): only
+        the whole-circuit calls (inverse_QFT, quantum_computation) run as fused passes; -1: strictly one kernel launch
+        per gate, inside the whole-circuit calls too."""
+        mode = -1 if (enable is not True and enable is not False and int(enable) < 0) else int(bool(enable))
+        check(lib().qcx_set_fusion(self._h, mode), "qcx_set_fusion")
 
     def flush(self):
         check(lib().qcx_flush(self._h), "qcx_flush")

@@ -122,10 +122,12 @@ def test_reset_register(qc):
     assert_bits_equal(s, want, "reset")
 
 
+@pytest.mark.parametrize("mode", [-1, 0], ids=["one-launch-per-gate", "circuit-as-fused-passes"])
 @pytest.mark.parametrize("L,M,C,a", [(3, 4, 15, 7), (4, 4, 15, 7), (5, 5, 21, 2), (5, 5, 33, 7), (8, 4, 15, 7), (6, 6, 35, 2)])
-def test_shor_circuit_bit_exact(qc, ob, L, M, C, a):
+def test_shor_circuit_bit_exact(qc, ob, L, M, C, a, mode):
     n = L + M
     with qc.Register(L, M) as reg:
+        reg.set_fusion(mode)
         qc.reset_register(reg)
         qc.quantum_computation(C, a, reg)
         got = reg.read()
@@ -140,15 +142,18 @@ def test_shor_circuit_reference_intpow_mode(qc, ob):
     L, M, C, a = 8, 4, 15, 7
     n = L + M
     with qc.Register(L, M) as reg:
+        reg.set_fusion(-1)
         qc.reset_register(reg); qc.quantum_computation(C, a, reg, ref_intpow=True); got = reg.read()
     want = np.zeros(2 << n); ob.reset(want, n); ob.quantum_computation(want, n, M, C, a, ref_intpow=True)
     assert_bits_equal(got, want, "ref-intpow circuit")
 
 
-def test_iqft_schedule_full_register(qc, ob):
+@pytest.mark.parametrize("mode", [-1, 0], ids=["one-launch-per-gate", "circuit-as-fused-passes"])
+def test_iqft_schedule_full_register(qc, ob, mode):
     n = 12
     a = ob.random_state(n, 77)
     with qc.Register(n, 0) as reg:
+        reg.set_fusion(mode)
         reg.write(a); qc.inverse_QFT(reg); got = reg.read()
     want = a.copy(); ob.iqft(want, n, 0)
     assert_bits_equal(got, want, "IQFT schedule n=12")

@@ -91,7 +91,8 @@ def test_cli_without_gpu_fails_loudly(hostlib):
     (["-C", "33", "-L", "5", "-M", "5", "-f", "7"], (11, 3)),         # the reference's documented example, with -f
     (["-C", "21", "-L", "9", "-M", "5", "-a", "2"], (3, 7)),
     (["-C", "35", "-L", "5", "-M", "6"], None),                      # loop mode over trial integers
-    (["-C", "21", "-L", "11", "-M", "5", "-a", "2", "-F"], (3, 7)),  # with gate fusion
+    (["-C", "21", "-L", "11", "-M", "5", "-a", "2", "-F"], (3, 7)),  # every gate call queued
+    (["-C", "21", "-L", "11", "-M", "5", "-a", "2", "-G"], (3, 7)),  # one kernel launch per gate
 ])
 def test_cli_factors_on_gpu(hostlib, args, factors):
     ok = 0
@@ -116,3 +117,15 @@ def test_cli_reference_histogram_seed(hostlib):
     r = run_cli("-C", "15", "-L", "3", "-M", "4", "-a", "7", "-s", "12345", "-V")
     assert r.returncode in (0, 3)
     assert "omega = " in r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_measures_the_same_state_in_every_fusion_mode(hostlib):
+    """default (circuit as fused passes), -F (everything queued), -G (one launch per gate): same MT19937 seed ->
+    the same measured basis state, because the amplitudes are the same bits"""
+    outs = []
+    for extra in ([], ["-F"], ["-G"]):
+        r = run_cli("-C", "21", "-L", "12", "-M", "5", "-a", "2", "-s", "7", "-V", *extra)
+        assert r.returncode in (0, 3), r.stdout + r.stderr
+        outs.append([l.split("omega")[0] for l in r.stdout.splitlines() if "Measured state" in l])
+    assert outs[0] and outs[0] == outs[1] == outs[2], outs

@@ -5,6 +5,8 @@
   config 5' n=30 Shor N=21 a=2 (L=25, M=5) on ONE GPU   (50 H + 25 C_AMODC + 300 CPHASE + measure)
 and per-kernel-class GB/s on the algorithmic bytes of SURVEY s8(d).  Writes one JSON object."""
 import argparse
+
+FUSION = -1
 import json
 import math
 import os
@@ -35,6 +37,7 @@ def cfg2(n=26, reps=5):
 
 def cfg3(n=28, reps=3):
     with qc.Register(n, 0) as reg:
+        reg.set_fusion(FUSION)
         reg.fill_random(7)
         run = lambda: qc.inverse_QFT(reg)
         run()
@@ -54,6 +57,7 @@ def cfg5(L=25, M=5, Cn=21, a=2, seed=12345):
     n = L + M
     rng = qc.Rng(seed)
     with qc.Register(L, M) as reg:
+        reg.set_fusion(FUSION)
         qc.reset_register(reg); qc.quantum_computation(Cn, a, reg); reg.synchronize()     # warm-up
         qc.reset_register(reg)
         dt = timed(reg, lambda: qc.quantum_computation(Cn, a, reg))
@@ -76,8 +80,10 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="gpurun_out/bench_configs.json")
     ap.add_argument("--skip5", action="store_true")
+    ap.add_argument("--fusion", type=int, default=-1, help="-1: one launch per gate (default here), 0: whole-circuit calls as fused passes (the library default), 1: everything queued")
     a = ap.parse_args()
-    out = {"config2": cfg2(), "config3": cfg3()}
+    FUSION = a.fusion
+    out = {"fusion_mode": FUSION, "config2": cfg2(), "config3": cfg3()}
     print(json.dumps(out["config2"])); print(json.dumps(out["config3"]), flush=True)
     if not a.skip5:
         out["config5_single_gpu"] = cfg5()

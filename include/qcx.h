@@ -161,6 +161,31 @@ typedef struct {
     uint32_t C, A;      /* modular multiply: modulus and multiplier (A < C) */
 } qcx_gate_desc;
 int  qcx_shard_run_fused(void *amp, unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates, void *stream);
+
+/* The pass planner alone, on the host (no GPU needed; test and tooling interface).  Cuts a gate list into actions --
+ * fused passes over LDS tiles, or single gates that run as their stand-alone kernel -- and returns the records the
+ * pass kernels interpret, 32 bytes each, all passes back to back.  Record formats: csrc/qcx_kernels.h (FuseOp and
+ * the ROUNDS form); tests/fuse_emulator.py interprets them on the CPU and compares with the oracle.
+ * Returns QCX_INSUFFICIENT_MEMORY (with the needed counts in n_actions / n_records) when an array is too small. */
+typedef struct {
+    uint32_t type, a;
+    uint64_t mask;
+    double   c, s;
+} qcx_fuse_record;
+typedef struct {
+    int      fused;                 /* 0: the single gate first_gate, stand-alone kernel; 1: one fused pass */
+    unsigned first_gate, ngates;    /* the gates of the list this action covers (in order, no gaps between actions) */
+    unsigned T, c, nh;              /* tile = 2^T amplitudes: the c lowest index bits + nh higher bits hbit[0..nh) */
+    unsigned char hbit[16];
+    unsigned nopipe;                /* 1: one tile per workgroup (phase-dominated pass), 0: pipelined kernel */
+    unsigned rounds_form;           /* 1: records in ROUNDS form (rounds / items / runs), 0: plain gate list */
+    size_t   rec_off, rec_cnt;      /* this pass's records (tables included) inside `records` */
+    unsigned nops;                  /* records the kernel walks (the rest, if any, are tables) */
+    unsigned table_bytes, table_rec_off;    /* folded modular-multiply tables: size, and offset in records from rec_off */
+} qcx_plan_action;
+int  qcx_fusion_plan(unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates,
+                     qcx_plan_action *actions, unsigned max_actions, unsigned *n_actions,
+                     qcx_fuse_record *records, size_t max_records, size_t *n_records);
 /* sequential cumulative scan of |amp|^2 over this shard continuing from cum_in
  * (global index of local 0 = first_global; indices >= last_excluded are not
  * examined, Q:283).  Synchronous. */

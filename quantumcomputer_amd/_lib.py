@@ -75,6 +75,7 @@ SIGNATURES = {
     "qcx_shard_swap_bits": (_i, [_p, _p, _u, _u, C.POINTER(_u), C.POINTER(_u), _p]),
     "qcx_shard_norm2": (_i, [_p, _u, C.POINTER(_d), _p]),
     "qcx_shard_run_fused": (_i, [_p, _u, _u, _u, _p, _p]),
+    "qcx_fusion_plan": (_i, [_u, _u, _u, _p, _p, _u, C.POINTER(_u), _p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "qcx_shard_measure_scan": (_i, [_p, _u, _u64, _u64, _d, _d, C.POINTER(_i), C.POINTER(_u64), C.POINTER(_d), _p]),
     "qcx_shard_collapse": (_i, [_p, _u, _i64, _p]),
 }
@@ -90,6 +91,39 @@ class GateDesc(C.Structure):
     """qcx_gate_desc (include/qcx.h)"""
     _fields_ = [("type", C.c_uint32), ("q", C.c_uint32), ("mask", C.c_uint64), ("c", C.c_double), ("s", C.c_double),
                 ("C", C.c_uint32), ("A", C.c_uint32)]
+
+
+class FuseRecord(C.Structure):
+    """qcx_fuse_record (include/qcx.h): one 32-byte record of a fused pass"""
+    _fields_ = [("type", C.c_uint32), ("a", C.c_uint32), ("mask", C.c_uint64), ("c", C.c_double), ("s", C.c_double)]
+
+
+class PlanAction(C.Structure):
+    """qcx_plan_action (include/qcx.h)"""
+    _fields_ = [("fused", C.c_int), ("first_gate", C.c_uint), ("ngates", C.c_uint), ("T", C.c_uint), ("c", C.c_uint),
+                ("nh", C.c_uint), ("hbit", C.c_ubyte * 16), ("nopipe", C.c_uint), ("rounds_form", C.c_uint),
+                ("rec_off", C.c_size_t), ("rec_cnt", C.c_size_t), ("nops", C.c_uint), ("table_bytes", C.c_uint),
+                ("table_rec_off", C.c_uint)]
+
+
+def fusion_plan(n_local, M, descs):
+    """The pass planner alone (host code, no GPU needed).  descs: (type, q, mask, c, s, C, A) tuples as for
+    qcx_shard_run_fused.  Returns (actions, records): a list of PlanAction and a ctypes array of FuseRecord."""
+    arr = (GateDesc * max(len(descs), 1))()
+    for i, d in enumerate(descs):
+        arr[i].type, arr[i].q, arr[i].mask, arr[i].c, arr[i].s, arr[i].C, arr[i].A = d
+    na, nr = C.c_uint(0), C.c_size_t(0)
+    cap_a, cap_r = len(descs) + 4, 4 * len(descs) + 64
+    while True:
+        acts = (PlanAction * cap_a)()
+        recs = (FuseRecord * cap_r)()
+        st = lib().qcx_fusion_plan(n_local, M, len(descs), C.cast(arr, C.c_void_p), C.cast(acts, C.c_void_p), cap_a, C.byref(na),
+                                   C.cast(recs, C.c_void_p), cap_r, C.byref(nr))
+        if st == 1 and (na.value > cap_a or nr.value > cap_r):        # QCX_INSUFFICIENT_MEMORY: grow and retry
+            cap_a, cap_r = max(cap_a, na.value), max(cap_r, nr.value)
+            continue
+        check(st, "qcx_fusion_plan")
+        return [acts[k] for k in range(na.value)], recs, nr.value
 
 
 _lib = None

@@ -99,7 +99,7 @@ struct Tune {
     long fuse_c_phase = 4;
     long fuse_phase_ratio = 6; // a pass is phase-dominated when it holds at least this many phases per H (and nothing else)
     long fuse_camruns = 1;     // rounds form: fold runs of permutation-type modular multiplies into one gather
-    long fuse_pruns  = 1;      // rounds form: group equal-selection phases into branch-free runs
+    long fuse_pruns  = 1;      // (no effect any more: phases of the rounds form always go as phase runs; kept for old tuning scripts)
     long fuse_rounds = 1;      // fused passes: rounds form (4 amplitudes per thread in registers, radix-4 H steps)
     long fuse_ldsdma = 1;      // fused passes: fill the tile with global_load_lds (LDS-DMA)
     long fuse_max_queue = 4096;
@@ -737,21 +737,8 @@ extern "C" void *qcx_device_pointer(qcx_register *r) { if (r) (void)fuse_flush(r
 static GateQueue *g_shard_queue[64];
 static std::mutex g_shard_queue_mutex[64];
 
-extern "C" int qcx_shard_run_fused(void *amp, unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates, void *stream)
+static int descs_to_gates(unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates, std::vector<QGate> &out)
 {
-    if (!amp || n_local == 0 || n_local > 40 || M > n_local || (count && !gates)) return QCX_BAD_ARGUMENTS;
-    if (M > 12) return QCX_UNSUPPORTED;
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) return QCX_HIP_ERROR;
-    std::lock_guard<std::mutex> lock(g_shard_queue_mutex[dev]);
-    if (!g_shard_queue[dev]) g_shard_queue[dev] = new GateQueue();
-    qcx_register tmp;
-    memset(&tmp, 0, sizeof tmp);
-    tmp.L = (int)(n_local - M); tmp.M = (int)M; tmp.n = n_local; tmp.dim = (uint64_t)1 << n_local;
-    tmp.amp = (amp_t *)amp; tmp.stream = tmp.own_stream = (hipStream_t)stream;
-    tmp.fusion = 1; tmp.queue = g_shard_queue[dev];
-    tmp.queue->gates.clear();
     for (unsigned k = 0; k < count; k++) {
         const qcx_gate_desc &d = gates[k];
         QGate g; memset(&g, 0, sizeof g);
@@ -769,9 +756,67 @@ extern "C" int qcx_shard_run_fused(void *amp, unsigned n_local, unsigned M, unsi
                                                      : camodc_closed_form(n_local, M, d.C, g.A, d.q);
             g.type = closed ? (uint32_t)FUSE_CAMODC : 99u;
         } else return QCX_BAD_ARGUMENTS;
-        tmp.queue->gates.push_back(g);
+        out.push_back(g);
     }
+    return QCX_NO_ERROR;
+}
+
+extern "C" int qcx_shard_run_fused(void *amp, unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates, void *stream)
+{
+    if (!amp || n_local == 0 || n_local > 40 || M > n_local || (count && !gates)) return QCX_BAD_ARGUMENTS;
+    if (M > 12) return QCX_UNSUPPORTED;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return QCX_HIP_ERROR;
+    std::lock_guard<std::mutex> lock(g_shard_queue_mutex[dev]);
+    if (!g_shard_queue[dev]) g_shard_queue[dev] = new GateQueue();
+    qcx_register tmp;
+    memset(&tmp, 0, sizeof tmp);
+    tmp.L = (int)(n_local - M); tmp.M = (int)M; tmp.n = n_local; tmp.dim = (uint64_t)1 << n_local;
+    tmp.amp = (amp_t *)amp; tmp.stream = tmp.own_stream = (hipStream_t)stream;
+    tmp.fusion = 1; tmp.queue = g_shard_queue[dev];
+    tmp.queue->gates.clear();
+    QCX_TRY(descs_to_gates(n_local, M, count, gates, tmp.queue->gates));
     return fuse_flush(&tmp);
+}
+
+// The planner alone, on the host (no GPU needed): which passes / stand-alone gates a gate list becomes and the
+// records the pass kernels would interpret.  actions[k] describes action k; records receives the raw 32-byte
+// records of all passes back to back (action.rec_off / rec_cnt index into it, in records).
+extern "C" int qcx_fusion_plan(unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates,
+                               qcx_plan_action *actions, unsigned max_actions, unsigned *n_actions,
+                               qcx_fuse_record *records, size_t max_records, size_t *n_records)
+{
+    if (n_local == 0 || n_local > 40 || M > n_local || (count && !gates) || !n_actions || !n_records) return QCX_BAD_ARGUMENTS;
+    if (M > 12) return QCX_UNSUPPORTED;
+    static_assert(sizeof(qcx_fuse_record) == sizeof(FuseOp), "record layout");
+    qcx_register tmp;
+    memset(&tmp, 0, sizeof tmp);
+    tmp.L = (int)(n_local - M); tmp.M = (int)M; tmp.n = n_local; tmp.dim = (uint64_t)1 << n_local;
+    std::vector<QGate> q;
+    QCX_TRY(descs_to_gates(n_local, M, count, gates, q));
+    std::vector<FuseAction> acts;
+    std::vector<FuseOp> ops;
+    fuse_plan(&tmp, q, acts, ops);
+    *n_actions = (unsigned)acts.size();
+    *n_records = ops.size();
+    if (acts.size() > max_actions || ops.size() > max_records || (!actions && !acts.empty()) || (!records && !ops.empty()))
+        return QCX_INSUFFICIENT_MEMORY;
+    for (size_t k = 0; k < acts.size(); k++) {
+        const FuseAction &a = acts[k];
+        qcx_plan_action &o = actions[k];
+        memset(&o, 0, sizeof o);
+        o.fused = a.fused;
+        if (!a.fused) { o.first_gate = (unsigned)a.gate; o.ngates = 1; continue; }
+        o.first_gate = (unsigned)a.first_gate; o.ngates = (unsigned)a.ngates;
+        o.T = a.P.T; o.c = a.P.c; o.nh = a.P.nh; o.nopipe = (unsigned)a.nopipe;
+        memcpy(o.hbit, a.P.hbit, sizeof o.hbit);
+        o.rounds_form = (unsigned)a.P.cam_ctl_local[0];
+        o.rec_off = a.op_off; o.rec_cnt = a.op_cnt; o.nops = a.P.nops;
+        o.table_bytes = (unsigned)a.P.cam_ctl_local[1]; o.table_rec_off = (unsigned)a.P.cam_ctl_local[2];
+    }
+    if (!ops.empty()) memcpy(records, ops.data(), ops.size() * sizeof(FuseOp));
+    return QCX_NO_ERROR;
 }
 
 // gate fusion: 1 = queue gates and run them as fused LDS-tile passes; results are

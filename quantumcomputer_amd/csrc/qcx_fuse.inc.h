@@ -51,7 +51,7 @@ struct FuseAction {
     int      fused;          // 0: stand-alone gate `gate`, 1: fused pass
     size_t   gate;
     FusePass P;
-    size_t   op_off, op_cnt, ngates;
+    size_t   op_off, op_cnt, ngates, first_gate;
     int      nopipe;         // phase-heavy pass: the one-tile-per-workgroup kernel (more resident waves) instead of the pipelined one
 };
 
@@ -226,12 +226,11 @@ static int launch_pass(qcx_register *r, const FusePass &P_in, const FuseOp *d_op
     return QCX_NO_ERROR;
 }
 
-// plan (cut the queue into passes) -> upload every pass's records in one copy -> launch in order.  No host
-// synchronisation except waiting for the PREVIOUS flush's kernels before its record buffers are reused.
-static int fuse_flush(qcx_register *r)
+// The planner: cut a gate list into actions (fused passes and stand-alone gates) and emit every pass's records.
+// Pure host code (no HIP call): qcx_fusion_plan exposes it so that the CPU-only tests can check the records against
+// the oracle with an emulator of the pass kernels (tests/fuse_emulator.py).
+static void fuse_plan(const qcx_register *r, const std::vector<QGate> &gates, std::vector<FuseAction> &acts, std::vector<FuseOp> &all_ops)
 {
-    GateQueue *gq = r->queue;
-    if (!gq || gq->gates.empty()) return QCX_NO_ERROR;
     const unsigned n = r->n;
     unsigned T = (unsigned)g_tune.fuse_T, c_def = (unsigned)g_tune.fuse_c;
     if (T > 12) T = 12;
@@ -239,11 +238,7 @@ static int fuse_flush(qcx_register *r)
     if (T > n) T = n;
     if (c_def > T) c_def = T;
 
-    std::vector<QGate> gates;
-    gates.swap(gq->gates);                       // the queue is empty from here on (re-entrancy safe)
-
-    std::vector<FuseAction> acts;
-    std::vector<FuseOp> all_ops, legacy;
+    std::vector<FuseOp> legacy;
     std::vector<unsigned> need;
     size_t i = 0;
     while (i < gates.size()) {
@@ -289,7 +284,7 @@ static int fuse_flush(qcx_register *r)
         std::sort(hbits.begin(), hbits.end());
 
         act.fused = 1;
-        act.ngates = i - first;
+        act.ngates = i - first; act.first_gate = first;
         act.P.c = c; act.P.nh = (uint32_t)hbits.size(); act.P.T = c + act.P.nh;
         act.P.cam_ctl_local[3] = (int32_t)(((size_t)2 << std::min(12u, (unsigned)r->M)) + 16);   // table area sits behind the lut
         for (unsigned j = 0; j < act.P.nh; j++) act.P.hbit[j] = (uint8_t)hbits[j];
@@ -344,6 +339,19 @@ static int fuse_flush(qcx_register *r)
         }
         acts.push_back(act);
     }
+}
+
+// plan -> upload every pass's records in one copy -> launch in order.  No host synchronisation except waiting for
+// the PREVIOUS flush's kernels before its record buffers are reused.
+static int fuse_flush(qcx_register *r)
+{
+    GateQueue *gq = r->queue;
+    if (!gq || gq->gates.empty()) return QCX_NO_ERROR;
+    std::vector<QGate> gates;
+    gates.swap(gq->gates);                       // the queue is empty from here on (re-entrancy safe)
+    std::vector<FuseAction> acts;
+    std::vector<FuseOp> all_ops;
+    fuse_plan(r, gates, acts, all_ops);
 
     if (!all_ops.empty()) {
         if (gq->ev_valid) HIP_TRY(hipEventSynchronize(gq->ev));       // the previous flush may still read the buffers

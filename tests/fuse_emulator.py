@@ -1,0 +1,245 @@
+"""CPU emulator of the fused-pass kernels' record interpreter (TEST INFRASTRUCTURE, numpy).
+
+`qcx_fusion_plan` (include/qcx.h) returns what the planner in csrc/qcx_fuse.inc.h would hand to the GPU: actions (fused
+passes / stand-alone gates) and the 32-byte records of every pass.  This module applies those records to a small state
+vector with the arithmetic the kernels in csrc/qcx_kernels.h use -- same products and sums in the same order, the
+"+ 0.0" canonicalisation where the kernels put it (per gate in the plain form; once per round / run in the ROUNDS
+form) -- so that the CPU-only test suite can check planner + record format + kernel semantics against the oracle
+without a GPU.  Everything is expressed on GLOBAL amplitude indices: tile-local bit j is global bit j for j < c and
+global bit hbit[j - c] above.
+"""
+import struct
+
+import numpy as np
+
+FUSE_H, FUSE_PHASE, FUSE_CAMODC, FUSE_ROUND, FUSE_PRUN, FUSE_CAMRUN = 0, 1, 2, 3, 4, 5
+SQRT1_2 = 0.70710678118654752440
+
+
+class Pass:
+    def __init__(self, n, act):
+        self.n = n
+        self.c = act.c
+        self.hbit = [int(act.hbit[j]) for j in range(act.nh)]
+        self.T = act.T
+        assert self.T == self.c + len(self.hbit)
+        self.idx = np.arange(1 << n, dtype=np.uint64)
+        tile_mask = (1 << self.c) - 1
+        for b in self.hbit:
+            tile_mask |= 1 << b
+        self.base = self.idx & np.uint64(~tile_mask & ((1 << 64) - 1))
+
+    def gbit(self, j):
+        return j if j < self.c else self.hbit[j - self.c]
+
+    def bit(self, j_local):
+        return ((self.idx >> np.uint64(self.gbit(j_local))) & np.uint64(1)).astype(bool)
+
+    def local_all_set(self, mloc):
+        ok = np.ones(self.idx.shape, dtype=bool)
+        j = 0
+        while mloc >> j:
+            if (mloc >> j) & 1:
+                assert j < self.T, "tile-local mask bit outside the tile"
+                ok &= self.bit(j)
+            j += 1
+        return ok
+
+    def outside_all_set(self, mext):
+        m = np.uint64(mext)
+        return (self.base & m) == m
+
+
+def _h(re, im, gb, canon):
+    """H on global bit gb: the kernels' butterfly (t0 +/- t1, each product s * x rounded on its own)"""
+    n_amp = re.shape[0]
+    i0 = np.arange(n_amp, dtype=np.int64)
+    i0 = i0[(i0 >> gb) & 1 == 0]
+    i1 = i0 | (1 << gb)
+    t0r, t0i, t1r, t1i = SQRT1_2 * re[i0], SQRT1_2 * im[i0], SQRT1_2 * re[i1], SQRT1_2 * im[i1]
+    ar, ai, br, bi = t0r + t1r, t0i + t1i, t0r - t1r, t0i - t1i
+    if canon:
+        ar, ai, br, bi = ar + 0.0, ai + 0.0, br + 0.0, bi + 0.0
+    re[i0], im[i0], re[i1], im[i1] = ar, ai, br, bi
+
+
+def _rotate(re, im, sel, cc, ss, canon):
+    x, y = re[sel], im[sel]
+    nx = (cc * x) - (ss * y)
+    ny = (cc * y) + (ss * x)
+    if canon:
+        nx, ny = nx + 0.0, ny + 0.0
+    re[sel], im[sel] = nx, ny
+
+
+def _cam_extra(rec):
+    return struct.unpack("<IIII", struct.pack("<dd", rec.c, rec.s))       # C, d, Cd, inv
+
+
+def _camodc_step(P, re, im, rec):
+    """fuse_camodc_step: closed form of the controlled modular multiply on 2^M blocks inside the tile"""
+    M = rec.a & 0xFF
+    ctl_local = ((rec.a >> 8) & 0xFF) - 1
+    Cn, d, Cd, inv = _cam_extra(rec)
+    on = P.outside_all_set(rec.mask)
+    if ctl_local >= 0:
+        on = on & P.bit(ctl_local)
+    idx = P.idx.astype(np.int64)
+    f = idx & ((1 << M) - 1)
+    act = on & (f < Cn)
+    nr, ni = re.copy(), im.copy()
+    blk0 = idx - f
+    if d == 1:
+        src = blk0 + (f * inv) % Cn
+        sr, si = np.zeros_like(re), np.zeros_like(im)
+        sr[act] += re[src[act]]; si[act] += im[src[act]]
+    else:
+        sr, si = np.zeros_like(re), np.zeros_like(im)
+        live = act & (f % d == 0)
+        s0 = ((f // d) * inv) % Cd
+        for q in range(d):
+            src = blk0 + s0 + q * Cd
+            sr[live] += re[src[live]]; si[live] += im[src[live]]
+    nr[act], ni[act] = sr[act], si[act]
+    re[:], im[:] = nr, ni
+
+
+def _camrun(P, re, im, recs, i, blob):
+    """FUSE_CAMRUN: a run of permutation-type multiplies folded into one gather through per-gate byte tables"""
+    hdr = recs[i]
+    cnt, cpad = hdr.a & 0xFFFF, hdr.a >> 16
+    tabs = int(hdr.mask)
+    M = recs[i + 1].a & 0xFF
+    Cn = _cam_extra(recs[i + 1])[0]
+    x = np.ones(P.idx.shape, dtype=np.int64)
+    for g in range(cnt):
+        r = recs[i + 1 + g]
+        assert (r.type & 0xFF) == FUSE_CAMODC and _cam_extra(r)[1] == 1 and _cam_extra(r)[0] == Cn
+        cond = P.outside_all_set(r.mask)
+        cl = ((r.a >> 8) & 0xFF) - 1
+        if cl >= 0:
+            cond = cond & P.bit(cl)
+        tb = np.frombuffer(blob[tabs + g * cpad: tabs + (g + 1) * cpad], dtype=np.uint8).astype(np.int64)
+        x = np.where(cond, tb[x], x)
+    idx = P.idx.astype(np.int64)
+    f = idx & ((1 << M) - 1)
+    wr = (x != 1) & (f < Cn)
+    src = (idx - f) + (x * f) % Cn
+    nr, ni = re.copy(), im.copy()
+    nr[wr] = 0.0 + re[src[wr]]
+    ni[wr] = 0.0 + im[src[wr]]
+    re[:], im[:] = nr, ni
+    return cnt
+
+
+def apply_pass(state, n, act, recs):
+    """one fused pass; state = interleaved (re, im) float64 array of 2 * 2^n, modified in place"""
+    re, im = state[0::2].copy(), state[1::2].copy()
+    P = Pass(n, act)
+    r0 = act.rec_off
+    R = [recs[r0 + k] for k in range(act.rec_cnt)]
+    blob = b""
+    if act.table_bytes:
+        raw = b"".join(bytes(memoryview(recs[r0 + act.table_rec_off + k]).cast("B")) for k in range(act.rec_cnt - act.table_rec_off))
+        blob = raw[:act.table_bytes]
+    nops = act.nops
+    i = 0
+    stats = dict(rounds=0, runs=0, run_gates=0, h=0)
+    if not act.rounds_form:
+        while i < nops:
+            r = R[i]
+            t = r.type & 0xFF
+            if t == FUSE_H:
+                _h(re, im, P.gbit(r.a), True); stats["h"] += 1
+            elif t == FUSE_PHASE:
+                _rotate(re, im, P.outside_all_set(r.mask) & P.local_all_set(r.a), r.c, r.s, True)
+            elif t == FUSE_CAMODC:
+                _camodc_step(P, re, im, r)
+            else:
+                raise AssertionError(f"record type {t} in a plain gate list")
+            i += 1
+    else:
+        while i < nops:
+            r = R[i]
+            t = r.type & 0xFF
+            if t == FUSE_ROUND:
+                rb0, rb1, has_h, cnt = r.a & 0xFF, (r.a >> 8) & 0xFF, (r.a >> 16) & 1, int(r.mask)
+                assert rb0 < rb1 < P.T and cnt >= 1
+                qreg = P.bit(rb0).astype(np.int64) | (P.bit(rb1).astype(np.int64) << 1)
+                stats["rounds"] += 1
+                saw_h = False
+                o, oend = i + 1, i + cnt
+                while o <= oend:
+                    it = R[o].type
+                    kind, code, rc = it & 0xFF, (it >> 8) & 0xFF, it >> 16
+                    if kind == FUSE_H:
+                        assert (code & 32) and rc == 0
+                        _h(re, im, P.gbit(rb1 if code & 1 else rb0), False)
+                        saw_h = True; stats["h"] += 1
+                        o += 1
+                    elif kind == FUSE_PRUN:
+                        rsel, canon = code & 15, bool(code & 16)
+                        assert 1 <= rc <= 64 and rsel and not (code & 32)
+                        assert canon == (not has_h), "a run canonicalises its own zeros exactly when its round has no H"
+                        touched = np.zeros(P.idx.shape, dtype=bool)
+                        for g in range(rc):
+                            gr = R[o + 1 + g]
+                            assert (gr.type & 0xFF) == FUSE_PHASE and ((gr.type >> 8) & 15) == rsel
+                            assert not (gr.a & ((1 << rb0) | (1 << rb1))), "register bits stay out of the lane mask"
+                            sel = P.outside_all_set(gr.mask) & P.local_all_set(gr.a) & (((rsel >> qreg) & 1) == 1)
+                            _rotate(re, im, sel, gr.c, gr.s, False)
+                            touched |= sel
+                        if canon:
+                            re[touched] += 0.0; im[touched] += 0.0
+                        stats["runs"] += 1; stats["run_gates"] += rc
+                        o += 1 + rc
+                    else:
+                        raise AssertionError(f"item kind {kind} inside a round")
+                assert o == oend + 1 and saw_h == bool(has_h)
+                if has_h:
+                    re += 0.0; im += 0.0
+                i += 1 + cnt
+            elif t == FUSE_CAMRUN:
+                i += 1 + _camrun(P, re, im, R, i, blob)
+            elif t == FUSE_CAMODC:
+                _camodc_step(P, re, im, r)
+                i += 1
+            else:
+                raise AssertionError(f"record type {t} between rounds")
+    state[0::2], state[1::2] = re, im
+    return stats
+
+
+def run_plan(state, n, M, descs, actions, recs, ob):
+    """apply a whole plan: fused passes through the emulator, stand-alone gates through the oracle"""
+    covered = 0
+    totals = dict(passes=0, standalone=0, rounds=0, runs=0, run_gates=0, h=0)
+    for act in actions:
+        assert act.first_gate == covered, "actions cover the gate list in order without gaps"
+        covered += act.ngates
+        if act.fused:
+            st = apply_pass(state, n, act, recs)
+            totals["passes"] += 1
+            for k, v in st.items():
+                totals[k] += v
+        else:
+            typ, q, mask, c, s, Cn, A = descs[act.first_gate]
+            totals["standalone"] += 1
+            if typ == 0:
+                ob.hadamard(state, n, q)
+            elif typ == 1:
+                bits = [b for b in range(n) if (mask >> b) & 1]
+                assert len(bits) == 2
+                _rotate_oracle_pair(state, n, bits, c, s)
+            else:
+                ob.camodc(state, n, M, Cn, A, q)
+    assert covered == len(descs)
+    return totals
+
+
+def _rotate_oracle_pair(state, n, bits, c, s):
+    re, im = state[0::2].copy(), state[1::2].copy()
+    idx = np.arange(1 << n, dtype=np.int64)
+    sel = (((idx >> bits[0]) & 1) == 1) & (((idx >> bits[1]) & 1) == 1)
+    _rotate(re, im, sel, c, s, True)
+    state[0::2], state[1::2] = re, im

@@ -1,0 +1,142 @@
+"""CPU: the fused-pass PLANNER (csrc/qcx_fuse.inc.h, host code) and the record formats the pass kernels interpret.
+`qcx_fusion_plan` returns the plan without touching a GPU; tests/fuse_emulator.py applies its records with the kernels'
+arithmetic; the result must be the oracle's state, bit for bit.  The GPU suite then only has to show that the kernels
+do what the emulator does (tests/test_gpu_fusion.py)."""
+import math
+
+import numpy as np
+import pytest
+
+import fuse_emulator as emu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+TUNE_KEYS = ("fuse_T", "fuse_c", "fuse_rounds", "fuse_camruns", "fuse_T_phase", "fuse_c_phase", "fuse_phase_ratio")
+
+
+@pytest.fixture()
+def tune_guard(qc):
+    old = {k: qc.lib().qcx_tune_get(k.encode()) for k in TUNE_KEYS}
+    yield
+    qc.tune(**old)
+
+
+def random_program(rs, n, M, Cn, length):
+    """(descs for the planner, steps for the oracle)"""
+    descs, steps = [], []
+    for _ in range(length):
+        k = rs.randint(0, 10)
+        if k < 4:
+            q = int(rs.randint(0, n))
+            descs.append((0, q, 0, 0.0, 0.0, 0, 0)); steps.append(("h", q))
+        elif k < 9 or M == 0:
+            c, t = (int(x) for x in rs.choice(n, 2, replace=False))
+            th = float(rs.uniform(-3, 3)) if k % 2 else math.pi / (1 << int(rs.randint(1, 12)))
+            steps.append(("p", c, t, th))
+            descs.append((1, 0, (1 << c) | (1 << t), 0.0, 0.0, 0, 0))
+        else:
+            atox, ctl = int(rs.randint(1, 4 * Cn)), int(rs.randint(M, n))
+            descs.append((2, ctl, 0, 0.0, 0.0, Cn, atox % Cn)); steps.append(("c", atox, ctl))
+    return descs, steps
+
+
+def fill_polar(qc, descs, steps):
+    out = []
+    for d, s in zip(descs, steps):
+        if s[0] == "p":
+            c, sn = qc.polar(s[3])
+            d = (1, 0, d[2], c, sn, 0, 0)
+        out.append(d)
+    return out
+
+
+def oracle_run(ob, state, n, M, Cn, steps):
+    for s in steps:
+        if s[0] == "h":
+            ob.hadamard(state, n, s[1])
+        elif s[0] == "p":
+            ob.cphase(state, n, s[1], s[2], s[3])
+        else:
+            ob.camodc(state, n, M, Cn, s[1], s[2])
+
+
+CASES = [(12, 0, 1), (13, 4, 15), (14, 5, 21), (11, 4, 15), (12, 6, 35)]
+TUNES = [dict(), dict(fuse_T=10, fuse_c=4), dict(fuse_T=12, fuse_c=3), dict(fuse_T=9, fuse_c=4), dict(fuse_rounds=0),
+         dict(fuse_T_phase=10, fuse_phase_ratio=1), dict(fuse_T_phase=12, fuse_c_phase=2, fuse_phase_ratio=1), dict(fuse_camruns=0)]
+
+
+@pytest.mark.parametrize("tune", TUNES, ids=lambda t: ",".join(f"{k}={v}" for k, v in t.items()) or "default")
+@pytest.mark.parametrize("n,M,Cn", CASES)
+def test_planned_records_reproduce_the_oracle(qc, ob, tune_guard, n, M, Cn, tune):
+    qc.tune(**tune)
+    rs = np.random.RandomState(n * 100 + M + len(tune) * 7)
+    for trial in range(2):
+        descs, steps = random_program(rs, n, M, Cn, 70)
+        descs = fill_polar(qc, descs, steps)
+        actions, recs, nrec = qc.fusion_plan(n, M, descs)
+        state = ob.random_state(n, 40 + trial)
+        want = state.copy()
+        oracle_run(ob, want, n, M, Cn, steps)
+        totals = emu.run_plan(state, n, M, descs, actions, recs, ob)
+        assert np.array_equal(bits(state), bits(want)), f"n={n} M={M} {tune} trial {trial}: {totals}"
+        assert totals["passes"] >= 1
+
+
+def iqft_descs(qc, n, M):
+    descs = []
+    for l in range(n - 1, M - 1, -1):
+        descs.append((0, l, 0, 0.0, 0.0, 0, 0))
+        for k in range(l - 1, M - 1, -1):
+            c, s = qc.polar(math.pi / float(1 << (l - k)))
+            descs.append((1, 0, (1 << l) | (1 << k), c, s, 0, 0))
+    return descs
+
+
+def test_plan_of_the_n28_iqft(qc, tune_guard):
+    """config 3: 28 H + 378 phases -> 4 passes; the three phase-dominated ones on 2^10 tiles, one tile per workgroup"""
+    n = 28
+    descs = iqft_descs(qc, n, 0)
+    actions, recs, nrec = qc.fusion_plan(n, 0, descs)
+    assert len(descs) == 406 and [a.fused for a in actions] == [1, 1, 1, 1]
+    assert sum(a.ngates for a in actions) == 406
+    assert [(a.T, a.c, a.nopipe) for a in actions] == [(10, 4, 1), (10, 4, 1), (10, 4, 1), (11, 4, 0)]
+    hot = [[a.hbit[j] for j in range(a.nh)] for a in actions]
+    assert hot[0] == [22, 23, 24, 25, 26, 27] and hot[1] == [16, 17, 18, 19, 20, 21] and hot[2] == [10, 11, 12, 13, 14, 15]
+    for a in actions:
+        assert a.rounds_form == 1
+        R = [recs[a.rec_off + k] for k in range(a.nops)]
+        runs = [r.type >> 16 for r in R if (r.type & 0xFF) == emu.FUSE_PRUN]
+        assert runs and max(runs) <= 64
+        assert sum(runs) + sum(1 for r in R if (r.type & 0xFF) == emu.FUSE_H) == a.ngates
+
+
+def test_plan_of_the_n30_shor_circuit(qc, tune_guard):
+    """config 5 on one GPU: 25 H, 25 controlled multiplies (one folded run), 25 H + 300 phases"""
+    L, M, Cn, a = 25, 5, 21, 2
+    n = L + M
+    descs = [(0, l, 0, 0.0, 0.0, 0, 0) for l in range(M, n)]
+    x = a % Cn
+    for l in range(M, n):
+        descs.append((2, l, 0, 0.0, 0.0, Cn, x)); x = (x * x) % Cn
+    descs += iqft_descs(qc, n, M)
+    actions, recs, nrec = qc.fusion_plan(n, M, descs)
+    assert len(descs) == 375 and all(a.fused for a in actions) and sum(a.ngates for a in actions) == 375
+    assert len(actions) <= 8
+    camruns = [recs[a.rec_off + k] for a in actions for k in range(a.nops) if (recs[a.rec_off + k].type & 0xFF) == emu.FUSE_CAMRUN]
+    assert len(camruns) == 1 and (camruns[0].a & 0xFFFF) == 25
+
+
+def test_single_gates_and_oversized_multiplies_stay_stand_alone(qc, tune_guard):
+    n, M = 13, 4
+    c, s = qc.polar(0.3)
+    descs = [(0, 5, 0, 0.0, 0.0, 0, 0)]
+    actions, _, _ = qc.fusion_plan(n, M, descs)
+    assert len(actions) == 1 and not actions[0].fused                    # alone: its tuned kernel
+    # C > 2^M (the reference's undersized-M case, table form) never joins a pass
+    descs = [(0, 5, 0, 0.0, 0.0, 0, 0), (1, 0, 0b110000, c, s, 0, 0), (2, 6, 0, 0.0, 0.0, 21, 2), (0, 7, 0, 0.0, 0.0, 0, 0),
+             (1, 0, 0b11, c, s, 0, 0)]
+    actions, _, _ = qc.fusion_plan(n, M, descs)
+    assert [(a.fused, a.first_gate, a.ngates) for a in actions] == [(1, 0, 2), (0, 2, 1), (1, 3, 2)]

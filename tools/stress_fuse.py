@@ -10,7 +10,7 @@ from test_gpu_fusion import random_program, run_both, bits
 bad = []
 for pruns in (1, 0):
     for rounds in (1, 0):
-        qc.tune(fuse_pruns=pruns, fuse_rounds=rounds)
+        qc.tune(fuse_T_phase=10 if pruns else 0, fuse_rounds=rounds)
         for (L, M, Cn) in ((16, 4, 15), (13, 5, 21), (12, 0, 1), (14, 6, 35)):
             for seed in range(12):
                 rs = np.random.RandomState(seed * 7 + L)
@@ -23,7 +23,7 @@ print("failures:", bad)
 if bad:
     pruns, rounds, L, M, seed, _ = bad[0]
     Cn = {4: 15, 5: 21, 0: 1, 6: 35}[M]
-    qc.tune(fuse_pruns=pruns, fuse_rounds=rounds)
+    qc.tune(fuse_T_phase=10 if pruns else 0, fuse_rounds=rounds)
     rs = np.random.RandomState(seed * 7 + L)
     prog = random_program(rs, L + M, M, Cn, 90)
     # bisect the program length

@@ -7,7 +7,8 @@
  * -Q turns on the reference's 32-bit INT_POW behaviour for differential runs, -j prints a one-line
  * JSON performance summary.  The circuit (qcx_quantum_computation) runs as fused passes by default; -G forces one kernel
  * launch per gate (qcx_set_fusion(reg, -1)), -F queues every gate call (qcx_set_fusion(reg, 1)); the results are the same
- * bits in all three modes.  Exit code = the reference's ErrorCode (Q:164-170, Q:1340-1347).
+ * bits in all three modes.  -o file writes the register's state after the LAST period-finding attempt (post-measurement,
+ * i.e. collapsed) and -O file the state right after the last circuit, before measuring (qcx_state_save).  Exit code = the reference's ErrorCode (Q:164-170, Q:1340-1347).
  *
  * The quantum part (reset, circuit, measurement) runs on the GPU through include/qcx.h; everything
  * here is host-side control flow written from scratch after the behaviour of find_period
@@ -31,6 +32,7 @@ typedef struct {
     int L, M;
     unsigned long seed;
     bool seed_given, ref_quirks, json, fusion, per_gate;
+    const char *dump_final, *dump_circuit;
 } Options;
 
 typedef struct {
@@ -39,7 +41,7 @@ typedef struct {
 } Stats;
 
 static const char *USAGE =
-    "Usage: qcx_shor -C num -L L_reg_size -M M_reg_size [-a trial_int | -f trial_int] [-v] [-V] [-s seed] [-Q] [-j] [-F | -G]\n";
+    "Usage: qcx_shor -C num -L L_reg_size -M M_reg_size [-a trial_int | -f trial_int] [-v] [-V] [-s seed] [-Q] [-j] [-F | -G] [-o state_file] [-O state_file]\n";
 
 static double now_seconds(void)
 {
@@ -53,7 +55,7 @@ static int parse_args(int argc, char **argv, Options *o)
     bool haveC = false, haveL = false, haveM = false;
     int ch;
     memset(o, 0, sizeof *o);
-    while ((ch = getopt(argc, argv, "C:L:M:a:f:s:vVQjFG")) != -1) {
+    while ((ch = getopt(argc, argv, "C:L:M:a:f:s:o:O:vVQjFG")) != -1) {
         switch (ch) {
         case 'C': o->C = (unsigned)atoi(optarg); haveC = true; break;
         case 'L': o->L = atoi(optarg); haveL = true; break;
@@ -66,6 +68,8 @@ static int parse_args(int argc, char **argv, Options *o)
         case 'j': o->json = true; break;
         case 'F': o->fusion = true; break;
         case 'G': o->per_gate = true; break;
+        case 'o': o->dump_final = optarg; break;
+        case 'O': o->dump_circuit = optarg; break;
         default: fputs(USAGE, stdout); return QCX_BAD_ARGUMENTS;
         }
     }
@@ -109,6 +113,7 @@ static int find_period(unsigned *period, unsigned C, unsigned a, qcx_register *r
     if ((s = qcx_quantum_computation(C, a, o->ref_quirks ? 1 : 0, reg)) != QCX_NO_ERROR) return s;
     st->gates += 3UL * (unsigned long)o->L + (unsigned long)o->L * (unsigned long)(o->L - 1) / 2;
     st->attempts++;
+    if (o->dump_circuit && (s = qcx_state_save(reg, o->dump_circuit)) != QCX_NO_ERROR) return s;
     if (very_verbose) printf("      - Measuring state...\n");
     if ((s = qcx_measure_state(reg, rng, &state)) != QCX_NO_ERROR) return s;
     const double omega = qcx_read_omega(state, o->L, o->M);
@@ -199,6 +204,10 @@ int main(int argc, char **argv)
     const double dt = now_seconds() - t0;
     if (verbose) printf(" --- Time to run Shor's Algorithm: %.6fs.\n", dt);
 
+    if (o.dump_final) {
+        const int sd = qcx_state_save(reg, o.dump_final);
+        if (sd != QCX_NO_ERROR) fprintf(stderr, "Error: could not write %s: %s.\n", o.dump_final, qcx_last_error());
+    }
     if (o.json) {
         const double dim = (double)qcx_num_states(reg);
         printf("{\"C\": %u, \"L\": %d, \"M\": %d, \"qubits\": %d, \"attempts\": %lu, \"gates\": %lu, \"seconds\": %.6f, "

@@ -55,6 +55,7 @@ typedef struct qcx_rng      qcx_rng;        /* replaces gsl_rng (mt19937), Q:129
 
 const char *qcx_version(void);
 const char *qcx_status_string(int status);
+const char *qcx_last_error(void);      /* detail of the calling thread's last failure (HIP error string, file name ...) */
 int  qcx_device_count(int *count);
 int  qcx_set_device(int device);
 
@@ -110,6 +111,11 @@ int  qcx_measure_state_r(qcx_register *reg, double r, unsigned long *state_num);
 int  qcx_state_read(qcx_register *reg, unsigned long first, unsigned long count, double *out_re_im);
 int  qcx_state_write(qcx_register *reg, unsigned long first, unsigned long count, const double *in_re_im);
 int  qcx_norm2(qcx_register *reg, double *total_probability);                      /* T:28-37 */
+/* State files (golden vectors, debugging, checkpoint): a 64-byte header ("QCXSTATE", version,
+ * L, M, 2^n, FNV-1a 64 checksum) followed by the amplitudes as interleaved little-endian binary64 (re, im).  Streamed
+ * in 64 MiB pieces.  Load requires a register of the same L and M and verifies the checksum. */
+int  qcx_state_save(qcx_register *reg, const char *path);
+int  qcx_state_load(qcx_register *reg, const char *path);
 void *qcx_device_pointer(qcx_register *reg);      /* the amplitude buffer in HBM (for interop) */
 /* synthetic input for benches and full-size tests: component k (k = 2*index + {0 re, 1 im}) is
  * ((splitmix64(seed + k) >> 11) * 2^-53 - 0.5) * sqrt(6 / 2^n); generated on the device */

@@ -28,6 +28,7 @@ _u64, _i64 = C.c_uint64, C.c_int64
 SIGNATURES = {
     "qcx_version": (C.c_char_p, []),
     "qcx_status_string": (C.c_char_p, [_i]),
+    "qcx_last_error": (C.c_char_p, []),
     "qcx_device_count": (_i, [C.POINTER(_i)]),
     "qcx_set_device": (_i, [_i]),
     "qcx_register_create": (_i, [_i, _i, C.POINTER(_p)]),
@@ -75,13 +76,14 @@ SIGNATURES = {
     "qcx_shard_swap_bits": (_i, [_p, _p, _u, _u, C.POINTER(_u), C.POINTER(_u), _p]),
     "qcx_shard_norm2": (_i, [_p, _u, C.POINTER(_d), _p]),
     "qcx_shard_run_fused": (_i, [_p, _u, _u, _u, _p, _p]),
+    "qcx_state_save": (_i, [_p, C.c_char_p]),
+    "qcx_state_load": (_i, [_p, C.c_char_p]),
     "qcx_fusion_plan": (_i, [_u, _u, _u, _p, _p, _u, C.POINTER(_u), _p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "qcx_shard_measure_scan": (_i, [_p, _u, _u64, _u64, _d, _d, C.POINTER(_i), C.POINTER(_u64), C.POINTER(_d), _p]),
     "qcx_shard_collapse": (_i, [_p, _u, _i64, _p]),
 }
 # not in the public header: diagnostics / tuning hooks
 _EXTRA = {
-    "qcx_last_error": (C.c_char_p, []),
     "qcx_tune_set": (_i, [C.c_char_p, C.c_long]),
     "qcx_tune_get": (C.c_long, [C.c_char_p]),
     "qcx_measure_last_stats": (_i, [C.POINTER(_u), C.POINTER(_u)]),

@@ -32,6 +32,8 @@ static thread_local char g_last_error[256] = "";
         }                                                                                      \
     } while (0)
 
+#define set_error(...) snprintf(g_last_error, sizeof g_last_error, __VA_ARGS__)
+
 #define QCX_TRY(expr)                     \
     do {                                  \
         int s_ = (expr);                  \
@@ -1022,6 +1024,94 @@ extern "C" int qcx_state_write(qcx_register *r, unsigned long first, unsigned lo
     HIP_TRY(hipStreamSynchronize(r->stream));
     if (count) HIP_TRY(hipMemcpy(r->amp + first, in, (size_t)count * sizeof(amp_t), hipMemcpyHostToDevice));
     return QCX_NO_ERROR;
+}
+
+// ---- state files (golden-vector I/O, debugging, checkpoint) -------------------------------
+// 64-byte header, then the 2^n amplitudes as interleaved little-endian binary64 (re, im), index order.  Streamed
+// through a pinned staging buffer, so a 16 GiB state needs 64 MiB of host memory.  The checksum is FNV-1a 64 over the
+// payload bytes.  The payload goes straight to the device chunk by chunk, so a load that fails half-way (truncated
+// file, checksum mismatch) leaves a partial copy in the register and says so (QCX_UNKNOWN_ERROR + qcx_last_error).
+struct StateFileHeader {
+    char     magic[8];          // "QCXSTATE"
+    uint32_t version;           // 1
+    uint32_t bytes_per_amp;     // 16
+    int32_t  L, M;
+    uint64_t dim;               // 2^(L+M)
+    uint64_t checksum;          // FNV-1a 64 of the payload
+    uint8_t  pad[24];
+};
+static_assert(sizeof(StateFileHeader) == 64, "state file header");
+
+static uint64_t fnv1a64(const unsigned char *p, size_t len, uint64_t h)
+{
+    for (size_t k = 0; k < len; k++) { h ^= p[k]; h *= 0x100000001b3ull; }
+    return h;
+}
+
+extern "C" int qcx_state_save(qcx_register *r, const char *path)
+{
+    if (!r || !path) return QCX_BAD_ARGUMENTS;
+    FLUSH(r);
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    FILE *f = fopen(path, "wb");
+    if (!f) { set_error("qcx_state_save: cannot open %s", path); return QCX_BAD_ARGUMENTS; }
+    StateFileHeader h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, "QCXSTATE", 8); h.version = 1; h.bytes_per_amp = (uint32_t)sizeof(amp_t);
+    h.L = r->L; h.M = r->M; h.dim = r->dim;
+    int st = QCX_NO_ERROR;
+    void *stage = nullptr;
+    const size_t chunk = (size_t)std::min<uint64_t>(r->dim, (uint64_t)1 << 22);          // 4 Mi amplitudes = 64 MiB
+    if (hipHostMalloc(&stage, chunk * sizeof(amp_t)) != hipSuccess) { fclose(f); return QCX_INSUFFICIENT_MEMORY; }
+    uint64_t sum = 0xcbf29ce484222325ull;
+    if (fwrite(&h, sizeof h, 1, f) != 1) st = QCX_UNKNOWN_ERROR;
+    for (uint64_t at = 0; st == QCX_NO_ERROR && at < r->dim; at += chunk) {
+        const size_t cnt = (size_t)std::min<uint64_t>(chunk, r->dim - at);
+        if (hipMemcpy(stage, r->amp + at, cnt * sizeof(amp_t), hipMemcpyDeviceToHost) != hipSuccess) { st = QCX_HIP_ERROR; break; }
+        sum = fnv1a64((const unsigned char *)stage, cnt * sizeof(amp_t), sum);
+        if (fwrite(stage, sizeof(amp_t), cnt, f) != cnt) st = QCX_UNKNOWN_ERROR;
+    }
+    if (st == QCX_NO_ERROR) {
+        h.checksum = sum;
+        if (fseek(f, 0, SEEK_SET) != 0 || fwrite(&h, sizeof h, 1, f) != 1) st = QCX_UNKNOWN_ERROR;
+    }
+    (void)hipHostFree(stage);
+    if (fclose(f) != 0 && st == QCX_NO_ERROR) st = QCX_UNKNOWN_ERROR;
+    if (st != QCX_NO_ERROR) set_error("qcx_state_save: writing %s failed", path);
+    return st;
+}
+
+extern "C" int qcx_state_load(qcx_register *r, const char *path)
+{
+    if (!r || !path) return QCX_BAD_ARGUMENTS;
+    FLUSH(r);
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    FILE *f = fopen(path, "rb");
+    if (!f) { set_error("qcx_state_load: cannot open %s", path); return QCX_BAD_ARGUMENTS; }
+    StateFileHeader h;
+    if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "QCXSTATE", 8) != 0 || h.version != 1 || h.bytes_per_amp != sizeof(amp_t)) {
+        fclose(f); set_error("qcx_state_load: %s is not a state file of this version", path); return QCX_BAD_ARGUMENTS;
+    }
+    if (h.L != r->L || h.M != r->M || h.dim != r->dim) {
+        fclose(f); set_error("qcx_state_load: %s holds L=%d M=%d, the register is L=%d M=%d", path, h.L, h.M, r->L, r->M);
+        return QCX_BAD_ARGUMENTS;
+    }
+    void *stage = nullptr;
+    const size_t chunk = (size_t)std::min<uint64_t>(r->dim, (uint64_t)1 << 22);
+    if (hipHostMalloc(&stage, chunk * sizeof(amp_t)) != hipSuccess) { fclose(f); return QCX_INSUFFICIENT_MEMORY; }
+    int st = QCX_NO_ERROR;
+    uint64_t sum = 0xcbf29ce484222325ull;
+    for (uint64_t at = 0; st == QCX_NO_ERROR && at < r->dim; at += chunk) {
+        const size_t cnt = (size_t)std::min<uint64_t>(chunk, r->dim - at);
+        if (fread(stage, sizeof(amp_t), cnt, f) != cnt) { st = QCX_UNKNOWN_ERROR; break; }
+        sum = fnv1a64((const unsigned char *)stage, cnt * sizeof(amp_t), sum);
+        if (hipMemcpy(r->amp + at, stage, cnt * sizeof(amp_t), hipMemcpyHostToDevice) != hipSuccess) st = QCX_HIP_ERROR;
+    }
+    (void)hipHostFree(stage);
+    fclose(f);
+    if (st == QCX_NO_ERROR && sum != h.checksum) st = QCX_UNKNOWN_ERROR;
+    if (st != QCX_NO_ERROR) set_error("qcx_state_load: %s is truncated or corrupt (the register now holds a partial copy)", path);
+    return st;
 }
 
 extern "C" int qcx_norm2(qcx_register *r, double *out)

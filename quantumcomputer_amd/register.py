@@ -104,6 +104,13 @@ class Register:
             raise ValueError("amplitudes are (re, im) pairs")
         check(lib().qcx_state_write(self._h, first, a.size // 2, a.ctypes.data_as(C.c_void_p)), "qcx_state_write")
 
+    def save(self, path):
+        """state file: 64-byte header + interleaved binary64 amplitudes (qcx_state_save); see load_state_file()"""
+        check(lib().qcx_state_save(self._h, str(path).encode()), "qcx_state_save")
+
+    def load(self, path):
+        check(lib().qcx_state_load(self._h, str(path).encode()), "qcx_state_load")
+
     def fill_random(self, seed):
         """synthetic dense state generated on the device (include/qcx.h: qcx_state_fill_random)"""
         check(lib().qcx_state_fill_random(self._h, int(seed)), "qcx_state_fill_random")
@@ -229,3 +236,15 @@ def check_normalisation(reg, file=None):
     total = reg.norm2()
     print("Total Probability: %.16f" % total, file=file or sys.stdout)
     return total
+
+
+def load_state_file(path):
+    """Read a state file written by Register.save / qcx_state_save on the host: returns (L, M, amplitudes as an
+    interleaved float64 array, memory-mapped).  Verifies magic and version; the checksum is checked by Register.load."""
+    import struct
+    with open(path, "rb") as f:
+        hdr = f.read(64)
+    magic, version, bpa, L, M, dim, checksum = struct.unpack("<8sIIiiQQ", hdr[:40])
+    if magic != b"QCXSTATE" or version != 1 or bpa != 16 or dim != 1 << (L + M):
+        raise ValueError(f"{path}: not a qcx state file")
+    return L, M, np.memmap(path, dtype="<f8", mode="r", offset=64, shape=(2 * dim,))

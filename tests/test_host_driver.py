@@ -5,6 +5,8 @@ import ctypes as C
 import os
 import subprocess
 
+import numpy as np
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -129,3 +131,16 @@ def test_cli_measures_the_same_state_in_every_fusion_mode(hostlib):
         assert r.returncode in (0, 3), r.stdout + r.stderr
         outs.append([l.split("omega")[0] for l in r.stdout.splitlines() if "Measured state" in l])
     assert outs[0] and outs[0] == outs[1] == outs[2], outs
+
+
+@pytest.mark.gpu
+def test_cli_state_dumps(hostlib, tmp_path, qc):
+    """-O: the state right after the circuit (normalised superposition); -o: after the measurement (one basis state)"""
+    pre, post = tmp_path / "pre.qcx", tmp_path / "post.qcx"
+    r = run_cli("-C", "15", "-L", "6", "-M", "4", "-a", "7", "-s", "3", "-V", "-O", str(pre), "-o", str(post))
+    assert r.returncode in (0, 3), r.stdout + r.stderr
+    L, M, a = qc.load_state_file(pre)
+    assert (L, M) == (6, 4) and abs(float(np.sum(np.square(a))) - 1.0) < 1e-12 and np.count_nonzero(a) > 2
+    L, M, b = qc.load_state_file(post)
+    measured = [int(l.split("Measured state")[1].split(",")[0]) for l in r.stdout.splitlines() if "Measured state" in l][-1]
+    assert np.count_nonzero(b) == 1 and b[2 * measured] == 1.0

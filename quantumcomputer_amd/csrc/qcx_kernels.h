@@ -613,8 +613,8 @@ __global__ __launch_bounds__(64) void k_meas_chain(const amp_t *__restrict__ amp
 // HBM round trip for the lot.  Every gate performs exactly the arithmetic of its stand-alone
 // kernel, in the order the gates were issued, so results are bit-identical to the unfused path:
 //   H on a tile bit           butterfly between LDS slots (same t0 +/- t1 + 0.0 form)
-//   controlled phase          any control/target: a bit outside the tile is a per-tile constant;
-//                             runs of consecutive phases are applied per amplitude in registers
+//   controlled phase          any control/target: a bit outside the tile is a per-tile constant (the gate
+//                             is skipped or applies to the whole tile); consecutive phases stay in registers
 //   controlled modular mult.  when the M register is inside the tile (closed form of k_camodc)
 // ---------------------------------------------------------------------------
 enum : uint32_t { FUSE_H = 0, FUSE_PHASE = 1, FUSE_CAMODC = 2 };
@@ -757,8 +757,14 @@ __device__ __forceinline__ void fuse_apply_ops(amp_t *tile, unsigned short *lut,
 //   H on a register bit   = butterflies between registers (two H's per LDS round trip: radix 4);
 //   controlled phase      = rotate the registers the host selected (rsel: which of the 4 have the mask's
 //                           register bits set), after ONE test of the remaining local bits per thread and one
-//                           scalar test of the bits outside the tile per tile.
-// Same arithmetic, same order per amplitude as the per-gate kernels.
+//                           test of the bits outside the tile per tile.
+// Same arithmetic, same order per amplitude as the per-gate kernels.  Records of a round (32 B each):
+//   FUSE_ROUND   a = rb0 | rb1 << 8 | (round contains an H) << 16,  mask = records that follow (items + gates)
+//   item H       type = FUSE_H    | (32 | which register bit) << 8
+//   item run     type = FUSE_PRUN | (rsel | (canonicalise at the end of the run) << 4) << 8 | gates << 16  (1..64 gates)
+//   gate of run  type = FUSE_PHASE | rsel << 8,  a = tile-local mask without the register bits,
+//                mask = index bits outside the tile,  c, s = cos, sin
+// Between rounds: FUSE_CAMRUN (folded modular multiplies) and FUSE_CAMODC (a single one) with their own layouts.
 enum : uint32_t { FUSE_ROUND = 3, FUSE_CAMRUN = 5 };
 
 __device__ __forceinline__ void rotate_amp(amp_t &v, double cc, double ss)
@@ -769,20 +775,21 @@ __device__ __forceinline__ void rotate_amp(amp_t &v, double cc, double ss)
     v = w;
 }
 
-// A run of consecutive controlled phases that rotate the same registers (RSEL).
-//  * Which gates of the run act on this TILE (their controls outside the tile are all 1) is found 64 gates at a
-//    time: lane l tests gate l, one ballot gives the live set, and only live gates are walked.  A skipped gate
-//    costs nothing.
-//  * The walk is hand-scheduled (phase_chunk): measured, the compiler's version of this loop is bound by the
-//    scalar-ALU issue port (about 20 s_* instructions per gate for mask iteration, record address, select and
-//    EXEC bookkeeping), not by the FP64 work.  Here a gate costs ~9 scalar instructions: find/clear its bit, three
-//    scalar loads of its record (the next gate's record is in flight while the current one is applied), a
-//    v_cmpx that masks the lanes whose tile-local control bits are not all set, and the EXEC restore.
+// A run of consecutive controlled phases that rotate the same registers (rsel).
+//  * Which gates of the run act on this TILE (their controls outside the tile are all 1): lane l tests gate l
+//    against the tile's base index, one ballot gives the live set, and only live gates are walked.  A skipped
+//    gate costs nothing.
+//  * The walk is hand-scheduled: measured, the compiler's version of this loop is bound by the scalar-ALU issue
+//    port (about 20 s_* instructions per gate for mask iteration, record address, select and EXEC bookkeeping),
+//    not by the FP64 work.  Here a gate costs ~9 scalar instructions: find/clear its bit, three scalar loads of
+//    its record (the next gate's record is in flight while the current one is applied), a v_cmpx that masks the
+//    lanes whose tile-local control bits are not all set, and the EXEC restore.
 //  * A rotation is the same four products and two sums as rotate_amp, in place, without FMA.
 //  * The reference's result of every rotation is canonical (its "0 + ..." turns -0 into +0).  The sign of a zero
 //    never changes a later non-zero result and every zero result is canonicalised anyway, so the "+ 0.0" is
-//    applied ONCE at the end of the run, to the lanes that were rotated at least once (tch collects their EXEC
-//    masks); untouched lanes keep their bits.  Same values, bit for bit, as rotate_amp per gate.
+//    applied ONCE: at the end of a round that contains an H (an H touches every amplitude), otherwise at the end of
+//    the run to the lanes that were rotated at least once (tch collects their EXEC masks); untouched lanes keep
+//    their bits.  Same values, bit for bit, as rotate_amp per gate.
 enum : uint32_t { FUSE_PRUN = 4 };
 
 #define QCX_LOADREC(M, C, S)                                         \

@@ -94,7 +94,7 @@ struct Tune {
     long cam_grid_cap = 4096;
     long fuse_T      = 11;     // fused passes: tile = 2^T amplitudes in LDS (8..12)
     long fuse_c      = 4;      // fused passes: contiguous low bits of a tile (runs of 16 * 2^c bytes)
-    long fuse_grid_cap = 0;
+    long fuse_grid_cap = 24576; // workgroups of the one-tile-per-workgroup form (each walks several tiles: the table fill at kernel start is amortised)
     long fuse_pipe   = 1;      // fused passes: persistent double-buffered form (fill of tile i+1 under tile i)
     long fuse_pipe_grid = 1024; // workgroups of the persistent form
     long fuse_T_phase = 10;    // tile bits of phase-dominated passes (one tile per workgroup, not pipelined); 0 = same as the rest

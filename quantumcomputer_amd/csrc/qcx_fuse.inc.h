@@ -193,6 +193,22 @@ static void to_rounds(const std::vector<FuseOp> &legacy, unsigned T, std::vector
     close_round();
 }
 
+// the rounds-only kernel, built for 6, 7 or 8 waves per SIMD; false when the geometry has no rounds form
+template <int B, int TT>
+static bool launch_rounds_kernel(int occ, unsigned grid, size_t lds, hipStream_t st, amp_t *amp, unsigned n, const FusePass &P,
+                                 const FuseOp *d_ops, uint64_t ntiles)
+{
+    if constexpr ((1u << TT) == 4u * B) {
+        if (occ >= 8) hipLaunchKernelGGL((k_fused_rounds<B, TT, 8>), dim3(grid), dim3(B), lds, st, amp, n, P, d_ops, ntiles, d_ops);
+        else if (occ == 7) hipLaunchKernelGGL((k_fused_rounds<B, TT, 7>), dim3(grid), dim3(B), lds, st, amp, n, P, d_ops, ntiles, d_ops);
+        else hipLaunchKernelGGL((k_fused_rounds<B, TT, 6>), dim3(grid), dim3(B), lds, st, amp, n, P, d_ops, ntiles, d_ops);
+        return true;
+    } else {
+        (void)occ; (void)grid; (void)lds; (void)st; (void)amp; (void)n; (void)P; (void)d_ops; (void)ntiles;
+        return false;
+    }
+}
+
 static int launch_pass(qcx_register *r, const FusePass &P_in, const FuseOp *d_ops, bool nopipe)
 {
     FusePass P = P_in;
@@ -212,6 +228,7 @@ static int launch_pass(qcx_register *r, const FusePass &P_in, const FuseOp *d_op
         if (g_tune.fuse_pipe && !nopipe && ntiles >= 4096) { \
             const unsigned pg = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)g_tune.fuse_pipe_grid); \
             hipLaunchKernelGGL((k_fused_pipe<B, TTv>), dim3(pg), dim3(B), 2 * ((size_t)16 << P.T) + lut_bytes, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); \
+        } else if (P.cam_ctl_local[0] && g_tune.fuse_ldsdma && g_tune.fuse_rounds_occ >= 6 && launch_rounds_kernel<B, TTv>((int)g_tune.fuse_rounds_occ, grid, lds, r->stream, r->amp, n, P, d_ops, ntiles)) { \
         } else if (g_tune.fuse_ldsdma) hipLaunchKernelGGL((k_fused<B, TTv, true>), dim3(grid), dim3(B), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); \
         else hipLaunchKernelGGL((k_fused<B, TTv, false>), dim3(grid), dim3(B), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); } while (0)
     switch (P.T) {

@@ -1071,7 +1071,7 @@ __device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, unsigned short *l
 }
 
 template <int BLOCK, int TT, bool LDSDMA>   // TT = tile bits when known at compile time (loops unroll, loads batch); 0 = generic
-__global__ __launch_bounds__(BLOCK, 1536 / BLOCK) void k_fused(amp_t *__restrict__ amp, unsigned n, FusePass P,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void k_fused(amp_t *__restrict__ amp, unsigned n, FusePass P,
                                                    const FuseOp *__restrict__ ops, uint64_t ntiles, const FuseOp *ops_asm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char qcx_lds_raw[];
@@ -1141,6 +1141,59 @@ __global__ __launch_bounds__(BLOCK, 1536 / BLOCK) void k_fused(amp_t *__restrict
             for (unsigned k = 0; k < EPT; k++)
                 if (k < ept && k * BLOCK + threadIdx.x < tsize) __builtin_nontemporal_store(v[k], g + off_k[k]);
         }
+        __syncthreads();
+    }
+}
+
+// The ROUNDS form on its own: the kernel the scheduler launches for every pass in rounds form (4 amplitudes per
+// thread: BLOCK = 2^TT / 4).  One tile per workgroup at a time, LDS-DMA fill, a grid of a few workgroups per CU
+// slot that walk the tiles (the table fill below is paid once per workgroup, not once per tile).  Load / process /
+// store phases of the resident workgroups overlap each other; measured, that beats the double-buffered pipeline
+// inside one workgroup (k_fused_pipe) as soon as enough workgroups are resident, so this kernel carries nothing but
+// the rounds interpreter and is held to OCC waves per SIMD.
+template <int BLOCK, int TT, int OCC>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) void k_fused_rounds(
+    amp_t *__restrict__ amp, unsigned n, FusePass P, const FuseOp *__restrict__ ops, uint64_t ntiles, const FuseOp *ops_asm)
+{
+    static_assert((1u << TT) == 4u * BLOCK, "rounds form: 4 amplitudes per thread");
+    extern __shared__ __attribute__((aligned(16))) unsigned char qcx_lds_raw[];
+    amp_t *tile = reinterpret_cast<amp_t *>(qcx_lds_raw);
+    constexpr unsigned tsize = 1u << TT;
+    unsigned short *lut = reinterpret_cast<unsigned short *>(tile + tsize);
+    unsigned char *camtab = reinterpret_cast<unsigned char *>(lut) + P.cam_ctl_local[3];
+    for (unsigned b = threadIdx.x; b < (unsigned)P.cam_ctl_local[1]; b += BLOCK)
+        camtab[b] = reinterpret_cast<const unsigned char *>(ops + P.cam_ctl_local[2])[b];
+    uint64_t *xm = reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(lut) + P.xm_off);
+    for (unsigned b = threadIdx.x; b < P.xm_cnt + 66u; b += BLOCK) xm[b] = b < P.xm_cnt ? ops[b].mask : 0;    // + padding
+    __syncthreads();
+    const unsigned c = P.c, nh = P.nh;
+    const unsigned lowmask = (1u << c) - 1u;
+    auto scatter = [&](unsigned e) -> uint64_t {
+        uint64_t off = e & lowmask;
+        for (unsigned j = 0; j < nh; j++) off |= (uint64_t)((e >> (c + j)) & 1u) << P.hbit[j];
+        return off;
+    };
+    const uint64_t off_t = scatter(threadIdx.x);
+    uint64_t off_k[4];
+#pragma unroll
+    for (unsigned k = 0; k < 4; k++) off_k[k] = scatter(k * BLOCK);
+    const unsigned wbase = (threadIdx.x >> 6) * 64;
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        uint64_t base = t << c;
+        for (unsigned j = 0; j < nh; j++) base = insert_zero(base, P.hbit[j]);
+        amp_t *g = amp + (base | off_t);
+#pragma unroll
+        for (unsigned k = 0; k < 4; k++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + off_k[k]),
+                                             (__attribute__((address_space(3))) void *)(tile + k * BLOCK + wbase), 16, 0, 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        fuse_apply_rounds<BLOCK, TT>(tile, lut, camtab, xm, P, ops, ops_asm, base);
+        amp_t v[4];
+#pragma unroll
+        for (unsigned k = 0; k < 4; k++) v[k] = tile[k * BLOCK + threadIdx.x];
+#pragma unroll
+        for (unsigned k = 0; k < 4; k++) __builtin_nontemporal_store(v[k], g + off_k[k]);
         __syncthreads();
     }
 }

@@ -97,7 +97,7 @@ struct Tune {
     long fuse_grid_cap = 24576; // workgroups of the one-tile-per-workgroup form (each walks several tiles: the table fill at kernel start is amortised)
     long fuse_pipe   = 0;      // 1: persistent double-buffered form (fill of tile i+1 under tile i) instead of several resident one-tile workgroups
     long fuse_pipe_grid = 1024; // workgroups of the persistent form
-    long fuse_rounds_occ = 6;  // rounds-form passes: k_fused_rounds built for this many waves per SIMD (6, 7, 8; 0 = the general kernel)
+    long fuse_rounds_occ = 8;  // rounds-form passes: k_fused_rounds built for this many waves per SIMD (6, 7, 8; 0 = the general kernel)
     long fuse_T_phase = 10;    // tile bits of phase-dominated passes (one tile per workgroup, not pipelined); 0 = same as the rest
     long fuse_c_phase = 4;
     long fuse_phase_ratio = 6; // a pass is phase-dominated when it holds at least this many phases per H (and nothing else)

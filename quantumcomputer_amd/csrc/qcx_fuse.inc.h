@@ -199,9 +199,12 @@ static bool launch_rounds_kernel(int occ, unsigned grid, size_t lds, hipStream_t
                                  const FuseOp *d_ops, uint64_t ntiles)
 {
     if constexpr ((1u << TT) == 4u * B) {
-        if (occ >= 8) hipLaunchKernelGGL((k_fused_rounds<B, TT, 8>), dim3(grid), dim3(B), lds, st, amp, n, P, d_ops, ntiles, d_ops);
-        else if (occ == 7) hipLaunchKernelGGL((k_fused_rounds<B, TT, 7>), dim3(grid), dim3(B), lds, st, amp, n, P, d_ops, ntiles, d_ops);
-        else hipLaunchKernelGGL((k_fused_rounds<B, TT, 6>), dim3(grid), dim3(B), lds, st, amp, n, P, d_ops, ntiles, d_ops);
+        const bool cam = P.has_cam != 0;
+#define QCX_ROUNDS_LAUNCH(O, C) hipLaunchKernelGGL((k_fused_rounds<B, TT, O, C>), dim3(grid), dim3(B), lds, st, amp, n, P, d_ops, ntiles, d_ops)
+        if (occ >= 8) { if (cam) QCX_ROUNDS_LAUNCH(8, true); else QCX_ROUNDS_LAUNCH(8, false); }
+        else if (occ == 7) { if (cam) QCX_ROUNDS_LAUNCH(7, true); else QCX_ROUNDS_LAUNCH(7, false); }
+        else { if (cam) QCX_ROUNDS_LAUNCH(6, true); else QCX_ROUNDS_LAUNCH(6, false); }
+#undef QCX_ROUNDS_LAUNCH
         return true;
     } else {
         (void)occ; (void)grid; (void)lds; (void)st; (void)amp; (void)n; (void)P; (void)d_ops; (void)ntiles;
@@ -302,6 +305,7 @@ static void fuse_plan(const qcx_register *r, const std::vector<QGate> &gates, st
 
         act.fused = 1;
         act.ngates = i - first; act.first_gate = first;
+        act.P.has_cam = n_other ? 1u : 0u;
         act.P.c = c; act.P.nh = (uint32_t)hbits.size(); act.P.T = c + act.P.nh;
         act.P.cam_ctl_local[3] = (int32_t)(((size_t)2 << std::min(12u, (unsigned)r->M)) + 16);   // table area sits behind the lut
         for (unsigned j = 0; j < act.P.nh; j++) act.P.hbit[j] = (uint8_t)hbits[j];

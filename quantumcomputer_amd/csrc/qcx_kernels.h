@@ -634,6 +634,7 @@ struct FusePass {
                                 // [3]: byte offset of the table area behind the lut in LDS
     uint8_t  hbit[16];          // global bit carried by tile-local bit c + j, ascending
     uint32_t xm_off, xm_cnt;    // LDS copy of the records' outside-tile masks: byte offset behind the lut, entries (0 = none)
+    uint32_t has_cam, pad_;     // the pass holds modular multiplies (selects the kernel variant)
 };
 
 // One controlled modular multiply on an LDS-resident tile whose low M local bits are the M register.
@@ -973,7 +974,7 @@ __device__ __forceinline__ void fuse_round_item(Quad &q, const FuseOp *item, uin
         : [base] "s"(item), [p] "v"(p), [rsel] "s"(hdr), [hs] "s"(hs) : "vcc", "scc");
 }
 
-template <int BLOCK, int TT>
+template <int BLOCK, int TT, bool CAM = true>     // CAM = false: the pass holds no modular multiply (smaller kernel)
 __device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, unsigned short *lut, const unsigned char *camtab,
                                                   const uint64_t *xm, const FusePass &P, const FuseOp *__restrict__ ops,
                                                   const FuseOp *ops_asm, uint64_t base)
@@ -1022,7 +1023,7 @@ __device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, unsigned short *l
               tile[p] = v0; tile[e1] = v1; tile[e2] = v2; tile[e3] = v3; }
             __syncthreads();
             i += 1 + cnt;
-        } else if (type == FUSE_CAMRUN) {
+        } else if (CAM && type == FUSE_CAMRUN) {
             // a run of consecutive permutation-type modular multiplies (gcd(A, C) = 1, same C) folded into ONE
             // gather: inside a 2^M block all amplitudes share the L-register bits, so the run moves the amplitude
             // of value g from  f0 = (prod of the inverses whose control is set) * g  mod C.  The product is
@@ -1063,9 +1064,11 @@ __device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, unsigned short *l
                 if (wr[k]) tile[k * BLOCK + threadIdx.x] = acc[k];
             __syncthreads();
             i += 1 + cnt;
-        } else {    // FUSE_CAMODC between rounds
+        } else if (CAM) {    // FUSE_CAMODC between rounds
             fuse_camodc_step<BLOCK, 4>(tile, lut, ops + i, base, 1u << TT);
             i++;
+        } else {
+            __builtin_unreachable();
         }
     }
 }
@@ -1151,7 +1154,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void
 // store phases of the resident workgroups overlap each other; measured, that beats the double-buffered pipeline
 // inside one workgroup (k_fused_pipe) as soon as enough workgroups are resident, so this kernel carries nothing but
 // the rounds interpreter and is held to OCC waves per SIMD.
-template <int BLOCK, int TT, int OCC>
+template <int BLOCK, int TT, int OCC, bool CAM>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) void k_fused_rounds(
     amp_t *__restrict__ amp, unsigned n, FusePass P, const FuseOp *__restrict__ ops, uint64_t ntiles, const FuseOp *ops_asm)
 {
@@ -1188,7 +1191,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
                                              (__attribute__((address_space(3))) void *)(tile + k * BLOCK + wbase), 16, 0, 2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        fuse_apply_rounds<BLOCK, TT>(tile, lut, camtab, xm, P, ops, ops_asm, base);
+        fuse_apply_rounds<BLOCK, TT, CAM>(tile, lut, camtab, xm, P, ops, ops_asm, base);
         amp_t v[4];
 #pragma unroll
         for (unsigned k = 0; k < 4; k++) v[k] = tile[k * BLOCK + threadIdx.x];

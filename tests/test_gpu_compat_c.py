@@ -20,10 +20,15 @@ def exe(tmp_path_factory):
     return out
 
 
-@pytest.mark.parametrize("C,L,M,a", [(15, 3, 4, 7), (21, 5, 5, 2), (15, 8, 4, 7), (33, 5, 5, 7)])
-def test_reference_style_c_program(exe, ob, C, L, M, a):
+@pytest.mark.parametrize("fusion", [None, "-1", "0"], ids=["queued (compat default)", "one launch per gate", "mode 0"])
+@pytest.mark.parametrize("C,L,M,a", [(15, 3, 4, 7), (21, 5, 5, 2), (15, 8, 4, 7), (33, 5, 5, 7), (21, 9, 5, 2)])
+def test_reference_style_c_program(exe, ob, C, L, M, a, fusion):
     n = L + M
-    r = subprocess.run([exe, str(C), str(L), str(M), str(a), "12345"], capture_output=True, text=True, timeout=120)
+    env = dict(os.environ)
+    env.pop("QCX_COMPAT_FUSION", None)
+    if fusion is not None:
+        env["QCX_COMPAT_FUSION"] = fusion
+    r = subprocess.run([exe, str(C), str(L), str(M), str(a), "12345"], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0, r.stderr
     lines = r.stdout.split()
     got = np.array([int(x, 16) for x in lines[:2 << n]], dtype=np.uint64)

@@ -109,6 +109,25 @@ def test_gate_kernels_have_no_fma():
     assert re.search(r"v_add_f64 v\[\d+:\d+\], v\[\d+:\d+\], 0\b", body)
 
 
+def test_fused_rounds_kernel_keeps_its_scalar_record_loads():
+    """Two code-generation facts the fused passes depend on ("Gate fusion"): the record array is read with
+    scalar loads (a vector load would wait for the tile DMA -- this regresses as soon as an asm statement captures the
+    __restrict__ record pointer), and the hand-scheduled item walk is in the kernel (EXEC-masked rotations)."""
+    s_path = os.path.join(ROOT, "quantumcomputer_amd", "libqcx.gfx950.s")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "quantumcomputer_amd", "csrc"), "-s", "isa"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    txt = open(s_path).read()
+    bodies = [txt[m.start():txt.find(".Lfunc_end", m.start())] for m in re.finditer(r"^_ZN3qcx14k_fused_roundsILi512ELi11ELi8E\w*:", txt, re.M)]
+    assert len(bodies) == 2
+    for b in bodies:
+        assert len(re.findall(r"global_load_dword ", b)) == 0 and len(re.findall(r"flat_load", b)) == 0
+        assert b.count("s_load_dword") > 20 and b.count("v_cmpx_eq_u32") >= 15 * 4
+        assert "v_fma_f64" not in b
+        m = re.search(r"; ScratchSize: (\d+)", txt[txt.find(b[:60]) + len(b):])
+        assert m and int(m.group(1)) <= 64          # at most a handful of spilled dwords at 64 VGPRs
+
+
 def test_product_rng_matches_oracle_and_known_answers(qc, ob):
     r = qc.Rng(5489)
     v = [r.get() for _ in range(10000)]

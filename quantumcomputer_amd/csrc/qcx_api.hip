@@ -127,12 +127,14 @@ extern "C" long qcx_tune_get(const char *key)
     return -1;
 }
 
-static inline unsigned grid_for(uint64_t work_items, uint64_t per_block, long cap)
+static inline unsigned grid_for(uint64_t work_items, uint64_t per_block, long cap, unsigned block_threads = 1024)
 {
     uint64_t g = (work_items + per_block - 1) / per_block;
     if (g == 0) g = 1;
     if (cap > 0 && g > (uint64_t)cap) g = (uint64_t)cap;
-    if (g > 0x7fffffffULL) g = 0x7fffffffULL;       // kernels grid-stride, so any cap is valid
+    // kernels grid-stride, so any cap is valid; HIP wants grid * block < 2^32 threads (n = 33, 34 registers get there)
+    const uint64_t hard = std::min<uint64_t>(0x7fffffffULL, 0xffffffffULL / block_threads);
+    if (g > hard) g = hard;
     return (unsigned)g;
 }
 
@@ -209,7 +211,7 @@ extern "C" int qcx_shard_fill_random(void *amp, unsigned n_local, uint64_t first
 {
     if (!amp || n_local > 40) return QCX_BAD_ARGUMENTS;
     const uint64_t count = (uint64_t)1 << n_local;
-    hipLaunchKernelGGL(k_fill_random, dim3(grid_for(count, 256 * 4, 0)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_fill_random, dim3(grid_for(count, 256 * 4, 0, 256)), dim3(256), 0, (hipStream_t)stream,
                        (amp_t *)amp, count, first_global, seed, scale);
     HIP_TRY(hipGetLastError());
     return QCX_NO_ERROR;
@@ -218,7 +220,7 @@ extern "C" int qcx_shard_fill_random(void *amp, unsigned n_local, uint64_t first
 template <int PPT, bool NTL, bool NTS, bool WC, int BLOCK>
 static void launch_h_pair(const Tune &t, amp_t *a, unsigned q, uint64_t npairs, hipStream_t st)
 {
-    const unsigned grid = grid_for(npairs, BLOCK * PPT, t.h_grid_cap);
+    const unsigned grid = grid_for(npairs, BLOCK * PPT, t.h_grid_cap, BLOCK);
     // stream-interleaved tile order only for an uncapped power-of-two grid that divides evenly
     unsigned glog = 0, slog = 0;
     if ((grid & (grid - 1)) == 0 && (uint64_t)grid * (BLOCK * PPT) == npairs) {
@@ -269,11 +271,11 @@ static void launch_h_wave_q(const Tune &t, amp_t *a, uint64_t namps, hipStream_t
     const uint64_t ntiles = namps / (64 * R);
     unsigned glog, slog;
     if (t.h_wave_block == 64) {
-        const unsigned grid = grid_for(ntiles, 1, t.h_grid_cap);
+        const unsigned grid = grid_for(ntiles, 1, t.h_grid_cap, 64);
         stream_map(grid, grid, ntiles, t.h_streams_log2, &glog, &slog);
         hipLaunchKernelGGL((k_h_wave<Q, R, NTL, NTS, 64>), dim3(grid), dim3(64), 0, st, a, ntiles, glog, slog);
     } else {
-        const unsigned grid = grid_for(ntiles, 4 /* waves per 256-thread block */, t.h_grid_cap);
+        const unsigned grid = grid_for(ntiles, 4 /* waves per 256-thread block */, t.h_grid_cap, 256);
         stream_map(grid, (uint64_t)grid * 4, ntiles, t.h_streams_log2, &glog, &slog);
         hipLaunchKernelGGL((k_h_wave<Q, R, NTL, NTS, 256>), dim3(grid), dim3(256), 0, st, a, ntiles, glog, slog);
     }
@@ -371,7 +373,7 @@ extern "C" int qcx_shard_hadamard(void *amp, unsigned n_local, unsigned q, void 
 template <int NB, int APT, bool NT, int BLOCK>
 static void launch_phase_cfg(amp_t *a, unsigned b0, unsigned b1, double c, double s, uint64_t count, hipStream_t st)
 {
-    const unsigned grid = grid_for(count, (uint64_t)BLOCK * APT, g_tune.ph_grid_cap);
+    const unsigned grid = grid_for(count, (uint64_t)BLOCK * APT, g_tune.ph_grid_cap, BLOCK);
     unsigned glog, slog;
     long want = g_tune.ph_streams_log2;
     if (want < 0) want = (NB == 0 || b0 >= 8) ? 1 : 2;
@@ -523,7 +525,7 @@ extern "C" int qcx_shard_swap_bits(const void *src, void *dst, unsigned n_local,
         S.a[m] = pos_a[m]; S.b[m] = pos_b[m];
     }
     const uint64_t count = (uint64_t)1 << n_local;
-    hipLaunchKernelGGL((k_swap_bits<256>), dim3(grid_for(count, 256, 0)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((k_swap_bits<256>), dim3(grid_for(count, 256, 0, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const amp_t *)src, (amp_t *)dst, count, S);
     HIP_TRY(hipGetLastError());
     return QCX_NO_ERROR;

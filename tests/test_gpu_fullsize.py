@@ -41,6 +41,34 @@ def big(qc):
     reg.close()
 
 
+# (first in the module: these tests build their own full-size register, so they must run before the module-wide
+# `big` register exists -- at n = 34 one register is 256 GiB of the 288 GB)
+@pytest.mark.parametrize("M,C,atox,ctl", [(5, 21, 2, 29), (5, 21, 16, 5), (10, 1000, 7, 12), (4, 15, 7, 20), (5, 21, 7, 25)])
+def test_camodc_fullsize_windows_bit_exact(qc, ob, M, C, atox, ctl):
+    n = N_FULL
+    ctl = min(ctl, n - 1)
+    seed = 3000 + ctl
+    rs = np.random.RandomState(seed)
+    with qc.Register(n - M, M) as reg:
+        reg.fill_random(seed)
+        qc.c_amodc_gate(C, atox, ctl, reg)
+        starts = {0, (1 << n) - (1 << W), ((1 << ctl) >> W) << W} | {int(x) << W for x in rs.randint(0, 1 << (n - W), 6)}
+        for s in sorted(starts):
+            a = ob.fill_random(n, seed, s, 1 << W)
+            want = a.copy()
+            if (s >> ctl) & 1 or ctl < W:
+                # the window is a whole number of 2^M blocks: run the oracle gate on it as a W-qubit register
+                # (control inside the window keeps its position; a control above it is set for the whole window,
+                #  emulated by one extra top qubit)
+                if ctl < W:
+                    ob.camodc(want, W, M, C, atox, ctl)
+                else:
+                    ext = np.concatenate([np.zeros_like(a), a])
+                    ob.camodc(ext, W + 1, M, C, atox, W)
+                    want = ext[a.size:]
+            assert np.array_equal(bits(reg.read(s, 1 << W)), bits(want)), f"C_AMODC ctl={ctl} window at {s}"
+
+
 @pytest.mark.parametrize("q", [0, 1, 2, 3, 6, 7, 8, 11, 12, 17, 19, 20, 22, 23, 25, 28, N_FULL - 1])
 def test_hadamard_fullsize_windows_bit_exact(qc, ob, big, q):
     n = N_FULL
@@ -85,32 +113,6 @@ def test_cphase_fullsize_windows_bit_exact(qc, ob, big, c, t):
         a[sel, 0] = 0.0 + ((er * re) - (ei * im))
         a[sel, 1] = 0.0 + ((er * im) + (ei * re))
         assert np.array_equal(bits(big.read(s, 1 << W)), bits(a.reshape(-1))), f"CPHASE({c},{t}) window at {s}"
-
-
-@pytest.mark.parametrize("M,C,atox,ctl", [(5, 21, 2, 29), (5, 21, 16, 5), (10, 1000, 7, 12), (4, 15, 7, 20), (5, 21, 7, 25)])
-def test_camodc_fullsize_windows_bit_exact(qc, ob, M, C, atox, ctl):
-    n = N_FULL
-    ctl = min(ctl, n - 1)
-    seed = 3000 + ctl
-    rs = np.random.RandomState(seed)
-    with qc.Register(n - M, M) as reg:
-        reg.fill_random(seed)
-        qc.c_amodc_gate(C, atox, ctl, reg)
-        starts = {0, (1 << n) - (1 << W), ((1 << ctl) >> W) << W} | {int(x) << W for x in rs.randint(0, 1 << (n - W), 6)}
-        for s in sorted(starts):
-            a = ob.fill_random(n, seed, s, 1 << W)
-            want = a.copy()
-            if (s >> ctl) & 1 or ctl < W:
-                # the window is a whole number of 2^M blocks: run the oracle gate on it as a W-qubit register
-                # (control inside the window keeps its position; a control above it is set for the whole window,
-                #  emulated by one extra top qubit)
-                if ctl < W:
-                    ob.camodc(want, W, M, C, atox, ctl)
-                else:
-                    ext = np.concatenate([np.zeros_like(a), a])
-                    ob.camodc(ext, W + 1, M, C, atox, W)
-                    want = ext[a.size:]
-            assert np.array_equal(bits(reg.read(s, 1 << W)), bits(want)), f"C_AMODC ctl={ctl} window at {s}"
 
 
 def test_sweep_conserves_norm_and_hh_is_identity(qc, ob, big):

@@ -287,8 +287,8 @@ static void fuse_plan(const qcx_register *r, const std::vector<QGate> &gates, st
         unsigned c = c_def, budget = T - c_def;
         grow(c, budget);
         // A pass dominated by controlled phases is bound by FP64 issue and latency, not by HBM: it runs better on
-        // smaller tiles with one tile per workgroup (more resident waves, smaller barrier domains) than on the
-        // pipelined kernel, at the price of fewer hot bits per pass.
+        // smaller tiles (256-thread workgroups: smaller barrier domains, more of them resident), at the price of
+        // fewer hot bits per pass; and never on the pipelined kernel.
         const unsigned Tp = (unsigned)g_tune.fuse_T_phase;
         if (Tp >= 9 && Tp <= 12 && Tp <= n && g_tune.fuse_rounds && n_other == 0 &&
             n_ph >= (size_t)g_tune.fuse_phase_ratio * std::max<size_t>(n_h, 1)) {

@@ -158,7 +158,11 @@ def main():
     else:
         import torch.distributed as dist
         from quantumcomputer_amd.sharded import ShardedRegister
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("QCX_BENCH_BACKEND", "nccl")        # (gloo: rehearsal of the N > 1 path on one GPU, test rigs only)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
         reg = ShardedRegister(n, 0)
         reg.fill_random(1)
 
@@ -224,7 +228,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "qcx::k_h_pair (Hadamard, pair form, target qubit >= 3)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
-                         "launches_timed": len(dom_ms), "traffic": load_traffic()},
+                         "launches_timed": len(dom_ms),
+                         "traffic": load_traffic() if args.n_local == 30 else None},     # PMC passes were taken at n = 30
             "per_qubit_gbs": per_q_gbs,
             "fused_sweep": fused if args.gpus == 1 else None,
             "total_probability_after": norm,

@@ -97,6 +97,16 @@ class HipEngine:
         check(lib().qcx_shard_collapse(self._p(t), n_local, local_index, self._s()), "qcx_shard_collapse")
 
 
+class _Done:
+    """a finished collective (host-staged exchange)"""
+
+    def wait(self):
+        return True
+
+
+_DONE = _Done()
+
+
 class ShardedRegister:
     """Register (qc_shor.c:194-203) sharded by its top log2(world) physical index bits."""
 
@@ -134,6 +144,8 @@ class ShardedRegister:
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = torch.device(device)
         self.engine = engine if engine is not None else HipEngine(self.device)
+        self._host_staged = (not dry_run and self.device.type == "cuda" and self.world > 1
+                             and dist.get_backend(group) == "gloo")
         self.dry_run = bool(dry_run)              # schedule only (tools/model_sharded.py): no amplitude storage
         if self.dry_run:
             self.bufs = [("buf", 0), ("buf", 1)]
@@ -205,6 +217,14 @@ class ShardedRegister:
             src, dst, out = dst, src, src_buf
         else:
             out = dst_buf
+        if self._host_staged:
+            # gloo has no device all-to-all: stage through the host (rehearsals of the multi-process path on one GPU,
+            # tests/test_gpu_sharded_multiproc.py).  Production is nccl (= RCCL), device to device.
+            src_h = src.cpu()
+            dst_h = torch.empty_like(src_h)
+            dist.all_to_all_single(dst_h, src_h, group=self.group)
+            dst.copy_(dst_h)
+            return _DONE, out
         work = dist.all_to_all_single(dst, src, group=self.group, async_op=async_op)
         return work, out
 
@@ -499,6 +519,7 @@ class ShardedRegister:
     def gather(self):
         """whole state on every rank (tests only: 16 * 2^n bytes)"""
         self._identity()
-        parts = [torch.empty_like(self.shard) for _ in range(self.world)]
-        dist.all_gather(parts, self.shard, group=self.group)
+        mine = self.shard.cpu() if self._host_staged else self.shard          # gloo gathers host tensors only
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine, group=self.group)
         return torch.cat(parts).cpu().numpy()

@@ -108,3 +108,19 @@ def test_shard_run_fused_gate_list(pg, ob, qc):
         eng.run_ops(t, nl, M, descs)
         got = t.cpu().numpy()
         assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), trial
+
+
+def test_rccl_all_to_all_single_float64_async(pg):
+    """the one collective the exchange uses, on RCCL as far as one GPU allows (world size 1): float64 device buffers,
+    async_op + Work.wait() ordering against kernels on the current stream, equal and explicit split sizes"""
+    import torch
+    src = torch.arange(1 << 21, dtype=torch.float64, device="cuda:0")
+    dst = torch.zeros_like(src)
+    src.mul_(0.5)                                            # a kernel on the current stream right before the collective
+    w = pg.all_to_all_single(dst, src, async_op=True)
+    w.wait()
+    dst.add_(1.0)                                            # ... and one right after the wait
+    assert torch.equal(dst, torch.arange(1 << 21, dtype=torch.float64, device="cuda:0") * 0.5 + 1.0)
+    dst2 = torch.zeros_like(src)
+    pg.all_to_all_single(dst2, src, output_split_sizes=[src.numel()], input_split_sizes=[src.numel()])
+    assert torch.equal(dst2, src)

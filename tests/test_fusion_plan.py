@@ -140,3 +140,29 @@ def test_single_gates_and_oversized_multiplies_stay_stand_alone(qc, tune_guard):
              (1, 0, 0b11, c, s, 0, 0)]
     actions, _, _ = qc.fusion_plan(n, M, descs)
     assert [(a.fused, a.first_gate, a.ngates) for a in actions] == [(1, 0, 2), (0, 2, 1), (1, 3, 2)]
+
+
+@pytest.mark.parametrize("count", [63, 64, 65, 128, 129, 200])
+def test_long_phase_runs_are_cut_at_64_gates(qc, ob, tune_guard, count):
+    """a run holds at most 64 gates (one ballot word): longer stretches of equal-selection phases become several runs"""
+    n = 13
+    rs = np.random.RandomState(count)
+    steps = [("h", 7)]
+    for k in range(count):
+        steps.append(("p", 7, int(rs.choice([0, 1, 2, 3, 5, 6, 9, 11, 12])), float(rs.uniform(-3, 3))))
+    steps.append(("h", 9))
+    descs = []
+    for s in steps:
+        if s[0] == "h":
+            descs.append((0, s[1], 0, 0.0, 0.0, 0, 0))
+        else:
+            c, sn = qc.polar(s[3])
+            descs.append((1, 0, (1 << s[1]) | (1 << s[2]), c, sn, 0, 0))
+    actions, recs, nrec = qc.fusion_plan(n, 0, descs)
+    runs = [recs[k].type >> 16 for k in range(nrec) if (recs[k].type & 0xFF) == emu.FUSE_PRUN]
+    assert sum(runs) == count and max(runs) <= 64 and len(runs) >= -(-count // 64)
+    state = ob.random_state(n, 9)
+    want = state.copy()
+    oracle_run(ob, want, n, 0, 1, steps)
+    emu.run_plan(state, n, 0, descs, actions, recs, ob)
+    assert np.array_equal(bits(state), bits(want))

@@ -261,3 +261,23 @@ def test_phase_only_programs_keep_untouched_negative_zeros(qc, ob):
     assert np.array_equal(bits(fused), bits(plain))
     nz = want != 0.0
     assert np.array_equal(bits(plain)[nz], bits(want)[nz]) and np.array_equal(plain, want)
+
+
+@pytest.mark.parametrize("count", [63, 64, 65, 128, 129, 200])
+def test_long_phase_runs(qc, ob, count):
+    """runs are cut at 64 gates (one ballot word per run): exactly 64, one more, several runs, with controls inside
+    the tile, in the lane bits, in the wave bits and outside the tile"""
+    n = 16
+    rs = np.random.RandomState(count)
+    st = ob.random_state(n, 13)
+    want = st.copy()
+    with qc.Register(n, 0) as reg:
+        reg.write(st); reg.set_fusion(True)
+        qc.hadamard_gate(7, reg); ob.hadamard(want, n, 7)
+        for k in range(count):
+            t = int(rs.choice([0, 1, 2, 3, 5, 6, 9, 11, 12, 14, 15]))
+            th = float(rs.uniform(-3, 3))
+            qc.c_phase_shift_gate(7, t, th, reg); ob.cphase(want, n, 7, t, th)
+        qc.hadamard_gate(9, reg); ob.hadamard(want, n, 9)
+        got = reg.read()
+    assert np.array_equal(bits(got), bits(want))

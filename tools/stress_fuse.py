@@ -12,7 +12,7 @@ for pruns in (1, 0):
     for rounds in (1, 0):
         qc.tune(fuse_T_phase=10 if pruns else 0, fuse_rounds=rounds)
         for (L, M, Cn) in ((16, 4, 15), (13, 5, 21), (12, 0, 1), (14, 6, 35)):
-            for seed in range(12):
+            for seed in range(int(os.environ.get('STRESS_SEEDS', '12'))):
                 rs = np.random.RandomState(seed * 7 + L)
                 prog = random_program(rs, L + M, M, Cn, 90)
                 got, want, _ = run_both(qc, ob, L, M, Cn, prog, 11)

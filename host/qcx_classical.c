@@ -56,17 +56,23 @@ void qcx_cf_denominators(double omega, unsigned count, unsigned *den)
     }
 }
 
-unsigned qcx_read_x_tilde(unsigned long state_num, int L, int M)
+/* the L register read in reversed bit order (Q:868-883), as a 64-bit value: L can exceed 32 on this engine */
+static unsigned long long read_x_tilde64(unsigned long state_num, int L, int M)
 {
-    unsigned x = 0;
-    for (int p = 0; p < L; p++)
-        x |= (unsigned)((state_num >> (L + M - 1 - p)) & 1UL) << p;
+    unsigned long long x = 0;
+    for (int p = 0; p < L && p < 64; p++)
+        x |= (unsigned long long)((state_num >> (L + M - 1 - p)) & 1UL) << p;
     return x;
+}
+
+unsigned qcx_read_x_tilde(unsigned long state_num, int L, int M)      /* the reference's unsigned int: low 32 bits */
+{
+    return (unsigned)read_x_tilde64(state_num, L, M);
 }
 
 double qcx_read_omega(unsigned long state_num, int L, int M)
 {
-    return (double)qcx_read_x_tilde(state_num, L, M) / (double)(1ULL << L);
+    return (double)read_x_tilde64(state_num, L, M) / ldexp(1.0, L);
 }
 
 static int is_period(unsigned a, unsigned p, unsigned C, int ref_intpow)

@@ -144,3 +144,23 @@ def test_cli_state_dumps(hostlib, tmp_path, qc):
     L, M, b = qc.load_state_file(post)
     measured = [int(l.split("Measured state")[1].split(",")[0]) for l in r.stdout.splitlines() if "Measured state" in l][-1]
     assert np.count_nonzero(b) == 1 and b[2 * measured] == 1.0
+
+
+def test_classical_helpers_under_asan_ubsan(tmp_path):
+    """host/qcx_classical.c swept over ordinary and hostile inputs with -fsanitize=address,undefined (CPU only)"""
+    exe = str(tmp_path / "classical_san")
+    subprocess.run(["gcc", "-O1", "-g", "-std=gnu11", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe,
+                    os.path.join(ROOT, "tests", "c", "classical_sanitize.c"), os.path.join(ROOT, "host", "qcx_classical.c"), "-lm"],
+                   check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "sanitized calls ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_read_omega_beyond_32_register_bits(hostlib):
+    """L > 32 (this engine holds n = 34 on one GPU): x~ no longer fits the reference's unsigned int"""
+    L, M = 34, 0
+    state = (1 << 33) | 1                       # bits 33 and 0 set -> reversed: bits 0 and 33 of x~
+    hostlib.qcx_read_omega.restype = C.c_double
+    hostlib.qcx_read_omega.argtypes = [C.c_ulong, C.c_int, C.c_int]
+    want = (1 + (1 << 33)) / float(1 << 34)
+    assert hostlib.qcx_read_omega(state, L, M) == want

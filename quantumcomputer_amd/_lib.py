@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqcx.so")
+LIB_PATH = os.environ.get("QCX_LIB", os.path.join(_HERE, "libqcx.so"))      # (override: sanitizer builds of the host code, test rigs)
 
 # status codes (include/qcx.h; 0..4 are the reference's ErrorCode, qc_shor.c:164-170)
 NO_ERROR, INSUFFICIENT_MEMORY, BAD_ARGUMENTS, PERIOD_NOT_FOUND, UNKNOWN_ERROR = range(5)

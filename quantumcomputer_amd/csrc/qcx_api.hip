@@ -106,15 +106,16 @@ struct Tune {
     long fuse_rounds = 1;      // fused passes: rounds form (4 amplitudes per thread in registers, radix-4 H steps)
     long fuse_ldsdma = 1;      // fused passes: fill the tile with global_load_lds (LDS-DMA)
     long fuse_max_queue = 4096;
+    long meas_block_log = 0;   // parallel measurement: 2^this amplitudes per block (8..13); 0 = from the shard size
     long meas_parallel = 1;    // 0: always the single-wave sequential scan
-    long meas_min_log2 = 16;   // shards below 2^this amplitudes use the single-wave scan (tools/probe_shots.py: 320 us at 2^15, 620 us at 2^16 against ~370 us for the parallel form)
+    long meas_min_log2 = 12;   // shards below 2^this amplitudes use the single-wave scan (tools/probe_shots.py)
 };
 static Tune g_tune;
 
 extern "C" int qcx_tune_set(const char *key, long value)
 {
 #define K(name) if (!strcmp(key, #name)) { g_tune.name = value; return QCX_NO_ERROR; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_pruns) K(fuse_camruns) K(fuse_pipe) K(fuse_pipe_grid) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_pruns) K(fuse_camruns) K(fuse_pipe) K(fuse_pipe_grid) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ)
 #undef K
     return QCX_BAD_ARGUMENTS;
 }
@@ -122,7 +123,7 @@ extern "C" int qcx_tune_set(const char *key, long value)
 extern "C" long qcx_tune_get(const char *key)
 {
 #define K(name) if (!strcmp(key, #name)) return g_tune.name;
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_pruns) K(fuse_camruns) K(fuse_pipe) K(fuse_pipe_grid) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_pruns) K(fuse_camruns) K(fuse_pipe) K(fuse_pipe_grid) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ)
 #undef K
     return -1;
 }
@@ -568,7 +569,15 @@ extern "C" int qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_
         hipLaunchKernelGGL(k_measure_scan, dim3(1), dim3(64), 0, st, (const amp_t *)amp, count, cum_in, r, w->mout);
     } else {
         // exact parallel form (qcx_kernels.h, K4b): block binade guesses -> integer block increments -> chain
-        const uint64_t nb64 = (count + MEAS_BLOCK - 1) >> MEAS_BLOCK_LOG;
+        // block size: the chain costs ~14 ns per block, the one block that is rescanned sequentially ~28 ns per amplitude
+        unsigned blog = (unsigned)g_tune.meas_block_log;
+        if (blog == 0) {
+            unsigned bits = 0;
+            while (bits < 63 && ((uint64_t)1 << bits) < count) bits++;
+            blog = bits ? (bits - 1) / 2 : 8;
+        }
+        blog = std::min<unsigned>(std::max<unsigned>(blog, 8u), (unsigned)MEAS_BLOCK_LOG_MAX);
+        const uint64_t nb64 = (count + (((uint64_t)1 << blog) - 1)) >> blog;
         if (nb64 > 0x7fffffffULL) return QCX_UNSUPPORTED;
         const unsigned nblocks = (unsigned)nb64;
         {
@@ -582,11 +591,11 @@ extern "C" int qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_
                 w->meas_cap = nblocks;
             }
         }
-        hipLaunchKernelGGL((k_meas_blocksum<256>), dim3(nblocks), dim3(256), 0, st, (const amp_t *)amp, count, w->meas_sums);
+        hipLaunchKernelGGL((k_meas_blocksum<256>), dim3(nblocks), dim3(256), 0, st, (const amp_t *)amp, count, w->meas_sums, blog);
         hipLaunchKernelGGL(k_meas_prefix, dim3(1), dim3(1024), 0, st, w->meas_sums, nblocks, cum_in, w->meas_prefix);
-        hipLaunchKernelGGL((k_meas_composite<256>), dim3(nblocks), dim3(256), 0, st, (const amp_t *)amp, count, w->meas_prefix, w->meas_blocks);
+        hipLaunchKernelGGL((k_meas_composite<256>), dim3(nblocks), dim3(256), 0, st, (const amp_t *)amp, count, w->meas_prefix, w->meas_blocks, blog);
         hipLaunchKernelGGL(k_meas_chain, dim3(1), dim3(64), 0, st, (const amp_t *)amp, count, w->meas_blocks, nblocks,
-                           cum_in, r, w->mout, w->meas_stats);
+                           cum_in, r, w->mout, w->meas_stats, blog);
     }
     HIP_TRY(hipGetLastError());
     if (parallel) HIP_TRY(hipMemcpyAsync(w->h_meas_stats, w->meas_stats, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));

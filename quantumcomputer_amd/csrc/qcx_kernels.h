@@ -406,8 +406,9 @@ __global__ __launch_bounds__(64) void k_measure_scan(const amp_t *__restrict__ a
 //      strictly sequential wave scan of k_measure_scan.  The result is the reference's index,
 //      bit for bit, for every input; only the speed depends on the data.
 // ---------------------------------------------------------------------------
-constexpr int MEAS_BLOCK_LOG = 13;
-constexpr unsigned MEAS_BLOCK = 1u << MEAS_BLOCK_LOG;          // amplitudes per block
+// amplitudes per block = 2^blog, a launch parameter (8..13): the chain costs ~14 ns per block and the one block that is
+// rescanned sequentially ~28 ns per amplitude, so small registers want small blocks (host: meas_block_log)
+constexpr int MEAS_BLOCK_LOG_MAX = 13;
 enum : uint32_t { MEAS_ALLZERO = 1u << 16, MEAS_TIE = 1u << 17, MEAS_BIG = 1u << 18, MEAS_EUNK = 1u << 19 };
 
 struct MeasBlock {
@@ -419,10 +420,11 @@ struct MeasBlock {
 __device__ __forceinline__ double prob_of(amp_t v) { return v.x * v.x + v.y * v.y; }    // gsl_complex_abs2
 
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_meas_blocksum(const amp_t *__restrict__ amp, uint64_t count, double *sums)
+__global__ __launch_bounds__(BLOCK) void k_meas_blocksum(const amp_t *__restrict__ amp, uint64_t count, double *sums, unsigned blog)
 {
     __shared__ double red[BLOCK / 64];
-    const uint64_t base = (uint64_t)blockIdx.x << MEAS_BLOCK_LOG;
+    const uint64_t base = (uint64_t)blockIdx.x << blog;
+    const unsigned MEAS_BLOCK = 1u << blog;
     double acc = 0.0;
 #pragma unroll 4
     for (unsigned j = threadIdx.x; j < MEAS_BLOCK; j += BLOCK) {
@@ -461,11 +463,12 @@ __global__ __launch_bounds__(1024) void k_meas_prefix(const double *__restrict__
 
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_meas_composite(const amp_t *__restrict__ amp, uint64_t count,
-                                                            const double *__restrict__ prefix, MeasBlock *out)
+                                                            const double *__restrict__ prefix, MeasBlock *out, unsigned blog)
 {
     __shared__ uint64_t redS[BLOCK / 64];
     __shared__ uint32_t redF[BLOCK / 64];
-    const uint64_t base = (uint64_t)blockIdx.x << MEAS_BLOCK_LOG;
+    const uint64_t base = (uint64_t)blockIdx.x << blog;
+    const unsigned MEAS_BLOCK = 1u << blog;
     const uint64_t pbits = (uint64_t)__double_as_longlong(prefix[blockIdx.x]);
     const int e = (int)((pbits >> 52) & 0x7ff);                  // biased exponent of the assumed start value
     uint64_t S = 0;
@@ -542,7 +545,7 @@ __device__ __forceinline__ bool wave_exact_scan(const amp_t *__restrict__ amp, u
 
 __global__ __launch_bounds__(64) void k_meas_chain(const amp_t *__restrict__ amp, uint64_t count,
                                                    const MeasBlock *__restrict__ blocks, unsigned nblocks,
-                                                   double cum_in, double r, MeasureOut *out, unsigned *stats)
+                                                   double cum_in, double r, MeasureOut *out, unsigned *stats, unsigned blog)
 {
     const unsigned lane = threadIdx.x;
     double cum = cum_in;
@@ -593,8 +596,8 @@ __global__ __launch_bounds__(64) void k_meas_chain(const amp_t *__restrict__ amp
             }
             if (!fast) {
                 slow++;
-                const uint64_t first = (uint64_t)(b0 + j) << MEAS_BLOCK_LOG;
-                const uint64_t len = min((uint64_t)MEAS_BLOCK, count - first);
+                const uint64_t first = (uint64_t)(b0 + j) << blog;
+                const uint64_t len = min((uint64_t)1 << blog, count - first);
                 uint64_t hi = 0; double hc = 0.0;
                 if (wave_exact_scan(amp, first, len, cum, r, &hi, &hc)) {
                     if (lane == 0) { out->found = 1; out->index = hi; out->cum = hc; if (stats) { stats[0] = slow; stats[1] = nblocks; } }

@@ -15,10 +15,11 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 
 
-@pytest.fixture()
-def force_parallel(qc):
-    old = {k: qc.lib().qcx_tune_get(k.encode()) for k in ("meas_parallel", "meas_min_log2")}
-    qc.tune(meas_parallel=1, meas_min_log2=10)
+@pytest.fixture(params=[0, 8, 10, 13], ids=lambda b: f"block=2^{b}" if b else "block=auto")
+def force_parallel(qc, request):
+    """the exact parallel form even on small registers, with every block size (0: chosen from the register size)"""
+    old = {k: qc.lib().qcx_tune_get(k.encode()) for k in ("meas_parallel", "meas_min_log2", "meas_block_log")}
+    qc.tune(meas_parallel=1, meas_min_log2=10, meas_block_log=request.param)
     yield
     qc.tune(**old)
 
@@ -57,7 +58,8 @@ def test_random_dense_states(qc, ob, force_parallel, n):
     a = ob.random_state(n, 40 + n)
     check(qc, ob, n, a, [0.0, 1.0, 0.5, 1e-9, 0.999999999] + list(rs.uniform(0, 1, 10)) + partial_sum_rs(a, rs))
     slow, blocks = last_stats(qc)
-    assert blocks == (1 << n) // 8192 and slow <= 80
+    blog = qc.lib().qcx_tune_get(b"meas_block_log") or min(13, max(8, (n - 1) // 2))     # auto: from the register size
+    assert blocks == -(-((1 << n) - 1) // (1 << blog)) and slow <= 80
 
 
 def test_uniform_superposition_no_rounding(qc, ob, force_parallel):

@@ -163,7 +163,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-        reg = ShardedRegister(n, 0)
+        reg = ShardedRegister(n, 0, fusion=False)       # one launch per gate, like the N = 1 headline
         reg.fill_random(1)
 
         def sweep():

@@ -111,7 +111,7 @@ class ShardedRegister:
     """Register (qc_shor.c:194-203) sharded by its top log2(world) physical index bits."""
 
     def __init__(self, L_size, M_size, device=None, group=None, engine=None, max_queue=8192, slices_log2=None,
-                 dry_run=False, fusion=False):
+                 dry_run=False, fusion=True):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -139,7 +139,9 @@ class ShardedRegister:
         self.zone_lo = self.slice_bits - k
         self.overlap = os.environ.get("QCX_SHARD_OVERLAP", "1") != "0"
         self.overlapped_gates = 0
-        self.fusion = bool(fusion)         # run gate lists through the fused-pass scheduler (same bits, fewer HBM passes)
+        # run each window's gate list through the fused-pass scheduler (qcx_shard_run_fused): same bits, fewer HBM passes.
+        # False: one kernel launch per gate (bench.py --gpus N uses that to stay comparable with its N = 1 headline)
+        self.fusion = bool(fusion)
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = torch.device(device)

@@ -39,7 +39,7 @@ def main():
     out = {"config": a.config, "n_gpus": world}
     if a.config == 4:
         n = a.n or 32
-        reg = ShardedRegister(n, 0)
+        reg = ShardedRegister(n, 0, fusion=a.fused)
         reg.fill_random(1); reg.synchronize()
         nl = reg.n_local
         res = {}

@@ -26,6 +26,11 @@ for _sl in (1, 2, 3):
             d = _v(1, ppt=_ppt, blk=64, sl=_sl); d["h_skew"] = _skew
             VARIANTS[f"p{_ppt}_s{_sl}_k{_skew}"] = d
 
+# capped (grid-stride) grids: fewer, longer-lived workgroups walking the pairs in order
+for _cap in (2048, 4096, 8192, 16384, 32768, 65536, 262144):
+    for _blk in (64, 256):
+        VARIANTS[f"cap{_cap}_b{_blk}"] = _v(1, ppt=1, blk=_blk, cap=_cap)
+
 
 def main():
     ap = argparse.ArgumentParser()

@@ -1,5 +1,5 @@
 """fused Shor N=21 at n=30, part by part (each part flushed on its own): where the time of the circuit goes"""
-import sys, time, os, math
+import sys, time, os
 sys.path.insert(0, os.getcwd())
 import quantumcomputer_amd as qc
 L, M, C, a = 25, 5, 21, 2

@@ -102,4 +102,33 @@ static inline void c_amodc_gate(unsigned int C, unsigned long long int atox, uns
     qcx_compat_die(qcx_c_amodc_gate(C, atox, c_qubit_num, reg->handle), "c_amodc_gate");
 }
 
+/* ---- the developer helpers of testing_and_debug.c (T:7-37), on the device-resident state -------------------------
+ * Same output format: one line "|b_{n-1}...b_0> 0.xx" per basis state with a non-zero amplitude (|amplitude|, two
+ * decimals), and "Total Probability: %.16f".  The state is read back in pieces of 2^16 amplitudes. */
+static inline void display_state(Register reg)
+{
+    enum { QCX_PIECE = 1 << 16 };
+    double *buf = (double *)malloc(2 * sizeof(double) * QCX_PIECE);
+    if (!buf) { fprintf(stderr, "display_state: out of memory\n"); return; }
+    for (unsigned long first = 0; first < reg.num_states; first += QCX_PIECE) {
+        const unsigned long cnt = reg.num_states - first < QCX_PIECE ? reg.num_states - first : QCX_PIECE;
+        qcx_compat_die(qcx_state_read(reg.handle, first, cnt, buf), "display_state");
+        for (unsigned long k = 0; k < cnt; k++) {
+            const double prob = hypot(buf[2 * k], buf[2 * k + 1]);            /* gsl_complex_abs (T:13) */
+            if (prob != 0.0) {
+                printf("|");
+                for (int b = (int)reg.num_qubits - 1; b >= 0; b--) printf("%d", (int)(((first + k) >> b) & 1ul));
+                printf("> %.2f\n", prob);
+            }
+        }
+    }
+    free(buf);
+}
+static inline void check_normalisation(Register reg)
+{
+    double total = 0.0;
+    qcx_compat_die(qcx_norm2(reg.handle, &total), "check_normalisation");
+    printf("Total Probability: %.16f\n", total);
+}
+
 #endif /* QCX_COMPAT_H */

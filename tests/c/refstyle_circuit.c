@@ -48,6 +48,16 @@ int main(int argc, char **argv)
     circuit_like_reference(C, a, &reg, matrix);
     swap_states(&reg);
 
+    if (argc > 6 && strcmp(argv[6], "debug") == 0) {       /* the developer helpers of testing_and_debug.c */
+        check_normalisation(reg);
+        unsigned long m = measure_state(reg, rng);
+        printf("measured %lu\n", m);
+        display_state(reg);
+        check_normalisation(reg);
+        register_free(&reg);
+        qcx_rng_free(rng);
+        return 0;
+    }
     double *host = (double *)malloc(reg.num_states * 2 * sizeof(double));
     if (qcx_state_read(reg.handle, 0, reg.num_states, host) != QCX_NO_ERROR) return 4;
     for (unsigned long i = 0; i < 2 * reg.num_states; i++) {

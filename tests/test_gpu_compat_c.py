@@ -37,3 +37,16 @@ def test_reference_style_c_program(exe, ob, C, L, M, a, fusion):
     assert np.array_equal(got, want.view(np.uint64))
     rng = ob.Rng(12345)
     assert int(lines[-1]) == ob.measure(want, n, rng.uniform())
+
+
+def test_debug_helpers_of_the_reference(exe):
+    """display_state / check_normalisation (testing_and_debug.c:7-37) through the compat header, same output format"""
+    C, L, M, a = 21, 5, 5, 2
+    n = L + M
+    r = subprocess.run([exe, str(C), str(L), str(M), str(a), "12345", "debug"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout.splitlines()
+    assert out[0].startswith("Total Probability: ") and abs(float(out[0].split(": ")[1]) - 1.0) < 1e-13
+    idx = int(out[1].split()[1])
+    assert out[2] == "|" + format(idx, f"0{n}b") + "> 1.00"           # collapsed: exactly one basis state, amplitude 1
+    assert out[3] == "Total Probability: 1.0000000000000000" and len(out) == 4

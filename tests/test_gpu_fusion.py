@@ -15,7 +15,7 @@ def bits(a):
 @pytest.fixture()
 def tune_guard(qc):
     keys = ("fuse_T", "fuse_c", "fuse_grid_cap", "fuse_max_queue", "fuse_rounds", "fuse_pipe", "fuse_ldsdma", "fuse_camruns",
-            "fuse_T_phase", "fuse_c_phase", "fuse_phase_ratio", "fuse_pipe_grid")
+            "fuse_T_phase", "fuse_c_phase", "fuse_phase_ratio", "fuse_pipe_grid", "fuse_rounds_occ")
     old = {k: qc.lib().qcx_tune_get(k.encode()) for k in keys}
     yield
     qc.tune(**old)
@@ -281,3 +281,15 @@ def test_long_phase_runs(qc, ob, count):
         qc.hadamard_gate(9, reg); ob.hadamard(want, n, 9)
         got = reg.read()
     assert np.array_equal(bits(got), bits(want))
+
+
+@pytest.mark.parametrize("occ", [0, 6, 7, 8])
+def test_rounds_kernel_builds(qc, ob, tune_guard, occ):
+    """k_fused_rounds built for 6 / 7 / 8 waves per SIMD (with and without the modular-multiply code), 0 = the general
+    k_fused kernel: same bits"""
+    qc.tune(fuse_rounds_occ=occ)
+    rs = np.random.RandomState(occ + 40)
+    for (L, M, Cn) in ((13, 5, 21), (17, 0, 1), (15, 4, 15)):
+        prog = random_program(rs, L + M, M, Cn, 80)
+        got, want, _ = run_both(qc, ob, L, M, Cn, prog, 17)
+        assert np.array_equal(bits(got), bits(want)), (occ, L, M)

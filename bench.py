@@ -66,11 +66,13 @@ def cpu_baseline(n_sample, budget_s=12.0):
 
 def load_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes, if any"""
-    p = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    try:
-        return json.load(open(p)).get("k_h_pair_bytes_per_launch_n30")
-    except Exception:
-        return None
+    import glob
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):     # latest pass first
+        try:
+            return json.load(open(p)).get("k_h_pair_bytes_per_launch_n30")
+        except Exception:
+            continue
+    return None
 
 
 def main():

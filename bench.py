@@ -3,7 +3,9 @@
 (BASELINE.json: "amplitude-updates/s (gate*2^n/s) and HBM GB/s vs roofline, n=30 H-sweep").
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+  N > 1, either form:
+      python bench.py --gpus N ...                         (starts its N ranks itself, see self_launch)
+      python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
               --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one sweep: hadamard_gate(q) for q = 0..n-1, one kernel launch per gate through the C ABI
@@ -16,12 +18,20 @@ Extra objects on the JSON line:
   roofline      the dominant kernel (k_h_pair, the pair-form Hadamard used for q >= 3): algorithmic
                 bytes per launch (32 B per amplitude = 32 * 2^n_local) / mean launch duration measured
                 with HIP events recorded between the gates of the timed region, vs 8 TB/s HBM peak.
-  cpu_baseline  the CPU oracle (oracle/, a port of the reference arithmetic, pairwise in place,
-                OpenMP over the host cores) on a bounded sample of the same workload (smaller n).
+                `traffic` is NOT measured in this run: it is the per-launch HBM byte count of the committed
+                rocprofv3 --pmc passes of this same command (`traffic_source` names the file).
+  cpu_baseline  the CPU oracle (oracle/, a port of the reference arithmetic) on bounded samples of the same
+                workload: tier T3 = pairwise in place, OpenMP over the host cores (the headline `value`),
+                T2 = the reference's COO mat-vec alone, T1 = the literal reference algorithm.
+  fused_sweep   (N = 1) the same 30 gate calls with qcx_set_fusion(1): passes, GB/s per pass, roofline fraction.
+  config4       (N > 1) BASELINE config 4: H on every global qubit vs a local one at n = 29 + log2 N
+                (n = 32 on 8 GPUs), exchange GB/s per GPU.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,10 +41,20 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def mem_available_gib():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 2**20
+    except OSError:
+        pass
+    return 0.0
+
+
 def cpu_baseline(n_sample, budget_s=12.0):
-    """oracle (kind "port") timed on this box's host cores: H-sweep at n_sample qubits"""
+    """oracle (kind "port") timed on this box's host cores: H-sweep at n_sample qubits (tier T3), plus the
+    reference's own two costs for context: its COO mat-vec alone (T2) and build + mat-vec (T1)"""
     from oracle import binding as ob
-    import numpy as np
     # threads = the CPUs this process may use, capped at the GPU box's per-GPU CPU share
     try:
         avail = len(os.sched_getaffinity(0))
@@ -50,29 +70,101 @@ def cpu_baseline(n_sample, budget_s=12.0):
             ob.hadamard(a, n_sample, q, cores)
             gates += 1
     dt = time.perf_counter() - t0
-    # the literal reference algorithm (scan 4^n index pairs, build COO, mat-vec), 1 thread, for context
+    del a
+    # T1: the literal reference algorithm (scan 4^n index pairs, build COO, mat-vec), 1 thread
     lit_n = 11
     R = ob.LiteralRegister(lit_n, 0)
     R.set_state(ob.fill_random(lit_n, 1))
     t1 = time.perf_counter(); R.hadamard(lit_n - 1); lit_dt = time.perf_counter() - t1
     R.close()
-    del a, np
-    return {"value": gates * float(1 << n_sample) / dt, "unit": "amplitude-updates/s", "cores": cores, "kind": "port",
+    # T2: the reference's mat-vec (Q:396-413) on a COO matrix built in O(2^n) instead of by the 4^n scan, 1 thread
+    spmv_n = 22
+    R = ob.LiteralRegister(spmv_n, 0)
+    R.set_state(ob.fill_random(spmv_n, 1))
+    R.spmv_hadamard(0)                                      # first call grows the COO arrays
+    t2 = time.perf_counter()
+    for q in (0, spmv_n // 2, spmv_n - 1):
+        R.spmv_hadamard(q)
+    spmv_dt = (time.perf_counter() - t2) / 3
+    R.close()
+    return {"value": gates * float(1 << n_sample) / dt, "unit": "amplitude-updates/s", "cores": cores, "kind": "port", "tier": "T3",
             "sample": f"{gates // n_sample} Hadamard sweeps q=0..{n_sample - 1} of an n={n_sample} register ({gates} gates, {dt:.1f} s), "
                       f"oracle pairwise in-place form, OpenMP {cores} threads",
-            "literal_reference_algorithm": {"value": float(1 << lit_n) / lit_dt, "unit": "amplitude-updates/s", "cores": 1,
+            "reference_matvec_only": {"tier": "T2", "value": float(1 << spmv_n) / spmv_dt, "unit": "amplitude-updates/s", "cores": 1,
+                                      "sample": f"hadamard_gate at n={spmv_n}, q in (0, {spmv_n // 2}, {spmv_n - 1}): COO triplets laid down in "
+                                                f"O(2^n), then the reference's mat-vec loop ({spmv_dt * 1e3:.0f} ms per gate)"},
+            "literal_reference_algorithm": {"tier": "T1", "value": float(1 << lit_n) / lit_dt, "unit": "amplitude-updates/s", "cores": 1,
                                             "sample": f"one hadamard_gate at n={lit_n}: 4^n index-pair scan + COO mat-vec ({lit_dt * 1e3:.1f} ms)"}}
 
 
 def load_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes, if any"""
+    """(bytes per launch, source file) of the dominant kernel from the latest committed rocprofv3 --pmc summary"""
     import glob
-    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):     # latest pass first
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):     # latest round first
         try:
-            return json.load(open(p)).get("k_h_pair_bytes_per_launch_n30")
+            v = json.load(open(p)).get("k_h_pair_bytes_per_launch_n30")
         except Exception:
             continue
-    return None
+        if v:
+            return v, os.path.relpath(p, ROOT)
+    return None, None
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(ngpus, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes
+    (python -m torch.distributed.run, one rank per GPU) BEFORE anything in this process touches the GPU, relay
+    rank 0's JSON line, return the children's exit status.  Nothing is exec'ed: this process only waits."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    line = None
+    for ln in r.stdout.decode(errors="replace").splitlines():
+        s = ln.strip()
+        if s.startswith("{") and s.endswith("}"):
+            line = s
+        elif s:
+            print(s, file=sys.stderr)
+    if r.returncode != 0 or line is None:
+        print(f"bench.py: the {ngpus}-rank run failed (exit {r.returncode}, JSON line {'present' if line else 'missing'})", file=sys.stderr)
+        return r.returncode or 1
+    print(line, flush=True)
+    return 0
+
+
+def exchange_selfcheck(make_reg, torch, dist):
+    """N > 1, before the timed region: H on a global qubit applied twice must give the state back (to rounding) --
+    run once through the overlapped, sliced exchange and, if that fails, once through the synchronous unsliced one.
+    Returns the mode that works; raises if neither does.  (A wrong exchange would still produce a plausible-looking
+    throughput number; this keeps such a number from being printed.)"""
+    for mode in ("overlap", "sync"):
+        reg = make_reg(mode)
+        reg.fill_random(5)
+        reg.synchronize()
+        before = reg.shard.clone()
+        n = reg.num_qubits
+        for q in (n - 1, 3, n - 1, 3):                       # global, local, and back
+            reg.hadamard_gate(q)
+        reg._identity()                                      # flush + restore the identity layout
+        torch.cuda.synchronize()
+        err = (reg.shard - before).abs().max()
+        ref = before.abs().max()
+        t = torch.stack([err, ref])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ok = bool(t[0] <= 1e-12 * t[1]) and reg.exchanges >= 1
+        del reg, before
+        if ok:
+            return mode
+    raise RuntimeError("sharded exchange self-check failed in both modes (H.H != identity across ranks)")
 
 
 def main():
@@ -83,9 +175,13 @@ def main():
     ap.add_argument("--n-local", type=int, default=30, help="qubits per GPU shard (30 = 16 GiB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused", action="store_true")
+    ap.add_argument("--no-config4", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path (ShardedRegister) even at world size 1")
-    ap.add_argument("--cpu-n", type=int, default=28)
+    ap.add_argument("--cpu-n", type=int, default=0, help="register size of the CPU sample (0: 30 if the host has the memory, else 28)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     # stdout carries exactly ONE line (the JSON); libraries that chat on fd 1 (RCCL prints a version banner
     # there when a communicator is created) are sent to stderr for the duration of the run
@@ -99,10 +195,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("QCX_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))     # (override: test rigs only)
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev:
+        sys.exit(f"bench.py: rank {rank} wants device {local_rank} but {ndev} are visible "
+                 "(one rank per GPU; QCX_FORCE_DEVICE + QCX_BENCH_BACKEND=gloo rehearse several ranks on one GPU)")
     torch.cuda.set_device(local_rank)
     qc.lib()
 
@@ -111,8 +208,11 @@ def main():
     n = args.n_local + k
     gates_per_step = n
     dim = float(1 << n)
+    sharded = args.gpus > 1 or args.force_sharded
+    config4 = None
+    exchange_mode = None
 
-    if args.gpus == 1 and not args.force_sharded:
+    if not sharded:
         reg = qc.Register(n, 0)
         reg.fill_random(1)
         nev = args.steps * (gates_per_step + 1)
@@ -151,21 +251,42 @@ def main():
             reg.synchronize()
             tf = time.perf_counter() - tf0
             passes = (reg.fusion_stats()[0] - p0) / args.steps
+            gbs_pass = passes * 32.0 * dim / (tf / args.steps) / 1e9
             fused = {"value": args.steps * gates_per_step * dim / tf, "unit": "amplitude-updates/s", "ms_per_step": tf / args.steps * 1e3,
-                     "hbm_passes_per_sweep": passes, "hbm_gbs_per_pass": passes * 32.0 * dim / (tf / args.steps) / 1e9,
-                     "note": "qcx_set_fusion(1): same 30 hadamard_gate calls, executed as fused passes over LDS tiles"}
+                     "hbm_passes_per_sweep": passes, "hbm_gbs_per_pass": gbs_pass, "roofline_frac": gbs_pass / HBM_PEAK_GBS,
+                     "note": "qcx_set_fusion(1): same 30 hadamard_gate calls, executed as fused passes over LDS tiles; "
+                             "32 B per amplitude are counted once per pass"}
             reg.set_fusion(False)
         reg.close()
         exchanges = 0
     else:
+        import datetime
         import torch.distributed as dist
         from quantumcomputer_amd.sharded import ShardedRegister
         backend = os.environ.get("QCX_BENCH_BACKEND", "nccl")        # (gloo: rehearsal of the N > 1 path on one GPU, test rigs only)
+        if world == 1:                                               # --force-sharded without a launcher: a one-rank job
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(free_port()))
+        tmo = datetime.timedelta(seconds=int(os.environ.get("QCX_BENCH_TIMEOUT_S", "300")))   # a hung collective ends the run, loudly
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
         else:
-            dist.init_process_group(backend)
-        reg = ShardedRegister(n, 0, fusion=False)       # one launch per gate, like the N = 1 headline
+            dist.init_process_group(backend, timeout=tmo)
+
+        def make(mode, nq, **kw):
+            if mode == "sync":                                       # unsliced, no overlap, async_op=False
+                kw = dict(kw, slices_log2=0)
+            r = ShardedRegister(nq, 0, fusion=False, **kw)           # one launch per gate, like the N = 1 headline
+            if mode == "sync":
+                r.overlap = r.async_exchange = False
+            return r
+
+        exchange_mode = "none (1 rank)"
+        if args.gpus > 1:
+            want = "sync" if os.environ.get("QCX_SHARD_OVERLAP", "1") == "0" else None
+            nchk = min(args.n_local, 22) + k
+            exchange_mode = want or exchange_selfcheck(lambda m: make(m, nchk), torch, dist)
+        reg = make(exchange_mode, n)
         reg.fill_random(1)
 
         def sweep():
@@ -188,18 +309,47 @@ def main():
         prof, reg.profile = reg.profile, None
         # Hadamard launches by physical target position; a launch on a slice moves 32 * 2^bits bytes
         per_q_ms = [[] for _ in range(n)]
-        h_bytes, h_ms = 0.0, 0.0
         for kind, pq, e0, e1, bits_ in prof:
             if kind != "h":
                 continue
             ms = e0.elapsed_time(e1)
-            h_bytes += 32.0 * float(1 << bits_); h_ms += ms
             per_q_ms[pq].append(ms * float(1 << (args.n_local - bits_)))      # scaled to a whole-shard launch
-        exch_ms = []
-        overlapped = reg.overlapped_gates
         norm = reg.norm2()
         exchanges = reg.exchanges - ex0
+        sigma = reg.sigma
+        overlapped = reg.overlap and sigma > 0
         fused = None
+        del reg
+        torch.cuda.empty_cache()
+
+        # BASELINE config 4: n = 32 over 8 GPUs (29 local qubits; the same shard size at other N), H on every global
+        # qubit vs a local one.  A global H = pack pass + all-to-all of (W-1)/W of the shard + the local gate.
+        if args.gpus > 1 and not args.no_config4:
+            nl4 = min(29, args.n_local)
+            r4 = make(exchange_mode, nl4 + k)
+
+            def timed(fn):
+                torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+                t1 = time.perf_counter(); fn(); torch.cuda.synchronize(); dist.barrier()
+                tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                return float(tt.item())
+            res = {}
+            r4.fill_random(1); r4.synchronize()
+            timed(lambda: (r4.hadamard_gate(nl4 - 8), r4.synchronize()))
+            res["local_h_ms"] = timed(lambda: (r4.hadamard_gate(nl4 - 8), r4.synchronize())) * 1e3
+            for q in range(nl4 + k - 1, nl4 - 1, -1):
+                r4.fill_random(1); r4.synchronize()
+                res[f"global_h_q{q}_ms"] = timed(lambda q=q: (r4.hadamard_gate(q), r4.synchronize())) * 1e3
+            shard_bytes = 16.0 * (1 << nl4)
+            g = [v for kk, v in res.items() if kk.startswith("global")]
+            config4 = {"n": nl4 + k, "shard_GiB": shard_bytes / 2**30, "results_ms": res,
+                       "amplitude_updates_per_s_global_h": float(1 << (nl4 + k)) / (sum(g) / len(g) * 1e-3),
+                       "note": "BASELINE config 4 (n=32 on 8 GPUs): a global H = pack pass + all-to-all of (W-1)/W of the shard "
+                               "+ the local gate; exchange rate = sent bytes / (global - local time)"}
+            if min(g) > res["local_h_ms"]:
+                config4["exchange_GBps_per_gpu"] = shard_bytes * (world - 1) / world / ((min(g) - res["local_h_ms"]) * 1e-3) / 1e9
+            del r4
 
     if rank == 0:
         bytes_per_launch = 32.0 * float(1 << args.n_local)           # 16 B read + 16 B written per amplitude, per GPU
@@ -211,6 +361,13 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         # (index = physical target bit; null where no launch hit that bit, e.g. the rank-id bits at N > 1)
         per_q_gbs = [round(bytes_per_launch / (min(per_q_ms[q]) * 1e-3) / 1e9, 1) if per_q_ms[q] else None for q in range(n)]
+        traffic, traffic_src = load_traffic() if args.n_local == 30 else (None, None)     # the PMC passes were taken at n = 30
+        if not sharded:
+            par = "1 GPU"
+        else:
+            par = (f"state sharded by top {k} qubits over {args.gpus} ranks, all-to-all qubit remap for global targets "
+                   f"({exchanges} exchanges in the {args.steps} timed sweeps, "
+                   + (f"exchange overlapped with the neighbouring gates on {1 << sigma} slices)" if overlapped else "synchronous unsliced exchange)"))
         out = {
             "metric": "amplitude-updates/s (gate*2^n/s), n=30 H-sweep" if args.gpus == 1 else
                       f"amplitude-updates/s (gate*2^n/s), n={n} H-sweep sharded over {args.gpus} GPUs",
@@ -220,30 +377,34 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"n={n} Hadamard sweep q=0..{n - 1} (config 2 of BASELINE.json at the headline size n=30), "
+            "config": {"workload": f"n={n} Hadamard sweep q=0..{n - 1} (config 2 of BASELINE.json at the headline size n=30"
+                                   + (f", weak-scaled: 2^{args.n_local} amplitudes per GPU" if args.gpus > 1 else "") + "), "
                                    f"one launch per gate through libqcx.so, complex128 state of {16 * dim / 2**30:.0f} GiB in HBM",
-                       "qubits": n, "gates_per_step": gates_per_step, "shard_qubits": args.n_local,
-                       "parallelism": "1 GPU" if args.gpus == 1 else f"state sharded by top {k} qubits over {args.gpus} ranks, "
-                                      f"all-to-all qubit remap for global targets ({exchanges} exchanges in the {args.steps} timed sweeps"
-                                      + (f", exchange overlapped with the neighbouring gates on {1 << reg.sigma} slices)" if args.gpus > 1 or args.force_sharded else ")")},
+                       "qubits": n, "gates_per_step": gates_per_step, "shard_qubits": args.n_local, "parallelism": par},
             "hbm_gbs_sweep_average": args.steps * gates_per_step * bytes_per_launch * args.gpus / dt / 1e9,
             "roofline": {"bound": "hbm", "kernel": "qcx::k_h_pair (Hadamard, pair form, target qubit >= 3)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
                          "launches_timed": len(dom_ms),
-                         "traffic": load_traffic() if args.n_local == 30 else None},     # PMC passes were taken at n = 30
+                         "traffic": traffic,
+                         "traffic_source": (f"{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; "
+                                            "not re-measured in this run") if traffic_src else None},
             "per_qubit_gbs": per_q_gbs,
-            "fused_sweep": fused if args.gpus == 1 else None,
+            "fused_sweep": fused,
             "total_probability_after": norm,
         }
+        if sharded:
+            out["exchange_mode"] = exchange_mode
+            out["config4"] = config4
         if not args.no_cpu_baseline and args.gpus == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_n)
+            cpu_n = args.cpu_n or (30 if mem_available_gib() >= 48 else 28)
+            out["cpu_baseline"] = cpu_baseline(cpu_n)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
-    if args.gpus > 1 or args.force_sharded:
+    if sharded:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

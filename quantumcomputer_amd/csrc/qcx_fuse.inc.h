@@ -221,6 +221,7 @@ static int launch_pass(qcx_register *r, const FusePass &P_in, const FuseOp *d_op
     const size_t lut_only = ((size_t)2 << std::min(12u, (unsigned)r->M)) + 16;    // source table of a modular-multiply step
     size_t lut_bytes = lut_only + (size_t)P.cam_ctl_local[1];                      // + tables of folded multiply runs
     P.xm_off = 0;
+    P.dbg = (uint32_t)g_tune.fuse_dbg;
     if (P.xm_cnt) {                                                                // + the records' outside-tile masks (phase runs)
         P.xm_off = (uint32_t)((lut_bytes + 7) & ~(size_t)7);
         lut_bytes = P.xm_off + 8 * ((size_t)P.xm_cnt + 66);          // padded: lanes look up to 64 entries past a run

@@ -637,7 +637,8 @@ struct FusePass {
                                 // [3]: byte offset of the table area behind the lut in LDS
     uint8_t  hbit[16];          // global bit carried by tile-local bit c + j, ascending
     uint32_t xm_off, xm_cnt;    // LDS copy of the records' outside-tile masks: byte offset behind the lut, entries (0 = none)
-    uint32_t has_cam, pad_;     // the pass holds modular multiplies (selects the kernel variant)
+    uint32_t has_cam, dbg;      // the pass holds modular multiplies (selects the kernel variant); dbg: diagnostics only (tools/probe_pass.py):
+                                // bit 0 skip the gates, bit 1 skip the stores, bit 2 skip the tile fill -- results are then wrong by design
 };
 
 // One controlled modular multiply on an LDS-resident tile whose low M local bits are the M register.
@@ -1188,18 +1189,22 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
         uint64_t base = t << c;
         for (unsigned j = 0; j < nh; j++) base = insert_zero(base, P.hbit[j]);
         amp_t *g = amp + (base | off_t);
+        if (!(P.dbg & 4u)) {
 #pragma unroll
-        for (unsigned k = 0; k < 4; k++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + off_k[k]),
-                                             (__attribute__((address_space(3))) void *)(tile + k * BLOCK + wbase), 16, 0, 2);
+            for (unsigned k = 0; k < 4; k++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + off_k[k]),
+                                                 (__attribute__((address_space(3))) void *)(tile + k * BLOCK + wbase), 16, 0, 2);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        fuse_apply_rounds<BLOCK, TT, CAM>(tile, lut, camtab, xm, P, ops, ops_asm, base);
+        if (!(P.dbg & 1u)) fuse_apply_rounds<BLOCK, TT, CAM>(tile, lut, camtab, xm, P, ops, ops_asm, base);
         amp_t v[4];
 #pragma unroll
         for (unsigned k = 0; k < 4; k++) v[k] = tile[k * BLOCK + threadIdx.x];
+        if (!(P.dbg & 2u)) {
 #pragma unroll
-        for (unsigned k = 0; k < 4; k++) __builtin_nontemporal_store(v[k], g + off_k[k]);
+            for (unsigned k = 0; k < 4; k++) __builtin_nontemporal_store(v[k], g + off_k[k]);
+        }
         __syncthreads();
     }
 }

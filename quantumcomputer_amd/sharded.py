@@ -138,6 +138,9 @@ class ShardedRegister:
         self.slice_bits = self.n_local - sigma
         self.zone_lo = self.slice_bits - k
         self.overlap = os.environ.get("QCX_SHARD_OVERLAP", "1") != "0"
+        # async_exchange False: every all-to-all is issued synchronously (async_op=False) -- the conservative fallback
+        # (QCX_SHARD_OVERLAP=0 selects it together with no overlap; bench.py reports which mode ran)
+        self.async_exchange = self.overlap
         self.overlapped_gates = 0
         # run each window's gate list through the fused-pass scheduler (qcx_shard_run_fused): same bits, fewer HBM passes.
         # False: one kernel launch per gate (bench.py --gpus N uses that to stay comparable with its N = 1 headline)
@@ -228,7 +231,7 @@ class ShardedRegister:
             dst.copy_(dst_h)
             return _DONE, out
         work = dist.all_to_all_single(dst, src, group=self.group, async_op=async_op)
-        return work, out
+        return (work if work is not None else _DONE), out
 
     def _trade_now(self, give):
         """whole-shard exchange without any overlap (used when restoring the identity layout)"""
@@ -418,7 +421,7 @@ class ShardedRegister:
             works, outs = [None] * S, [None] * S
             for sidx in range(S):
                 self._run_ops(pre_ops, src_views[sidx], self.slice_bits, sidx)
-                works[sidx], outs[sidx] = self._move_slice(sidx, swaps, src_buf, dst_buf, True)
+                works[sidx], outs[sidx] = self._move_slice(sidx, swaps, src_buf, dst_buf, self.async_exchange)
                 if sidx >= 1:
                     works[sidx - 1].wait()
                     view = self._views(outs[sidx - 1])[sidx - 1]

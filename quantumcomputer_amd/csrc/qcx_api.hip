@@ -449,11 +449,15 @@ extern "C" int qcx_shard_camodc(void *amp, unsigned n_local, unsigned M, unsigne
     P.M = M;
     P.logT = (M < 11) ? 11 : M;                      // >= 2048 amplitudes (32 KiB) per tile
     if (P.logT > n_local) P.logT = n_local;
+    // a control at or above the M register is squeezed out of the tile numbering (tiles hold control-set amplitudes
+    // only: half the vector is never read); that needs at least two tiles' worth of index space
+    if (ctl >= (int)M && P.logT == n_local && P.logT > M) P.logT--;
     if (P.logT < M) return QCX_BAD_ARGUMENTS;
     P.ctl = ctl;
     P.C = C;
     const uint64_t blk = (uint64_t)1 << M;
     const uint64_t all_tiles = (uint64_t)1 << (n_local - P.logT);
+    const uint64_t ctl_tiles = (ctl >= (int)M) ? all_tiles >> 1 : all_tiles;
     const size_t lds = (size_t)16 << P.logT;
 
     // closed form is valid when the control is outside the M register, every residue fits the
@@ -466,7 +470,7 @@ extern "C" int qcx_shard_camodc(void *amp, unsigned n_local, unsigned M, unsigne
         P.d = gcd_u32(A, C);            // gcd(0, C) = C
         P.Cd = C / P.d;
         P.inv = modinv_u32(A / P.d, P.Cd);
-        P.ntiles = (ctl >= (int)P.logT) ? all_tiles >> 1 : all_tiles;
+        P.ntiles = ctl_tiles;
         const unsigned grid = grid_for(P.ntiles, 1, g_tune.cam_grid_cap);
         hipLaunchKernelGGL((k_camodc<256>), dim3(grid), dim3(256), lds, st, a, P);
         HIP_TRY(hipGetLastError());
@@ -506,7 +510,7 @@ extern "C" int qcx_shard_camodc(void *amp, unsigned n_local, unsigned M, unsigne
     CamodcParams Pt = P;
     Pt.d = 1; Pt.Cd = C; Pt.inv = 0;
     if (ctl >= 0 && ctl < (int)M) Pt.ctl = -1;               // the table already encodes the control
-    Pt.ntiles = (Pt.ctl >= (int)P.logT) ? all_tiles >> 1 : all_tiles;
+    Pt.ntiles = (Pt.ctl >= (int)M) ? all_tiles >> 1 : all_tiles;
     const unsigned grid = grid_for(Pt.ntiles, 1, g_tune.cam_grid_cap);
     hipLaunchKernelGGL((k_camodc_table<256>), dim3(grid), dim3(256), lds, st, a, Pt, w->tab, w->tab + blk + 1);
     HIP_TRY(hipGetLastError());

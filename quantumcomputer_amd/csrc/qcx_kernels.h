@@ -198,15 +198,35 @@ __global__ __launch_bounds__(BLOCK) void k_phase(amp_t *__restrict__ amp, unsign
 //     f = f0 + t*(C/d),  t = 0..d-1,  f0 = ((g/d) * inv) mod (C/d),  d | g
 // (inv = (A/d)^-1 mod C/d, computed on the host); for the usual coprime case
 // d = 1 and the gate is a permutation.  A tile of 2^logT >= 2^M amplitudes is
-// staged in LDS so the update is in place with coalesced global traffic; tiles
-// whose control bit is 0 are never touched.
+// staged in LDS so the update is in place with coalesced global traffic; the
+// amplitudes whose control bit is 0 are never touched (camodc_tile).
 // ---------------------------------------------------------------------------
 struct CamodcParams {
     unsigned M, logT;
     int      ctl;        // local bit index, or -1: control lives in the rank id and is 1
     unsigned C, d, Cd, inv;
-    uint64_t ntiles;     // tiles to process (control-set tiles only when ctl >= logT)
+    uint64_t ntiles;     // tiles to process (tiles hold control-set amplitudes only when ctl >= M)
 };
+
+// base of tile tt.  A tile is 2^logT amplitudes that all have the control bit SET: a control at or
+// above the M register is squeezed out of the tile numbering (whether it lies above the tile or inside it), so the
+// control-clear half of the vector is never read.  Runs stay >= 2^M amplitudes (the control is never below M here).
+__device__ __forceinline__ amp_t *camodc_tile(amp_t *amp, const CamodcParams &P, uint64_t tt)
+{
+    if (P.ctl >= (int)P.logT) {
+        const unsigned b = (unsigned)P.ctl - P.logT;
+        return amp + ((insert_zero(tt, b) | ((uint64_t)1 << b)) << P.logT);
+    }
+    if (P.ctl >= (int)P.M) return amp + (tt << (P.logT + 1));
+    return amp + (tt << P.logT);
+}
+// offset of tile element e from camodc_tile(): with the control inside the tile, e with a 1 inserted at the control bit
+__device__ __forceinline__ unsigned camodc_elem(bool squeeze, unsigned ctl, unsigned e)
+{
+    if (!squeeze) return e;
+    const unsigned low = (1u << ctl) - 1u;
+    return ((e & ~low) << 1) | (1u << ctl) | (e & low);
+}
 
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_camodc(amp_t *__restrict__ amp, CamodcParams P)
@@ -214,16 +234,15 @@ __global__ __launch_bounds__(BLOCK) void k_camodc(amp_t *__restrict__ amp, Camod
     extern __shared__ __attribute__((aligned(16))) unsigned char qcx_lds_raw[];
     amp_t *tile = reinterpret_cast<amp_t *>(qcx_lds_raw);
     const unsigned T = 1u << P.logT, blkmask = (1u << P.M) - 1u;
+    const bool squeeze = P.ctl >= (int)P.M && P.ctl < (int)P.logT;
     for (uint64_t tt = blockIdx.x; tt < P.ntiles; tt += gridDim.x) {
-        uint64_t tsel = tt;
-        if (P.ctl >= (int)P.logT) tsel = insert_zero(tt, (unsigned)P.ctl - P.logT) | ((uint64_t)1 << ((unsigned)P.ctl - P.logT));
-        amp_t *g = amp + (tsel << P.logT);
-        for (unsigned e = threadIdx.x; e < T; e += BLOCK) tile[e] = g[e];
+        amp_t *g = camodc_tile(amp, P, tt);
+        for (unsigned e = threadIdx.x; e < T; e += BLOCK) tile[e] = g[camodc_elem(squeeze, (unsigned)P.ctl, e)];
         __syncthreads();
         for (unsigned e = threadIdx.x; e < T; e += BLOCK) {
             const unsigned f = e & blkmask;
             bool on = true;
-            if (P.ctl >= 0 && P.ctl < (int)P.logT) on = (e >> P.ctl) & 1u;
+            if (P.ctl >= 0 && P.ctl < (int)P.M) on = (e >> P.ctl) & 1u;
             if (!on || f >= P.C) continue;                     // identity rows (Q:611-613, Q:631-634)
             amp_t acc; acc.x = 0.0; acc.y = 0.0;
             if (f % P.d == 0) {
@@ -231,7 +250,7 @@ __global__ __launch_bounds__(BLOCK) void k_camodc(amp_t *__restrict__ amp, Camod
                 const amp_t *blk = tile + (e - f);
                 for (unsigned t = 0; t < P.d; t++, src += P.Cd) { acc.x += blk[src].x; acc.y += blk[src].y; }
             }
-            g[e] = acc;
+            g[camodc_elem(squeeze, (unsigned)P.ctl, e)] = acc;
         }
         __syncthreads();
     }
@@ -247,22 +266,18 @@ __global__ __launch_bounds__(BLOCK) void k_camodc_table(amp_t *__restrict__ amp,
     extern __shared__ __attribute__((aligned(16))) unsigned char qcx_lds_raw[];
     amp_t *tile = reinterpret_cast<amp_t *>(qcx_lds_raw);
     const unsigned T = 1u << P.logT, blkmask = (1u << P.M) - 1u;
+    const bool squeeze = P.ctl >= (int)P.M && P.ctl < (int)P.logT;
     for (uint64_t tt = blockIdx.x; tt < P.ntiles; tt += gridDim.x) {
-        uint64_t tsel = tt;
-        if (P.ctl >= (int)P.logT) tsel = insert_zero(tt, (unsigned)P.ctl - P.logT) | ((uint64_t)1 << ((unsigned)P.ctl - P.logT));
-        amp_t *g = amp + (tsel << P.logT);
-        for (unsigned e = threadIdx.x; e < T; e += BLOCK) tile[e] = g[e];
+        amp_t *g = camodc_tile(amp, P, tt);
+        for (unsigned e = threadIdx.x; e < T; e += BLOCK) tile[e] = g[camodc_elem(squeeze, (unsigned)P.ctl, e)];
         __syncthreads();
         for (unsigned e = threadIdx.x; e < T; e += BLOCK) {
             const unsigned f = e & blkmask;
-            bool on = true;
-            if (P.ctl >= 0 && P.ctl < (int)P.logT) on = (e >> P.ctl) & 1u;
-            if (!on) continue;
-            // with the control inside the M register the source's own control bit decides
+            // (a control inside the M register is encoded in the table: the host passes ctl = -1 then)
             const amp_t *blk = tile + (e - f);
             amp_t acc; acc.x = 0.0; acc.y = 0.0;
             for (uint32_t k = off[f]; k < off[f + 1]; k++) { acc.x += blk[srcs[k]].x; acc.y += blk[srcs[k]].y; }
-            g[e] = acc;
+            g[camodc_elem(squeeze, (unsigned)P.ctl, e)] = acc;
         }
         __syncthreads();
     }

@@ -33,6 +33,8 @@ typedef struct {
     unsigned long seed;
     bool seed_given, ref_quirks, json, fusion, per_gate;
     const char *dump_final, *dump_circuit;
+    int gpus;                   /* -g N: shard the register over N GPUs (2, 4, 8, 16) from this one process */
+    const char *gpu_list;       /* -d "0,0,1,1": HIP device of each shard (default shard r on device r) */
 } Options;
 
 typedef struct {
@@ -41,7 +43,7 @@ typedef struct {
 } Stats;
 
 static const char *USAGE =
-    "Usage: qcx_shor -C num -L L_reg_size -M M_reg_size [-a trial_int | -f trial_int] [-v] [-V] [-s seed] [-Q] [-j] [-F | -G] [-o state_file] [-O state_file]\n";
+    "Usage: qcx_shor -C num -L L_reg_size -M M_reg_size [-a trial_int | -f trial_int] [-v] [-V] [-s seed] [-Q] [-j] [-F | -G] [-g gpus [-d dev,dev,...]] [-o state_file] [-O state_file]\n";
 
 static double now_seconds(void)
 {
@@ -55,7 +57,7 @@ static int parse_args(int argc, char **argv, Options *o)
     bool haveC = false, haveL = false, haveM = false;
     int ch;
     memset(o, 0, sizeof *o);
-    while ((ch = getopt(argc, argv, "C:L:M:a:f:s:o:O:vVQjFG")) != -1) {
+    while ((ch = getopt(argc, argv, "C:L:M:a:f:s:o:O:g:d:vVQjFG")) != -1) {
         switch (ch) {
         case 'C': o->C = (unsigned)atoi(optarg); haveC = true; break;
         case 'L': o->L = atoi(optarg); haveL = true; break;
@@ -68,6 +70,8 @@ static int parse_args(int argc, char **argv, Options *o)
         case 'j': o->json = true; break;
         case 'F': o->fusion = true; break;
         case 'G': o->per_gate = true; break;
+        case 'g': o->gpus = atoi(optarg); break;
+        case 'd': o->gpu_list = optarg; break;
         case 'o': o->dump_final = optarg; break;
         case 'O': o->dump_circuit = optarg; break;
         default: fputs(USAGE, stdout); return QCX_BAD_ARGUMENTS;
@@ -189,7 +193,14 @@ int main(int argc, char **argv)
     issue_warnings(o.C, o.L, o.M);
 
     qcx_register *reg = NULL;                                                    /* Q:1316-1324 */
-    s = qcx_register_create(o.L, o.M, &reg);
+    if (o.gpus > 1) {                       /* one process, N shards: the top log2 N qubits select the GPU */
+        int devs[16], nd = 0;
+        for (int i = 0; i < 16; i++) devs[i] = i;
+        for (const char *p = o.gpu_list; p && *p && nd < 16; nd++) { devs[nd] = atoi(p); while (*p && *p != ',') p++; if (*p == ',') p++; }
+        for (int i = nd; nd > 0 && i < 16; i++) devs[i] = devs[nd - 1];
+        s = qcx_register_create_sharded(o.L, o.M, (unsigned)o.gpus, devs, &reg);
+    } else
+        s = qcx_register_create(o.L, o.M, &reg);
     if (s != QCX_NO_ERROR) {
         fprintf(stderr, "Error: could not create the %d-qubit register on the GPU: %s.\n", o.L + o.M, qcx_status_string(s));
         qcx_rng_free(rng);
@@ -210,9 +221,12 @@ int main(int argc, char **argv)
     }
     if (o.json) {
         const double dim = (double)qcx_num_states(reg);
+        unsigned long exchanges = 0;
+        qcx_sharded_stats(reg, &exchanges, NULL);
         printf("{\"C\": %u, \"L\": %d, \"M\": %d, \"qubits\": %d, \"attempts\": %lu, \"gates\": %lu, \"seconds\": %.6f, "
-               "\"amplitude_updates_per_s\": %.6e, \"status\": %d}\n",
-               o.C, o.L, o.M, o.L + o.M, st.attempts, st.gates, dt, dt > 0 ? (double)st.gates * dim / dt : 0.0, s);
+               "\"amplitude_updates_per_s\": %.6e, \"shards\": %u, \"exchanges\": %lu, \"status\": %d}\n",
+               o.C, o.L, o.M, o.L + o.M, st.attempts, st.gates, dt, dt > 0 ? (double)st.gates * dim / dt : 0.0,
+               qcx_register_shards(reg), exchanges, s);
     }
     qcx_register_destroy(reg);                                                   /* Q:1330-1333 */
     qcx_rng_free(rng);

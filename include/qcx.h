@@ -66,6 +66,16 @@ unsigned      qcx_num_qubits(const qcx_register *reg);   /* Register.num_qubits 
 unsigned long qcx_num_states(const qcx_register *reg);   /* Register.num_states */
 int  qcx_L_size(const qcx_register *reg);
 int  qcx_M_size(const qcx_register *reg);
+/* The same register sharded over `nshards` = 2, 4, 8 or 16 GPUs by THIS process (shard = top log2(nshards)
+ * index bits).  The handle is an ordinary qcx_register: every function of this header works on it, so the reference's
+ * circuit builders and main (Q:678-737, Q:1284-1347) run unchanged on the 8 GPUs of a node.  A Hadamard on a qubit held
+ * in the shard id costs one exchange: each GPU's pack pass stores straight into its peers' buffers over xGMI.
+ * devices[r] = HIP device of shard r (NULL: shard r on device r; entries may repeat: several shards on one GPU).
+ * Setting QCX_SHARDS=N in the environment makes qcx_register_create do this by itself (QCX_SHARD_DEVICES="0,1,..").
+ * Not available on a sharded register: qcx_register_set_stream, qcx_device_pointer (NULL), the event pool. */
+int  qcx_register_create_sharded(int L_size, int M_size, unsigned nshards, const int *devices, qcx_register **out);
+unsigned qcx_register_shards(const qcx_register *reg);      /* 1 for an unsharded register */
+int  qcx_sharded_stats(qcx_register *reg, unsigned long *exchanges, unsigned long *pack_passes);
 /* launch on a caller-owned hipStream_t (NULL = the register's own stream) */
 int  qcx_register_set_stream(qcx_register *reg, void *hip_stream);
 int  qcx_synchronize(qcx_register *reg);
@@ -167,6 +177,8 @@ typedef struct {
     uint32_t C, A;      /* modular multiply: modulus and multiplier (A < C) */
 } qcx_gate_desc;
 int  qcx_shard_run_fused(void *amp, unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates, void *stream);
+/* qcx_shard_run_fused keeps record buffers per (device, stream); call this before destroying a stream it was used on */
+int  qcx_shard_release_stream(void *stream);
 
 /* The pass planner alone, on the host (no GPU needed; test and tooling interface).  Cuts a gate list into actions --
  * fused passes over LDS tiles, or single gates that run as their stand-alone kernel -- and returns the records the

@@ -33,6 +33,9 @@ SIGNATURES = {
     "qcx_set_device": (_i, [_i]),
     "qcx_register_create": (_i, [_i, _i, C.POINTER(_p)]),
     "qcx_register_destroy": (_i, [_p]),
+    "qcx_register_create_sharded": (_i, [_i, _i, _u, C.POINTER(_i), C.POINTER(_p)]),
+    "qcx_register_shards": (_u, [_p]),
+    "qcx_sharded_stats": (_i, [_p, C.POINTER(_ul), C.POINTER(_ul)]),
     "qcx_num_qubits": (_u, [_p]),
     "qcx_num_states": (_ul, [_p]),
     "qcx_L_size": (_i, [_p]),
@@ -76,6 +79,7 @@ SIGNATURES = {
     "qcx_shard_swap_bits": (_i, [_p, _p, _u, _u, C.POINTER(_u), C.POINTER(_u), _p]),
     "qcx_shard_norm2": (_i, [_p, _u, C.POINTER(_d), _p]),
     "qcx_shard_run_fused": (_i, [_p, _u, _u, _u, _p, _p]),
+    "qcx_shard_release_stream": (_i, [_p]),
     "qcx_state_save": (_i, [_p, C.c_char_p]),
     "qcx_state_load": (_i, [_p, C.c_char_p]),
     "qcx_fusion_plan": (_i, [_u, _u, _u, _p, _p, _u, C.POINTER(_u), _p, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -87,6 +91,9 @@ _EXTRA = {
     "qcx_tune_set": (_i, [C.c_char_p, C.c_long]),
     "qcx_tune_get": (C.c_long, [C.c_char_p]),
     "qcx_measure_last_stats": (_i, [C.POINTER(_u), C.POINTER(_u)]),
+    "qcx_sharded_trace": (_i, [_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "qcx_sharded_restore_identity": (_i, [_p]),
+    "qcx_sharded_layout": (_i, [_p, C.POINTER(_u), _u]),
 }
 
 class GateDesc(C.Structure):

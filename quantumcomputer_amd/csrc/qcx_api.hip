@@ -13,7 +13,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
 #include <mutex>
+#include <string>
+#include <utility>
 #include <vector>
 
 using namespace qcx;
@@ -637,11 +640,13 @@ struct qcx_register {
     int        fusion;          // 1: every gate call is queued (fused passes, qcx_fuse.inc.h); 0: only the whole-circuit entry points; -1: nothing
     int        composite;       // > 0 while a whole-circuit entry point is queueing its gates
     struct GateQueue *queue;
+    struct ShardSet *sh;     // non-null: the register is sharded over several GPUs by this process (qcx_sharded.inc.h)
 };
 
 static int reg_camodc(qcx_register *r, unsigned C, unsigned A, unsigned ctl);
 
 #include "qcx_fuse.inc.h"
+#include "qcx_sharded.inc.h"
 
 #define FLUSH(r) QCX_TRY(fuse_flush(r))
 
@@ -706,10 +711,74 @@ static int reg_camodc(qcx_register *r, unsigned C, unsigned A, unsigned ctl)
     return qcx_shard_camodc(r->amp, r->n, (unsigned)r->M, C, A, (int)ctl, r->stream);
 }
 
+extern "C" int qcx_register_create_sharded(int L, int M, unsigned nshards, const int *devices, qcx_register **out)
+{
+    if (!out) return QCX_BAD_ARGUMENTS;
+    *out = nullptr;
+    if (L < 0 || M < 0 || L + M < 1 || L + M > 40) return QCX_BAD_ARGUMENTS;
+    if (nshards == 1 && !(devices && devices[0] < 0)) {
+        if (devices) QCX_TRY(qcx_set_device(devices[0]));
+        return qcx_register_create(L, M, out);
+    }
+    qcx_register *r = (qcx_register *)calloc(1, sizeof(qcx_register));
+    if (!r) return QCX_INSUFFICIENT_MEMORY;
+    r->L = L; r->M = M; r->n = (unsigned)(L + M); r->dim = (uint64_t)1 << r->n;
+    const int s = sh_create(L, M, nshards, devices, &r->sh);
+    if (s != QCX_NO_ERROR) { free(r); return s; }
+    if (!r->sh->dry && (hipEventCreate(&r->ev0) != hipSuccess || hipEventCreate(&r->ev1) != hipSuccess)) { sh_free(r->sh); free(r); return QCX_HIP_ERROR; }
+    *out = r;
+    return QCX_NO_ERROR;
+}
+
+extern "C" unsigned qcx_register_shards(const qcx_register *r) { return r ? (r->sh ? r->sh->W : 1u) : 0u; }
+
+extern "C" int qcx_sharded_stats(qcx_register *r, unsigned long *exchanges, unsigned long *pack_passes)
+{
+    if (!r) return QCX_BAD_ARGUMENTS;
+    if (exchanges) *exchanges = r->sh ? r->sh->exchanges : 0;
+    if (pack_passes) *pack_passes = r->sh ? r->sh->pack_passes : 0;
+    return QCX_NO_ERROR;
+}
+
+// diagnostics (not in the public header): the step list a dry-run register has scheduled since the last call, and the
+// restoration of the identity layout on demand (measurement and read-back do it themselves)
+extern "C" int qcx_sharded_trace(qcx_register *r, char *buf, size_t cap, size_t *need)
+{
+    if (!r || !r->sh || !need) return QCX_BAD_ARGUMENTS;
+    *need = r->sh->trace.size() + 1;
+    if (!buf || cap < *need) return QCX_INSUFFICIENT_MEMORY;
+    memcpy(buf, r->sh->trace.c_str(), *need);
+    r->sh->trace.clear();
+    return QCX_NO_ERROR;
+}
+extern "C" int qcx_sharded_restore_identity(qcx_register *r) { return (r && r->sh) ? sh_identity(r->sh) : QCX_BAD_ARGUMENTS; }
+extern "C" int qcx_sharded_layout(qcx_register *r, unsigned *perm, unsigned cap)
+{
+    if (!r || !r->sh || !perm || cap < r->n) return QCX_BAD_ARGUMENTS;
+    for (unsigned q = 0; q < r->n; q++) perm[q] = r->sh->perm[q];
+    return QCX_NO_ERROR;
+}
+
 extern "C" int qcx_register_create(int L, int M, qcx_register **out)
 {
     if (!out) return QCX_BAD_ARGUMENTS;
     *out = nullptr;
+    // QCX_SHARDS=N (N = 2, 4, 8, 16): every register this process creates is sharded over N devices -- how a program
+    // written against the reference's interface (qcx_compat.h, host/qcx_shor) gets onto the 8 GPUs of a node without
+    // an edit.  QCX_SHARD_DEVICES="0,0,1,1" places the shards (default: shard r on device r).
+    if (const char *e = getenv("QCX_SHARDS")) {
+        const int ns = atoi(e);
+        if (ns > 1) {
+            int devs[16];
+            for (int i = 0; i < 16; i++) devs[i] = i;
+            if (const char *d = getenv("QCX_SHARD_DEVICES")) {
+                int i = 0;
+                for (const char *p = d; *p && i < 16; i++) { devs[i] = atoi(p); while (*p && *p != ',') p++; if (*p == ',') p++; }
+                if (i < ns && i < 16) for (int j = i; j < 16; j++) devs[j] = devs[i ? i - 1 : 0];
+            }
+            return qcx_register_create_sharded(L, M, (unsigned)ns, devs, out);
+        }
+    }
     if (L < 0 || M < 0 || L + M < 1 || L + M > 36) return QCX_BAD_ARGUMENTS;
     int ndev = 0;
     QCX_TRY(qcx_device_count(&ndev));
@@ -719,12 +788,23 @@ extern "C" int qcx_register_create(int L, int M, qcx_register **out)
     r->L = L; r->M = M; r->n = (unsigned)(L + M); r->dim = (uint64_t)1 << r->n;
     hipError_t e = hipMalloc(&r->amp, r->dim * sizeof(amp_t));
     if (e != hipSuccess) { free(r); snprintf(g_last_error, sizeof g_last_error, "hipMalloc: %s", hipGetErrorString(e)); return QCX_INSUFFICIENT_MEMORY; }
-    if (hipStreamCreate(&r->own_stream) != hipSuccess || hipEventCreate(&r->ev0) != hipSuccess || hipEventCreate(&r->ev1) != hipSuccess) {
-        (void)hipFree(r->amp); free(r); return QCX_HIP_ERROR;
-    }
+    // (each step is undone on a later failure: nothing of a half-built register stays behind)
+    bool ok = hipStreamCreate(&r->own_stream) == hipSuccess;
+    const bool have_stream = ok;
+    const bool have_ev0 = ok && hipEventCreate(&r->ev0) == hipSuccess;
+    const bool have_ev1 = have_ev0 && hipEventCreate(&r->ev1) == hipSuccess;
+    ok = have_ev1;
     r->stream = r->own_stream;
     // the reference's buffers start zeroed by calloc-like GSL allocs only after reset; be deterministic
-    if (hipMemsetAsync(r->amp, 0, r->dim * sizeof(amp_t), r->stream) != hipSuccess) { (void)hipFree(r->amp); free(r); return QCX_HIP_ERROR; }
+    if (ok && hipMemsetAsync(r->amp, 0, r->dim * sizeof(amp_t), r->stream) != hipSuccess) ok = false;
+    if (!ok) {
+        snprintf(g_last_error, sizeof g_last_error, "qcx_register_create: %s", hipGetErrorString(hipGetLastError()));
+        if (have_ev1) (void)hipEventDestroy(r->ev1);
+        if (have_ev0) (void)hipEventDestroy(r->ev0);
+        if (have_stream) (void)hipStreamDestroy(r->own_stream);
+        (void)hipFree(r->amp); free(r);
+        return QCX_HIP_ERROR;
+    }
     *out = r;
     return QCX_NO_ERROR;
 }
@@ -732,6 +812,13 @@ extern "C" int qcx_register_create(int L, int M, qcx_register **out)
 extern "C" int qcx_register_destroy(qcx_register *r)
 {
     if (!r) return QCX_NO_ERROR;
+    if (r->sh) {
+        const bool dry = r->sh->dry;
+        sh_free(r->sh);
+        if (!dry) { (void)hipEventDestroy(r->ev0); (void)hipEventDestroy(r->ev1); }
+        free(r);
+        return QCX_NO_ERROR;
+    }
     (void)fuse_flush(r);
     (void)hipStreamSynchronize(r->stream);
     queue_free(r->queue);
@@ -749,11 +836,34 @@ extern "C" unsigned qcx_num_qubits(const qcx_register *r) { return r ? r->n : 0;
 extern "C" unsigned long qcx_num_states(const qcx_register *r) { return r ? (unsigned long)r->dim : 0; }
 extern "C" int qcx_L_size(const qcx_register *r) { return r ? r->L : 0; }
 extern "C" int qcx_M_size(const qcx_register *r) { return r ? r->M : 0; }
-extern "C" void *qcx_device_pointer(qcx_register *r) { if (r) (void)fuse_flush(r); return r ? (void *)r->amp : nullptr; }
+extern "C" void *qcx_device_pointer(qcx_register *r) { if (!r || r->sh) return nullptr; (void)fuse_flush(r); return (void *)r->amp; }
 
-// shard-level gate list through the fusion scheduler (one queue per device, one user at a time)
-static GateQueue *g_shard_queue[64];
-static std::mutex g_shard_queue_mutex[64];
+// shard-level gate list through the fusion scheduler: one queue (record buffers + the event that guards them) per
+// (device, stream), one user at a time.  A queue's event is only ever recorded on its own stream; the owner of a
+// stream drops the queue before destroying the stream (qcx_shard_release_stream) -- an event whose last record was on
+// a destroyed stream must not be synchronised any more.
+struct ShardQueue { GateQueue q; std::mutex use; };
+static std::mutex g_shard_queue_mutex;
+static std::map<std::pair<int, hipStream_t>, ShardQueue *> g_shard_queues;
+
+extern "C" int qcx_shard_release_stream(void *stream)
+{
+    std::vector<ShardQueue *> gone;
+    {
+        std::lock_guard<std::mutex> lock(g_shard_queue_mutex);
+        for (auto it = g_shard_queues.begin(); it != g_shard_queues.end();)
+            if (it->first.second == (hipStream_t)stream) { gone.push_back(it->second); it = g_shard_queues.erase(it); } else ++it;
+    }
+    for (ShardQueue *sq : gone) {
+        std::lock_guard<std::mutex> use(sq->use);
+        if (sq->q.ev_valid) { (void)hipEventSynchronize(sq->q.ev); (void)hipEventDestroy(sq->q.ev); sq->q.ev_valid = false; }
+        if (sq->q.d_ops) (void)hipFree(sq->q.d_ops);
+        if (sq->q.h_ops) (void)hipHostFree(sq->q.h_ops);
+        sq->q.d_ops = nullptr; sq->q.h_ops = nullptr;
+    }
+    for (ShardQueue *sq : gone) delete sq;
+    return QCX_NO_ERROR;
+}
 
 static int descs_to_gates(unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates, std::vector<QGate> &out)
 {
@@ -786,13 +896,19 @@ extern "C" int qcx_shard_run_fused(void *amp, unsigned n_local, unsigned M, unsi
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return QCX_HIP_ERROR;
-    std::lock_guard<std::mutex> lock(g_shard_queue_mutex[dev]);
-    if (!g_shard_queue[dev]) g_shard_queue[dev] = new GateQueue();
+    ShardQueue *sq;
+    {
+        std::lock_guard<std::mutex> lock(g_shard_queue_mutex);
+        ShardQueue *&slot = g_shard_queues[std::make_pair(dev, (hipStream_t)stream)];
+        if (!slot) slot = new ShardQueue();
+        sq = slot;
+    }
+    std::lock_guard<std::mutex> use(sq->use);
     qcx_register tmp;
     memset(&tmp, 0, sizeof tmp);
     tmp.L = (int)(n_local - M); tmp.M = (int)M; tmp.n = n_local; tmp.dim = (uint64_t)1 << n_local;
     tmp.amp = (amp_t *)amp; tmp.stream = tmp.own_stream = (hipStream_t)stream;
-    tmp.fusion = 1; tmp.queue = g_shard_queue[dev];
+    tmp.fusion = 1; tmp.queue = &sq->q;
     tmp.queue->gates.clear();
     QCX_TRY(descs_to_gates(n_local, M, count, gates, tmp.queue->gates));
     return fuse_flush(&tmp);
@@ -842,6 +958,7 @@ extern "C" int qcx_fusion_plan(unsigned n_local, unsigned M, unsigned count, con
 extern "C" int qcx_set_fusion(qcx_register *r, int enable)
 {
     if (!r) return QCX_BAD_ARGUMENTS;
+    if (r->sh) { QCX_TRY(sh_flush(r->sh)); r->sh->fusion = enable >= 0 ? 1 : -1; return QCX_NO_ERROR; }   // (gates are always queued; -1 = one launch per gate)
     FLUSH(r);
     r->fusion = enable > 0 ? 1 : (enable < 0 ? -1 : 0);
     return QCX_NO_ERROR;
@@ -850,6 +967,7 @@ extern "C" int qcx_set_fusion(qcx_register *r, int enable)
 extern "C" int qcx_flush(qcx_register *r)
 {
     if (!r) return QCX_BAD_ARGUMENTS;
+    if (r->sh) return sh_flush(r->sh);
     FLUSH(r);
     return QCX_NO_ERROR;
 }
@@ -857,6 +975,7 @@ extern "C" int qcx_flush(qcx_register *r)
 extern "C" int qcx_fusion_stats(qcx_register *r, unsigned long *passes, unsigned long *gates)
 {
     if (!r) return QCX_BAD_ARGUMENTS;
+    if (r->sh) { if (passes) *passes = 0; if (gates) *gates = 0; return QCX_NO_ERROR; }     // (per-device queues: see qcx_sharded_stats)
     if (passes) *passes = r->queue ? r->queue->passes_launched : 0;
     if (gates) *gates = r->queue ? r->queue->gates_fused : 0;
     return QCX_NO_ERROR;
@@ -865,6 +984,7 @@ extern "C" int qcx_fusion_stats(qcx_register *r, unsigned long *passes, unsigned
 extern "C" int qcx_register_set_stream(qcx_register *r, void *hip_stream)
 {
     if (!r) return QCX_BAD_ARGUMENTS;
+    if (r->sh) return QCX_UNSUPPORTED;                 // one stream per shard, owned by the register
     FLUSH(r);
     HIP_TRY(hipStreamSynchronize(r->stream));
     r->stream = hip_stream ? (hipStream_t)hip_stream : r->own_stream;
@@ -874,6 +994,7 @@ extern "C" int qcx_register_set_stream(qcx_register *r, void *hip_stream)
 extern "C" int qcx_synchronize(qcx_register *r)
 {
     if (!r) return QCX_BAD_ARGUMENTS;
+    if (r->sh) return sh_sync(r->sh);
     FLUSH(r);
     HIP_TRY(hipStreamSynchronize(r->stream));
     return QCX_NO_ERROR;
@@ -882,6 +1003,7 @@ extern "C" int qcx_synchronize(qcx_register *r)
 extern "C" int qcx_reset_register(qcx_register *r)
 {
     if (!r) return QCX_BAD_ARGUMENTS;
+    if (r->sh) return sh_reset(r->sh);
     if (r->queue) r->queue->gates.clear();         // pending gates act on a state that is being overwritten
     return qcx_shard_reset(r->amp, r->n, 1, r->stream);
 }
@@ -890,6 +1012,7 @@ extern "C" int qcx_hadamard_gate(unsigned q, qcx_register *r)
 {
     if (!r) return QCX_BAD_ARGUMENTS;
     if (q >= r->n) return QCX_BAD_QUBIT;
+    if (r->sh) { SGate g; memset(&g, 0, sizeof g); g.type = FUSE_H; g.q = q; return sh_push(r->sh, g); }
     if (r->fusion > 0 || r->composite) { QGate g; memset(&g, 0, sizeof g); g.type = FUSE_H; g.q = q; return fuse_push(r, g); }
     return qcx_shard_hadamard(r->amp, r->n, q, r->stream);
 }
@@ -912,6 +1035,7 @@ extern "C" int qcx_c_phase_shift_gate(unsigned c, unsigned t, double theta, qcx_
     if (c >= r->n || t >= r->n || c == t) return QCX_BAD_QUBIT;
     double er, ei;
     qcx_polar(theta, &er, &ei);
+    if (r->sh) { SGate g; memset(&g, 0, sizeof g); g.type = FUSE_PHASE; g.q = c; g.q2 = t; g.c = er; g.s = ei; return sh_push(r->sh, g); }
     if (r->fusion > 0 || r->composite) {
         QGate g; memset(&g, 0, sizeof g);
         g.type = FUSE_PHASE; g.mask = ((uint64_t)1 << c) | ((uint64_t)1 << t); g.c = er; g.s = ei;
@@ -924,6 +1048,7 @@ extern "C" int qcx_c_amodc_gate(unsigned C, unsigned long long atox, unsigned c,
 {
     if (!r || C == 0) return QCX_BAD_ARGUMENTS;
     if (c >= r->n) return QCX_BAD_QUBIT;
+    if (r->sh) { SGate g; memset(&g, 0, sizeof g); g.type = FUSE_CAMODC; g.q = c; g.C = C; g.A = (unsigned)(atox % C); return sh_push(r->sh, g); }
     if (r->fusion > 0 || r->composite) {
         QGate g; memset(&g, 0, sizeof g);
         g.q = c; g.C = C; g.A = (unsigned)(atox % C);
@@ -941,7 +1066,7 @@ extern "C" int qcx_swap_states(qcx_register *r) { return r ? QCX_NO_ERROR : QCX_
 struct CircuitScope {
     qcx_register *r;
     bool mine;
-    explicit CircuitScope(qcx_register *r_) : r(r_), mine(r_->fusion == 0) { if (mine) r->composite++; }
+    explicit CircuitScope(qcx_register *r_) : r(r_), mine(!r_->sh && r_->fusion == 0) { if (mine) r->composite++; }
     int done(int status)
     {
         if (!mine) return status;
@@ -1007,6 +1132,7 @@ static int quantum_computation_body(unsigned C, unsigned a, int intpow_mode, qcx
 extern "C" int qcx_measure_state_r(qcx_register *r, double rnd, unsigned long *state_num)
 {
     if (!r || !state_num) return QCX_BAD_ARGUMENTS;
+    if (r->sh) return sh_measure(r->sh, rnd, state_num);
     FLUSH(r);
     int found = 0; uint64_t idx = 0; double cum = 0.0;
     QCX_TRY(qcx_shard_measure_scan(r->amp, r->n, 0, r->dim - 1, 0.0, rnd, &found, &idx, &cum, r->stream));
@@ -1026,6 +1152,7 @@ extern "C" int qcx_state_read(qcx_register *r, unsigned long first, unsigned lon
 {
     if (!r || (!out && count)) return QCX_BAD_ARGUMENTS;
     if ((uint64_t)first > r->dim || (uint64_t)count > r->dim - first) return QCX_BAD_ARGUMENTS;
+    if (r->sh) return sh_copy(r->sh, first, count, out, true);
     FLUSH(r);
     HIP_TRY(hipStreamSynchronize(r->stream));
     if (count) HIP_TRY(hipMemcpy(out, r->amp + first, (size_t)count * sizeof(amp_t), hipMemcpyDeviceToHost));
@@ -1036,6 +1163,7 @@ extern "C" int qcx_state_write(qcx_register *r, unsigned long first, unsigned lo
 {
     if (!r || (!in && count)) return QCX_BAD_ARGUMENTS;
     if ((uint64_t)first > r->dim || (uint64_t)count > r->dim - first) return QCX_BAD_ARGUMENTS;
+    if (r->sh) return sh_copy(r->sh, first, count, const_cast<double *>(in), false);
     FLUSH(r);
     HIP_TRY(hipStreamSynchronize(r->stream));
     if (count) HIP_TRY(hipMemcpy(r->amp + first, in, (size_t)count * sizeof(amp_t), hipMemcpyHostToDevice));
@@ -1067,8 +1195,7 @@ static uint64_t fnv1a64(const unsigned char *p, size_t len, uint64_t h)
 extern "C" int qcx_state_save(qcx_register *r, const char *path)
 {
     if (!r || !path) return QCX_BAD_ARGUMENTS;
-    FLUSH(r);
-    HIP_TRY(hipStreamSynchronize(r->stream));
+    if (r->sh) QCX_TRY(sh_identity(r->sh)); else { FLUSH(r); HIP_TRY(hipStreamSynchronize(r->stream)); }
     FILE *f = fopen(path, "wb");
     if (!f) { set_error("qcx_state_save: cannot open %s", path); return QCX_BAD_ARGUMENTS; }
     StateFileHeader h;
@@ -1083,7 +1210,8 @@ extern "C" int qcx_state_save(qcx_register *r, const char *path)
     if (fwrite(&h, sizeof h, 1, f) != 1) st = QCX_UNKNOWN_ERROR;
     for (uint64_t at = 0; st == QCX_NO_ERROR && at < r->dim; at += chunk) {
         const size_t cnt = (size_t)std::min<uint64_t>(chunk, r->dim - at);
-        if (hipMemcpy(stage, r->amp + at, cnt * sizeof(amp_t), hipMemcpyDeviceToHost) != hipSuccess) { st = QCX_HIP_ERROR; break; }
+        if (r->sh ? sh_copy(r->sh, at, cnt, (double *)stage, true) != QCX_NO_ERROR
+                  : hipMemcpy(stage, r->amp + at, cnt * sizeof(amp_t), hipMemcpyDeviceToHost) != hipSuccess) { st = QCX_HIP_ERROR; break; }
         sum = fnv1a64((const unsigned char *)stage, cnt * sizeof(amp_t), sum);
         if (fwrite(stage, sizeof(amp_t), cnt, f) != cnt) st = QCX_UNKNOWN_ERROR;
     }
@@ -1100,8 +1228,7 @@ extern "C" int qcx_state_save(qcx_register *r, const char *path)
 extern "C" int qcx_state_load(qcx_register *r, const char *path)
 {
     if (!r || !path) return QCX_BAD_ARGUMENTS;
-    FLUSH(r);
-    HIP_TRY(hipStreamSynchronize(r->stream));
+    if (r->sh) QCX_TRY(sh_identity(r->sh)); else { FLUSH(r); HIP_TRY(hipStreamSynchronize(r->stream)); }
     FILE *f = fopen(path, "rb");
     if (!f) { set_error("qcx_state_load: cannot open %s", path); return QCX_BAD_ARGUMENTS; }
     StateFileHeader h;
@@ -1121,7 +1248,8 @@ extern "C" int qcx_state_load(qcx_register *r, const char *path)
         const size_t cnt = (size_t)std::min<uint64_t>(chunk, r->dim - at);
         if (fread(stage, sizeof(amp_t), cnt, f) != cnt) { st = QCX_UNKNOWN_ERROR; break; }
         sum = fnv1a64((const unsigned char *)stage, cnt * sizeof(amp_t), sum);
-        if (hipMemcpy(r->amp + at, stage, cnt * sizeof(amp_t), hipMemcpyHostToDevice) != hipSuccess) st = QCX_HIP_ERROR;
+        if (r->sh ? sh_copy(r->sh, at, cnt, (double *)stage, false) != QCX_NO_ERROR
+                  : hipMemcpy(r->amp + at, stage, cnt * sizeof(amp_t), hipMemcpyHostToDevice) != hipSuccess) st = QCX_HIP_ERROR;
     }
     (void)hipHostFree(stage);
     fclose(f);
@@ -1133,6 +1261,7 @@ extern "C" int qcx_state_load(qcx_register *r, const char *path)
 extern "C" int qcx_norm2(qcx_register *r, double *out)
 {
     if (!r || !out) return QCX_BAD_ARGUMENTS;
+    if (r->sh) return sh_norm2(r->sh, out);
     FLUSH(r);
     return qcx_shard_norm2(r->amp, r->n, out, r->stream);
 }
@@ -1140,6 +1269,7 @@ extern "C" int qcx_norm2(qcx_register *r, double *out)
 extern "C" int qcx_state_fill_random(qcx_register *r, uint64_t seed)
 {
     if (!r) return QCX_BAD_ARGUMENTS;
+    if (r->sh) return sh_fill_random(r->sh, seed);
     if (r->queue) r->queue->gates.clear();
     // U(-0.5, 0.5) components have variance 1/12: this scale makes the expected norm 1
     return qcx_shard_fill_random(r->amp, r->n, 0, seed, sqrt(6.0 / (double)r->dim), r->stream);
@@ -1150,6 +1280,7 @@ extern "C" int qcx_state_fill_random(qcx_register *r, uint64_t seed)
 extern "C" int qcx_events_create(qcx_register *r, unsigned count)
 {
     if (!r || count > 65536) return QCX_BAD_ARGUMENTS;
+    if (r->sh) return QCX_UNSUPPORTED;               // per-gate event pools are a single-GPU bench tool; use qcx_timer_start/stop
     for (unsigned i = 0; i < r->n_events; i++) (void)hipEventDestroy(r->events[i]);
     free(r->events);
     r->events = nullptr; r->n_events = 0;
@@ -1181,6 +1312,13 @@ extern "C" int qcx_event_elapsed(qcx_register *r, unsigned from_slot, unsigned t
 extern "C" int qcx_timer_start(qcx_register *r)
 {
     if (!r) return QCX_BAD_ARGUMENTS;
+    if (r->sh) {                                     // all shards idle, then the start event on shard 0's stream
+        if (r->sh->dry) return QCX_UNSUPPORTED;
+        QCX_TRY(sh_sync(r->sh));
+        HIP_TRY(hipSetDevice(r->sh->dev[0]));
+        HIP_TRY(hipEventRecord(r->ev0, r->sh->st[0]));
+        return QCX_NO_ERROR;
+    }
     FLUSH(r);
     HIP_TRY(hipEventRecord(r->ev0, r->stream));
     return QCX_NO_ERROR;
@@ -1189,6 +1327,17 @@ extern "C" int qcx_timer_start(qcx_register *r)
 extern "C" int qcx_timer_stop(qcx_register *r, double *ms)
 {
     if (!r || !ms) return QCX_BAD_ARGUMENTS;
+    if (r->sh) {                                     // everything queued has run on every shard, then the stop event
+        if (r->sh->dry) return QCX_UNSUPPORTED;
+        QCX_TRY(sh_sync(r->sh));
+        HIP_TRY(hipSetDevice(r->sh->dev[0]));
+        HIP_TRY(hipEventRecord(r->ev1, r->sh->st[0]));
+        HIP_TRY(hipEventSynchronize(r->ev1));
+        float f = 0.f;
+        HIP_TRY(hipEventElapsedTime(&f, r->ev0, r->ev1));
+        *ms = (double)f;
+        return QCX_NO_ERROR;
+    }
     FLUSH(r);
     HIP_TRY(hipEventRecord(r->ev1, r->stream));
     HIP_TRY(hipEventSynchronize(r->ev1));

@@ -1330,6 +1330,36 @@ __global__ __launch_bounds__(BLOCK) void k_swap_bits(const amp_t *__restrict__ s
 }
 
 // ---------------------------------------------------------------------------
+// X1b  pack + trade in ONE pass, for a sharded register whose shards live in one process (qcx_sharded.inc.h): shard
+// `me` of W = 2^k reads its own buffer and writes every amplitude straight into the buffer of the shard that owns it
+// after the trade -- peer stores over xGMI when that shard is on another GPU, so the pack pass IS the transfer:
+//     j = chunk << zone_lo | low   (chunk = the k trade-zone bits = destination shard)
+//     dst[chunk][me << zone_lo | low] = src[j with the bit pairs of S exchanged]
+// Blocks are dealt round-robin over the destination shards (block b -> chunk b mod W), so that all W - 1 links of a
+// GPU carry traffic at the same time instead of one after the other.  Stores are 1 KiB per wave instruction,
+// contiguous in the destination.
+// ---------------------------------------------------------------------------
+struct PushDst { amp_t *dst[16]; };
+
+template <int BLOCK, bool DEAL>     // DEAL needs BLOCK | 2^zone_lo; small shards take the plain element order
+__global__ __launch_bounds__(BLOCK) void k_pack_push(const amp_t *__restrict__ src, PushDst D, uint64_t count, SwapBits S,
+                                                       unsigned zone_lo, unsigned klog, unsigned me)
+{
+    const unsigned W = 1u << klog;
+    for (uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; t < count; t += (uint64_t)gridDim.x * BLOCK) {
+        unsigned chunk; uint64_t low;
+        if (DEAL) { const uint64_t b = t / BLOCK; chunk = (unsigned)(b & (W - 1)); low = (b >> klog) * BLOCK + threadIdx.x; }
+        else { chunk = (unsigned)(t >> zone_lo); low = t & (((uint64_t)1 << zone_lo) - 1); }
+        uint64_t i = ((uint64_t)chunk << zone_lo) | low;
+        for (unsigned m = 0; m < S.npairs; m++) {
+            const uint64_t x = ((i >> S.a[m]) ^ (i >> S.b[m])) & 1u;
+            i ^= (x << S.a[m]) | (x << S.b[m]);
+        }
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), D.dst[chunk] + (((uint64_t)me << zone_lo) | low));
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K3b  controlled modular multiply for M registers too large for an LDS tile (M > 12): out of place,
 // dst = gate(src), the caller swaps the two buffers afterwards (the reference's swap_states, Q:242-249).
 // Sources are gathered straight from HBM/L2 (16-B reads inside a 2^M block), so this path is correct

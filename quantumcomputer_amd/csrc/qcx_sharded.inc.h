@@ -1,0 +1,488 @@
+// qcx_sharded.inc.h -- a register sharded over the GPUs of one node by ONE host process.
+// Included into qcx_api.hip after struct qcx_register and the fusion queue.
+//
+// north_star: "the state vector shards across the 8 GPUs of one node by the top 3 qubit indices ... host code stays
+// in C".  This is the C side of that: qcx_register_create_sharded() returns an ordinary qcx_register*, so every entry
+// point of include/qcx.h -- and with it the reference's own circuit builders through qcx_compat.h, Q:678-737, and its
+// main, Q:1284-1347 -- drives W = 2^k shards without knowing.  (quantumcomputer_amd/sharded.py is the other host for
+// the same kernels: one PROCESS per GPU with the exchange as an RCCL all-to-all, which is what bench.py --gpus N runs.)
+//
+// Layout: shard r holds the 2^(n-k) amplitudes whose top k PHYSICAL index bits are r; a logical -> physical qubit
+// permutation lives on the host.
+//   * H on a physically local qubit, every controlled phase (diagonal) and the controlled modular multiply (permutes
+//     only the low M bits, which never move) touch no other shard: a control that sits in the shard id is a per-shard
+//     constant -- shards where it is 0 skip the gate.
+//   * H on a physically global qubit is the one exchange step: all k shard-id bits are traded for k local bits at
+//     once.  Every GPU runs ONE kernel (k_pack_push) that brings the bits to give up to the top of the local index
+//     AND writes each amplitude straight into the buffer of the GPU that owns it afterwards -- peer stores over xGMI,
+//     all 7 links of a GPU busy together, no staging buffer, no second pass.  Which local qubits to give up is
+//     decided with look-ahead over the queued gates (Belady: those whose next H lies furthest in the future).
+//   * measurement hands the exact running sum from shard to shard in index order (the index the unsharded scan
+//     would pick); norm and read-back flush the queue; measurement and read-back restore the identity layout.
+// Shards may share a device ("virtual" shards: several entries of `devices` equal) -- that is how the path is tested
+// on a one-GPU box; the code is the same, peer stores become local stores.
+// With devices[0] = -1 the register is a DRY RUN: no device memory, no launches; the schedule it would execute is
+// recorded as text (qcx_sharded_trace) and replayed against the oracle by the CPU-only tests.
+
+struct SGate {
+    uint32_t type;            // FUSE_H: H(q); FUSE_PHASE: phase on (q, q2) with (c, s); FUSE_CAMODC: modular multiply, control q
+    unsigned q, q2;           // LOGICAL qubits
+    double   c, s;
+    unsigned C, A;
+};
+
+struct ShardSet {
+    unsigned k = 0, W = 1, n = 0, n_local = 0, M = 0;
+    int      L = 0;
+    bool     dry = false;
+    std::vector<int>         dev;
+    std::vector<hipStream_t> st;
+    std::vector<amp_t *>     buf[2];
+    int      cur = 0;
+    std::vector<unsigned>    perm, inv;          // logical -> physical, physical -> logical
+    std::vector<SGate>       queue;
+    unsigned min_evict = 0, zone_lo = 0;
+    unsigned long exchanges = 0, pack_passes = 0;
+    std::vector<hipEvent_t>  ev_a, ev_b;
+    int      fusion = 1;                          // 1: each shard's gate list goes through the fused-pass scheduler; -1/0: one launch per gate
+    size_t   max_queue = 8192;
+    std::string trace;
+};
+
+#define SH_DEV(sh, r) do { if (!(sh)->dry) HIP_TRY(hipSetDevice((sh)->dev[r])); } while (0)
+
+static void sh_set_phys(ShardSet *sh, unsigned logical, unsigned pos) { sh->perm[logical] = pos; sh->inv[pos] = logical; }
+
+static void sh_identity_perm(ShardSet *sh)
+{
+    for (unsigned q = 0; q < sh->n; q++) { sh->perm[q] = q; sh->inv[q] = q; }
+}
+
+static void sh_free(ShardSet *sh)
+{
+    if (!sh) return;
+    if (!sh->dry) {
+        for (unsigned r = 0; r < sh->W; r++) {
+            if (r < sh->dev.size()) (void)hipSetDevice(sh->dev[r]);
+            if (r < sh->st.size() && sh->st[r]) { (void)hipStreamSynchronize(sh->st[r]); (void)qcx_shard_release_stream(sh->st[r]); }
+            for (int b = 0; b < 2; b++) if (r < sh->buf[b].size() && sh->buf[b][r]) (void)hipFree(sh->buf[b][r]);
+            if (r < sh->ev_a.size() && sh->ev_a[r]) (void)hipEventDestroy(sh->ev_a[r]);
+            if (r < sh->ev_b.size() && sh->ev_b[r]) (void)hipEventDestroy(sh->ev_b[r]);
+            if (r < sh->st.size() && sh->st[r]) (void)hipStreamDestroy(sh->st[r]);
+        }
+    }
+    delete sh;
+}
+
+static int sh_create(int L, int M, unsigned nshards, const int *devices, ShardSet **out)
+{
+    *out = nullptr;
+    if (nshards < 2 || nshards > 16 || (nshards & (nshards - 1))) { set_error("sharded register: 2, 4, 8 or 16 shards"); return QCX_BAD_ARGUMENTS; }
+    ShardSet *sh = new ShardSet();
+    sh->W = nshards;
+    while ((1u << sh->k) < nshards) sh->k++;
+    sh->L = L; sh->M = (unsigned)M; sh->n = (unsigned)(L + M);
+    if (sh->n <= sh->k) { delete sh; return QCX_BAD_ARGUMENTS; }
+    sh->n_local = sh->n - sh->k;
+    const unsigned k = sh->k;
+    sh->min_evict = std::max<unsigned>((sh->n_local >= 2 * k + 6) ? 6u : 0u, sh->M);     // never trade away the M register or runs < 1 KiB
+    if (sh->n_local < sh->min_evict + 2 * k) {
+        set_error("register too small for %u shards (need n_local - max(M, 6) >= 2 log2(shards))", nshards);
+        delete sh; return QCX_BAD_ARGUMENTS;
+    }
+    if ((unsigned)M > 12) { set_error("sharded register: M <= 12"); delete sh; return QCX_UNSUPPORTED; }
+    sh->zone_lo = sh->n_local - k;
+    sh->perm.resize(sh->n); sh->inv.resize(sh->n);
+    sh_identity_perm(sh);
+    sh->dry = devices && devices[0] < 0;
+    if (sh->dry) { *out = sh; return QCX_NO_ERROR; }
+    int ndev = 0;
+    { const int s = qcx_device_count(&ndev); if (s != QCX_NO_ERROR) { delete sh; return s; } }
+    sh->dev.resize(nshards);
+    for (unsigned r = 0; r < nshards; r++) {
+        sh->dev[r] = devices ? devices[r] : (int)r;
+        if (sh->dev[r] < 0 || sh->dev[r] >= ndev) {
+            set_error("sharded register: shard %u wants device %d, %d visible", r, sh->dev[r], ndev);
+            delete sh; return QCX_HIP_ERROR;
+        }
+    }
+    sh->st.assign(nshards, nullptr); sh->ev_a.assign(nshards, nullptr); sh->ev_b.assign(nshards, nullptr);
+    sh->buf[0].assign(nshards, nullptr); sh->buf[1].assign(nshards, nullptr);
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    const size_t bytes = (size_t)16 << sh->n_local;
+    int status = QCX_NO_ERROR;
+    for (unsigned r = 0; r < nshards && status == QCX_NO_ERROR; r++) {
+        hipError_t e = hipSetDevice(sh->dev[r]);
+        for (unsigned c = 0; c < nshards && e == hipSuccess; c++) {         // peer stores need the mapping both ways
+            if (sh->dev[c] == sh->dev[r]) continue;
+            int can = 0;
+            (void)hipDeviceCanAccessPeer(&can, sh->dev[r], sh->dev[c]);
+            if (!can) { set_error("no peer access between devices %d and %d", sh->dev[r], sh->dev[c]); status = QCX_HIP_ERROR; break; }
+            const hipError_t pe = hipDeviceEnablePeerAccess(sh->dev[c], 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) e = pe;
+            (void)hipGetLastError();
+        }
+        if (status != QCX_NO_ERROR) break;
+        if (e == hipSuccess) e = hipStreamCreate(&sh->st[r]);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sh->ev_a[r], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sh->ev_b[r], hipEventDisableTiming);
+        for (int b = 0; b < 2 && e == hipSuccess; b++) {
+            e = hipMalloc(&sh->buf[b][r], bytes);
+            if (e == hipSuccess) e = hipMemsetAsync(sh->buf[b][r], 0, bytes, sh->st[r]);
+        }
+        if (e != hipSuccess) {
+            set_error("sharded register, shard %u on device %d: %s", r, sh->dev[r], hipGetErrorString(e));
+            status = (e == hipErrorOutOfMemory) ? QCX_INSUFFICIENT_MEMORY : QCX_HIP_ERROR;
+        }
+    }
+    (void)hipSetDevice(prev);
+    if (status != QCX_NO_ERROR) { sh_free(sh); return status; }
+    *out = sh;
+    return QCX_NO_ERROR;
+}
+
+// ---- one gate list on every shard ------------------------------------------------------------------------------------
+// resolve a queued gate for shard r under the CURRENT layout: false = the gate is the identity on this shard
+static bool sh_resolve(const ShardSet *sh, const SGate &g, unsigned r, qcx_gate_desc *d)
+{
+    const unsigned nl = sh->n_local;
+    memset(d, 0, sizeof *d);
+    if (g.type == FUSE_H) { d->type = 0; d->q = sh->perm[g.q]; return true; }
+    if (g.type == FUSE_PHASE) {
+        d->type = 1; d->c = g.c; d->s = g.s;
+        for (unsigned lq : {g.q, g.q2}) {
+            const unsigned pq = sh->perm[lq];
+            if (pq >= nl) { if (!((r >> (pq - nl)) & 1u)) return false; }
+            else d->mask |= (uint64_t)1 << pq;
+        }
+        return true;
+    }
+    d->type = 2; d->C = g.C; d->A = g.A;
+    const unsigned pc = sh->perm[g.q];
+    if (pc >= nl) { if (!((r >> (pc - nl)) & 1u)) return false; d->q = 0xffffffffu; }
+    else d->q = pc;
+    return true;
+}
+
+static void sh_trace_ops(ShardSet *sh, const SGate *g, size_t cnt)
+{
+    char line[160];
+    snprintf(line, sizeof line, "ops %zu\n", cnt); sh->trace += line;
+    for (size_t i = 0; i < cnt; i++) {
+        if (g[i].type == FUSE_H) snprintf(line, sizeof line, "h %u\n", sh->perm[g[i].q]);
+        else if (g[i].type == FUSE_PHASE) snprintf(line, sizeof line, "p %u %u %a %a\n", sh->perm[g[i].q], sh->perm[g[i].q2], g[i].c, g[i].s);
+        else snprintf(line, sizeof line, "c %u %u %u\n", g[i].C, g[i].A, sh->perm[g[i].q]);
+        sh->trace += line;
+    }
+}
+
+static int sh_run_ops(ShardSet *sh, const SGate *g, size_t cnt)
+{
+    if (!cnt) return QCX_NO_ERROR;
+    if (sh->dry) { sh_trace_ops(sh, g, cnt); return QCX_NO_ERROR; }
+    std::vector<qcx_gate_desc> descs;
+    for (unsigned r = 0; r < sh->W; r++) {
+        SH_DEV(sh, r);
+        descs.clear();
+        for (size_t i = 0; i < cnt; i++) { qcx_gate_desc d; if (sh_resolve(sh, g[i], r, &d)) descs.push_back(d); }
+        if (descs.empty()) continue;
+        amp_t *a = sh->buf[sh->cur][r];
+        if (sh->fusion > 0 && descs.size() > 1) {
+            QCX_TRY(qcx_shard_run_fused(a, sh->n_local, sh->M, (unsigned)descs.size(), descs.data(), sh->st[r]));
+            continue;
+        }
+        for (const qcx_gate_desc &d : descs) {
+            if (d.type == 0) QCX_TRY(qcx_shard_hadamard(a, sh->n_local, d.q, sh->st[r]));
+            else if (d.type == 1) QCX_TRY(qcx_shard_phase(a, sh->n_local, d.mask, d.c, d.s, sh->st[r]));
+            else QCX_TRY(qcx_shard_camodc(a, sh->n_local, sh->M, d.C, d.A, d.q == 0xffffffffu ? -1 : (int)d.q, sh->st[r]));
+        }
+    }
+    return QCX_NO_ERROR;
+}
+
+// ---- layout changes --------------------------------------------------------------------------------------------------
+typedef std::vector<std::pair<unsigned, unsigned>> SwapList;
+
+// transpositions (application order) that bring local position give[j] to trade-zone slot j
+static SwapList sh_plan_give(const ShardSet *sh, std::vector<unsigned> pos)
+{
+    SwapList swaps;
+    for (unsigned j = 0; j < sh->k; j++) {
+        const unsigned t = sh->zone_lo + j, p = pos[j];
+        if (p != t) {
+            swaps.push_back({p, t});
+            for (unsigned jj = j + 1; jj < sh->k; jj++) if (pos[jj] == t) pos[jj] = p;
+        }
+    }
+    return swaps;
+}
+
+static void sh_book(ShardSet *sh, const SwapList &swaps, bool trade)
+{
+    for (const auto &ab : swaps) {
+        const unsigned la = sh->inv[ab.first], lb = sh->inv[ab.second];
+        sh_set_phys(sh, la, ab.second); sh_set_phys(sh, lb, ab.first);
+    }
+    if (trade)
+        for (unsigned j = 0; j < sh->k; j++) {
+            const unsigned lt = sh->inv[sh->zone_lo + j], lr = sh->inv[sh->n_local + j];
+            sh_set_phys(sh, lt, sh->n_local + j); sh_set_phys(sh, lr, sh->zone_lo + j);
+        }
+}
+
+static void sh_swapbits_arg(const SwapList &swaps, size_t lo, size_t hi, SwapBits *S)
+{
+    // the kernels compute the SOURCE index of destination j by applying their list in array order; data moved by
+    // s_1, ..., s_m in that order has source s_1(s_2(...s_m(j))): the list goes in reversed
+    memset(S, 0, sizeof *S);
+    S->npairs = (unsigned)(hi - lo);
+    for (size_t m = 0; m < hi - lo; m++) { S->a[m] = swaps[hi - 1 - m].first; S->b[m] = swaps[hi - 1 - m].second; }
+}
+
+static void sh_trace_swaps(ShardSet *sh, const char *what, const SwapList &swaps, size_t lo, size_t hi)
+{
+    sh->trace += what;
+    char t[32];
+    for (size_t m = lo; m < hi; m++) { snprintf(t, sizeof t, " %u:%u", swaps[m].first, swaps[m].second); sh->trace += t; }
+    sh->trace += "\n";
+}
+
+// pack (the transpositions) + trade of all k shard-id bits with the trade zone, as one kernel per shard
+static int sh_exchange(ShardSet *sh, const SwapList &swaps)
+{
+    if (sh->dry) { sh_trace_swaps(sh, "pack", swaps, 0, swaps.size()); sh->trace += "trade\n"; }
+    else {
+        const unsigned W = sh->W;
+        // (1) every shard's earlier work is done before anyone writes into its spare buffer
+        for (unsigned r = 0; r < W; r++) { SH_DEV(sh, r); HIP_TRY(hipEventRecord(sh->ev_a[r], sh->st[r])); }
+        for (unsigned r = 0; r < W; r++) {
+            SH_DEV(sh, r);
+            for (unsigned c = 0; c < W; c++) if (c != r) HIP_TRY(hipStreamWaitEvent(sh->st[r], sh->ev_a[c], 0));
+        }
+        SwapBits S;
+        sh_swapbits_arg(swaps, 0, swaps.size(), &S);
+        PushDst D;
+        memset(&D, 0, sizeof D);
+        for (unsigned c = 0; c < W; c++) D.dst[c] = sh->buf[sh->cur ^ 1][c];
+        const uint64_t count = (uint64_t)1 << sh->n_local;
+        for (unsigned r = 0; r < W; r++) {
+            SH_DEV(sh, r);
+            if (sh->zone_lo >= 8)
+                hipLaunchKernelGGL((k_pack_push<256, true>), dim3(grid_for(count, 256, 0, 256)), dim3(256), 0, sh->st[r],
+                                   (const amp_t *)sh->buf[sh->cur][r], D, count, S, sh->zone_lo, sh->k, r);
+            else
+                hipLaunchKernelGGL((k_pack_push<64, false>), dim3(grid_for(count, 64, 0, 64)), dim3(64), 0, sh->st[r],
+                                   (const amp_t *)sh->buf[sh->cur][r], D, count, S, sh->zone_lo, sh->k, r);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(sh->ev_b[r], sh->st[r]));
+        }
+        // (2) a shard's new buffer is complete when every shard has pushed
+        for (unsigned r = 0; r < W; r++) {
+            SH_DEV(sh, r);
+            for (unsigned c = 0; c < W; c++) if (c != r) HIP_TRY(hipStreamWaitEvent(sh->st[r], sh->ev_b[c], 0));
+        }
+        sh->cur ^= 1;
+    }
+    sh_book(sh, swaps, true);
+    sh->exchanges++;
+    if (!swaps.empty()) sh->pack_passes++;
+    return QCX_NO_ERROR;
+}
+
+// transpositions among local positions on every shard (8 per out-of-place pass)
+static int sh_local_permute(ShardSet *sh, const SwapList &swaps)
+{
+    for (size_t lo = 0; lo < swaps.size(); lo += 8) {
+        const size_t hi = std::min(swaps.size(), lo + 8);
+        if (sh->dry) sh_trace_swaps(sh, "permute", swaps, lo, hi);
+        else {
+            SwapBits S;
+            sh_swapbits_arg(swaps, lo, hi, &S);
+            for (unsigned r = 0; r < sh->W; r++) {
+                SH_DEV(sh, r);
+                QCX_TRY(qcx_shard_swap_bits(sh->buf[sh->cur][r], sh->buf[sh->cur ^ 1][r], sh->n_local, S.npairs, S.a, S.b, sh->st[r]));
+            }
+            sh->cur ^= 1;
+        }
+        sh_book(sh, SwapList(swaps.begin() + lo, swaps.begin() + hi), false);
+        sh->pack_passes++;
+    }
+    return QCX_NO_ERROR;
+}
+
+static size_t sh_next_use(const std::vector<SGate> &q, unsigned logical, size_t start)
+{
+    for (size_t i = start; i < q.size(); i++) if (q[i].type == FUSE_H && q[i].q == logical) return i;
+    return q.size() + 1;
+}
+
+// the k local positions whose qubits are H targets latest (Belady)
+static std::vector<unsigned> sh_choose_give(const ShardSet *sh, const std::vector<SGate> &q, size_t at)
+{
+    std::vector<std::pair<size_t, unsigned>> cand;                 // (next use, position)
+    for (unsigned p = sh->min_evict; p < sh->n_local; p++) cand.push_back({sh_next_use(q, sh->inv[p], at), p});
+    std::sort(cand.begin(), cand.end(), [](const std::pair<size_t, unsigned> &x, const std::pair<size_t, unsigned> &y) {
+        return x.first != y.first ? x.first > y.first : x.second > y.second; });
+    std::vector<unsigned> give;
+    for (unsigned j = 0; j < sh->k; j++) give.push_back(cand[j].second);
+    std::sort(give.begin(), give.end());
+    return give;
+}
+
+static int sh_flush(ShardSet *sh)
+{
+    if (sh->queue.empty()) return QCX_NO_ERROR;
+    std::vector<SGate> q;
+    q.swap(sh->queue);
+    size_t i = 0;
+    while (i < q.size()) {
+        size_t x = i;
+        while (x < q.size() && !(q[x].type == FUSE_H && sh->perm[q[x].q] >= sh->n_local)) x++;
+        QCX_TRY(sh_run_ops(sh, q.data() + i, x - i));
+        if (x == q.size()) break;
+        QCX_TRY(sh_exchange(sh, sh_plan_give(sh, sh_choose_give(sh, q, x))));
+        i = x;                                                       // the H at x is local now
+    }
+    return QCX_NO_ERROR;
+}
+
+static int sh_push(ShardSet *sh, const SGate &g)
+{
+    sh->queue.push_back(g);
+    if (sh->queue.size() >= sh->max_queue) return sh_flush(sh);
+    return QCX_NO_ERROR;
+}
+
+static bool sh_is_identity(const ShardSet *sh)
+{
+    for (unsigned q = 0; q < sh->n; q++) if (sh->perm[q] != q) return false;
+    return true;
+}
+
+// restore logical == physical (the order measurement and read-back need)
+static int sh_identity(ShardSet *sh)
+{
+    QCX_TRY(sh_flush(sh));
+    if (sh_is_identity(sh)) return QCX_NO_ERROR;
+    const unsigned n = sh->n, nl = sh->n_local, k = sh->k;
+    bool moved = false, some_in_id = false;
+    for (unsigned g = nl; g < n; g++) { moved |= sh->perm[g] != g; some_in_id |= sh->perm[g] >= nl; }
+    if (moved) {
+        if (some_in_id) {
+            // some rightful shard-id qubits sit in the shard id but in the wrong slot / beside strangers: one trade
+            // brings the whole shard id local (giving up positions that hold none of them)
+            std::vector<unsigned> cand;
+            for (unsigned p = nl; p-- > sh->min_evict && cand.size() < k;) if (sh->inv[p] < nl) cand.push_back(p);
+            QCX_TRY(sh_exchange(sh, sh_plan_give(sh, cand)));
+        }
+        std::vector<unsigned> give;
+        for (unsigned j = 0; j < k; j++) give.push_back(sh->perm[nl + j]);      // shard-id bit j <- logical qubit nl + j
+        QCX_TRY(sh_exchange(sh, sh_plan_give(sh, give)));
+    }
+    SwapList swaps;
+    std::vector<unsigned> perm = sh->perm, inv = sh->inv;
+    for (unsigned q = 0; q < nl; q++) {
+        const unsigned a = perm[q];
+        if (a != q) {
+            swaps.push_back({a, q});
+            const unsigned other = inv[q];
+            perm[q] = q; perm[other] = a; inv[q] = q; inv[a] = other;
+        }
+    }
+    QCX_TRY(sh_local_permute(sh, swaps));
+    if (!sh_is_identity(sh)) { set_error("sharded register: identity layout not restored"); return QCX_UNKNOWN_ERROR; }
+    return QCX_NO_ERROR;
+}
+
+static int sh_sync(ShardSet *sh)
+{
+    QCX_TRY(sh_flush(sh));
+    if (sh->dry) return QCX_NO_ERROR;
+    for (unsigned r = 0; r < sh->W; r++) { SH_DEV(sh, r); HIP_TRY(hipStreamSynchronize(sh->st[r])); }
+    return QCX_NO_ERROR;
+}
+
+static int sh_reset(ShardSet *sh)
+{
+    sh->queue.clear();                              // pending gates act on a state that is being overwritten
+    sh_identity_perm(sh);
+    if (sh->dry) { sh->trace += "reset\n"; return QCX_NO_ERROR; }
+    for (unsigned r = 0; r < sh->W; r++) { SH_DEV(sh, r); QCX_TRY(qcx_shard_reset(sh->buf[sh->cur][r], sh->n_local, r == 0, sh->st[r])); }
+    return QCX_NO_ERROR;
+}
+
+static int sh_fill_random(ShardSet *sh, uint64_t seed)
+{
+    sh->queue.clear();
+    sh_identity_perm(sh);
+    if (sh->dry) return QCX_UNSUPPORTED;
+    const double scale = sqrt(6.0 / (double)((uint64_t)1 << sh->n));
+    for (unsigned r = 0; r < sh->W; r++) {
+        SH_DEV(sh, r);
+        QCX_TRY(qcx_shard_fill_random(sh->buf[sh->cur][r], sh->n_local, (uint64_t)r << sh->n_local, seed, scale, sh->st[r]));
+    }
+    return QCX_NO_ERROR;
+}
+
+static int sh_norm2(ShardSet *sh, double *out)
+{
+    QCX_TRY(sh_flush(sh));
+    if (sh->dry) return QCX_UNSUPPORTED;
+    double t = 0.0;
+    for (unsigned r = 0; r < sh->W; r++) {
+        SH_DEV(sh, r);
+        double v = 0.0;
+        QCX_TRY(qcx_shard_norm2(sh->buf[sh->cur][r], sh->n_local, &v, sh->st[r]));
+        t += v;
+    }
+    *out = t;
+    return QCX_NO_ERROR;
+}
+
+// Q:272-306 over the shards: the sequential cumulative sum is handed from shard to shard in index order
+static int sh_measure(ShardSet *sh, double rnd, unsigned long *state_num)
+{
+    QCX_TRY(sh_identity(sh));
+    if (sh->dry) return QCX_UNSUPPORTED;
+    QCX_TRY(sh_sync(sh));
+    const uint64_t dim = (uint64_t)1 << sh->n, last_excluded = dim - 1;
+    double cum = 0.0;
+    uint64_t idx = last_excluded;                                               // Q:283 fall-through
+    for (unsigned r = 0; r < sh->W; r++) {
+        SH_DEV(sh, r);
+        int found = 0; uint64_t i = 0; double c2 = cum;
+        QCX_TRY(qcx_shard_measure_scan(sh->buf[sh->cur][r], sh->n_local, (uint64_t)r << sh->n_local, last_excluded, cum, rnd,
+                                       &found, &i, &c2, sh->st[r]));
+        cum = c2;
+        if (found) { idx = i; break; }
+    }
+    const unsigned owner = (unsigned)(idx >> sh->n_local);
+    for (unsigned r = 0; r < sh->W; r++) {
+        SH_DEV(sh, r);
+        QCX_TRY(qcx_shard_collapse(sh->buf[sh->cur][r], sh->n_local, r == owner ? (int64_t)(idx & ((((uint64_t)1) << sh->n_local) - 1)) : -1, sh->st[r]));
+    }
+    *state_num = (unsigned long)idx;
+    return QCX_NO_ERROR;
+}
+
+// host <-> shards, identity layout: amplitudes [first, first + count)
+static int sh_copy(ShardSet *sh, uint64_t first, uint64_t count, double *host, bool to_host)
+{
+    QCX_TRY(sh_identity(sh));
+    if (sh->dry) return QCX_UNSUPPORTED;
+    QCX_TRY(sh_sync(sh));
+    const uint64_t per = (uint64_t)1 << sh->n_local;
+    uint64_t at = first, left = count;
+    while (left) {
+        const unsigned r = (unsigned)(at >> sh->n_local);
+        const uint64_t off = at & (per - 1), cnt = std::min(left, per - off);
+        SH_DEV(sh, r);
+        amp_t *d = sh->buf[sh->cur][r] + off;
+        double *h = host + 2 * (at - first);
+        if (to_host) HIP_TRY(hipMemcpy(h, d, (size_t)cnt * sizeof(amp_t), hipMemcpyDeviceToHost));
+        else HIP_TRY(hipMemcpy(d, h, (size_t)cnt * sizeof(amp_t), hipMemcpyHostToDevice));
+        at += cnt; left -= cnt;
+    }
+    return QCX_NO_ERROR;
+}

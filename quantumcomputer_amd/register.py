@@ -62,9 +62,19 @@ class Register:
     """The qubit register (qc_shor.c:194-203): L_size, M_size, num_qubits, num_states and the
     state vector, which lives in HBM as 2^n interleaved (re, im) doubles, updated in place."""
 
-    def __init__(self, L_size, M_size):
+    def __init__(self, L_size, M_size, shards=1, devices=None):
+        """shards > 1: the register is sharded over that many GPUs by this process (qcx_register_create_sharded);
+        devices = HIP device of each shard (default shard r on device r; entries may repeat; [-1] = dry run: the
+        schedule only, see sharded_trace)"""
         h = C.c_void_p()
-        check(lib().qcx_register_create(int(L_size), int(M_size), C.byref(h)), "qcx_register_create")
+        if shards == 1 and devices is None:
+            check(lib().qcx_register_create(int(L_size), int(M_size), C.byref(h)), "qcx_register_create")
+        else:
+            dv = None
+            if devices is not None:
+                devices = list(devices) + [devices[-1]] * max(0, int(shards) - len(devices))
+                dv = (C.c_int * len(devices))(*devices)
+            check(lib().qcx_register_create_sharded(int(L_size), int(M_size), int(shards), dv, C.byref(h)), "qcx_register_create_sharded")
         self._h = h
         self.L_size = int(L_size)
         self.M_size = int(M_size)
@@ -120,6 +130,33 @@ class Register:
         out = C.c_double(0.0)
         check(lib().qcx_norm2(self._h, C.byref(out)), "qcx_norm2")
         return out.value
+
+    @property
+    def shards(self):
+        return int(lib().qcx_register_shards(self._h))
+
+    def sharded_stats(self):
+        """(exchanges, pack passes) a sharded register has performed"""
+        e, p = C.c_ulong(0), C.c_ulong(0)
+        check(lib().qcx_sharded_stats(self._h, C.byref(e), C.byref(p)), "qcx_sharded_stats")
+        return e.value, p.value
+
+    def sharded_trace(self):
+        """diagnostics: the steps a dry-run sharded register has scheduled since the last call, as text"""
+        need = C.c_size_t(0)
+        lib().qcx_sharded_trace(self._h, None, 0, C.byref(need))
+        buf = C.create_string_buffer(need.value)
+        check(lib().qcx_sharded_trace(self._h, buf, need.value, C.byref(need)), "qcx_sharded_trace")
+        return buf.value.decode()
+
+    def sharded_restore_identity(self):
+        check(lib().qcx_sharded_restore_identity(self._h), "qcx_sharded_restore_identity")
+
+    def sharded_layout(self):
+        """logical qubit -> physical index bit of a sharded register"""
+        perm = (C.c_uint * self.num_qubits)()
+        check(lib().qcx_sharded_layout(self._h, perm, self.num_qubits), "qcx_sharded_layout")
+        return list(perm)
 
     def set_fusion(self, enable=True):
         """Fused LDS-tile passes (bit-identical results).  True/1: every gate call is queued; False/0 (default): only

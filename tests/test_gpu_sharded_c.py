@@ -1,0 +1,171 @@
+"""GPU: the C-ABI sharded register (qcx_register_create_sharded: ONE process, W shards, exchange by k_pack_push stores into
+the peers' buffers) with all shards placed on the one GPU of the box -- the code path of an 8-GPU node except that the
+peer stores stay on the device.  Everything is compared with the oracle bit for bit, through the ordinary entry points
+of include/qcx.h; the reference-style C program and the C host driver are run sharded through QCX_SHARDS / -g."""
+import math
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def bits(a):
+    return np.asarray(a).view(np.uint64)
+
+
+@pytest.mark.parametrize("shards,n", [(2, 10), (4, 12), (8, 16), (16, 20)])
+@pytest.mark.parametrize("fusion", [1, -1])
+def test_hadamard_sweeps(qc, ob, shards, n, fusion):
+    with qc.Register(n, 0, shards=shards, devices=[0]) as reg:
+        assert reg.shards == shards
+        reg.set_fusion(fusion)
+        reg.fill_random(5)
+        want = ob.fill_random(n, 5)
+        assert np.array_equal(bits(reg.read()), bits(want))
+        for _ in range(2):
+            for q in range(n):
+                qc.hadamard_gate(q, reg); ob.hadamard(want, n, q)
+        assert np.array_equal(bits(reg.read()), bits(want))
+        ex, _ = reg.sharded_stats()
+        assert 2 <= ex <= 6                                  # one trade per sweep + restoring the identity layout
+
+
+@pytest.mark.parametrize("shards,C,L,M,a", [(2, 15, 3, 4, 7), (2, 21, 6, 5, 2), (4, 21, 8, 5, 2), (8, 21, 12, 5, 2), (4, 33, 9, 6, 7)])
+def test_shor_circuit_and_measurement(qc, ob, shards, C, L, M, a):
+    n = L + M
+    if n - (shards.bit_length() - 1) - max(M, 6) < 2 * (shards.bit_length() - 1):
+        pytest.skip("register too small for that many shards")
+    rng, orng = qc.Rng(12345), ob.Rng(12345)
+    with qc.Register(L, M, shards=shards, devices=[0]) as reg:
+        picks = []
+        for shot in range(4):
+            qc.reset_register(reg)
+            qc.quantum_computation(C, a, reg)
+            want = np.zeros(2 << n); ob.reset(want, n); ob.quantum_computation(want, n, M, C, a)
+            if shot == 0:
+                assert abs(reg.norm2() - 1.0) < 1e-13
+                assert np.array_equal(bits(reg.read()), bits(want))
+            picks.append((qc.measure_state(reg, rng), ob.measure(want, n, orng.uniform())))
+            assert np.array_equal(bits(reg.read()), bits(want))          # collapsed the same way
+        assert all(x == y for x, y in picks), picks
+
+
+def test_measurement_edges(qc, ob):
+    n = 12
+    with qc.Register(n, 0, shards=4, devices=[0]) as reg:
+        for r in (0.0, 1e-300, 0.25, 0.5, 0.999999999, 1.0 - 2.0 ** -53):
+            reg.fill_random(9)
+            for q in (n - 1, 3, n - 2):
+                qc.hadamard_gate(q, reg)
+            want = ob.fill_random(n, 9)
+            for q in (n - 1, 3, n - 2):
+                ob.hadamard(want, n, q)
+            assert qc.measure_state(reg, r) == ob.measure(want, n, r)
+            assert np.array_equal(bits(reg.read()), bits(want))
+
+
+@pytest.mark.parametrize("shards,n,M", [(2, 9, 0), (4, 12, 3), (4, 13, 5), (8, 16, 4)])
+def test_random_programs(qc, ob, shards, n, M):
+    rnd = random.Random(7 * shards + n)
+    with qc.Register(n - M, M, shards=shards, devices=[0]) as reg:
+        for trial in range(6):
+            reg.set_fusion(1 if trial % 2 == 0 else -1)
+            reg.fill_random(trial)
+            want = ob.fill_random(n, trial)
+            for _ in range(rnd.randrange(20, 90)):
+                t = rnd.random()
+                if t < 0.5:
+                    q = rnd.randrange(n)
+                    qc.hadamard_gate(q, reg); ob.hadamard(want, n, q)
+                elif t < 0.85 or M == 0:
+                    c, tq = rnd.sample(range(n), 2)
+                    th = rnd.uniform(-3.0, 3.0)
+                    qc.c_phase_shift_gate(c, tq, th, reg); ob.cphase(want, n, c, tq, th)
+                else:
+                    Cn, A, ctl = rnd.randrange(2, (1 << M) + 1), rnd.randrange(1, 200), rnd.randrange(M, n)
+                    qc.c_amodc_gate(Cn, A, ctl, reg); ob.camodc(want, n, M, Cn, A, ctl)
+                if rnd.random() < 0.03:
+                    assert abs(reg.norm2() - ob.norm2(want, n)) < 1e-12       # observing in a swapped layout is fine
+            assert np.array_equal(bits(reg.read()), bits(want)), (shards, n, M, trial)
+
+
+def test_state_io_and_timers(qc, ob, tmp_path):
+    n = 12
+    with qc.Register(n, 0, shards=4, devices=[0]) as reg, qc.Register(n, 0) as plain:
+        reg.fill_random(2)
+        qc.hadamard_gate(n - 1, reg)                                            # leaves a swapped layout behind
+        want = ob.fill_random(n, 2); ob.hadamard(want, n, n - 1)
+        assert np.array_equal(bits(reg.read(100, 3000)), bits(want[200:6200]))     # a window across shard boundaries
+        p = str(tmp_path / "s.qcx")
+        reg.save(p)
+        plain.load(p)
+        assert np.array_equal(bits(plain.read()), bits(want))
+        w2 = ob.fill_random(n, 77)
+        reg.write(w2[2 * 1000:2 * 3500], first=1000)
+        want[2 * 1000:2 * 3500] = w2[2 * 1000:2 * 3500]
+        assert np.array_equal(bits(reg.read()), bits(want))
+        reg.timer_start()
+        for q in range(n):
+            qc.hadamard_gate(q, reg)
+        assert reg.timer_stop() > 0.0
+        assert reg.device_pointer() == 0
+        with pytest.raises(qc.QcxError):
+            reg.events_create(4)
+
+
+def test_inverse_qft_entry_point(qc, ob):
+    L, M = 9, 4
+    n = L + M
+    with qc.Register(L, M, shards=4, devices=[0]) as reg:
+        reg.fill_random(4)
+        qc.inverse_QFT(reg)
+        want = ob.fill_random(n, 4); ob.iqft(want, n, M)
+        assert np.array_equal(bits(reg.read()), bits(want))
+
+
+def test_reference_style_c_program_sharded_by_environment(ob, tmp_path):
+    """the program of tests/c/refstyle_circuit.c (reference names, Register by value, gsl_rng ...) knows nothing about
+    shards: QCX_SHARDS makes qcx_register_create shard the register"""
+    out = str(tmp_path / "refstyle")
+    lib = os.path.join(ROOT, "quantumcomputer_amd")
+    subprocess.run(["gcc", "-std=gnu11", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c", "refstyle_circuit.c"), "-L", lib, "-lqcx", "-lm",
+                    "-Wl,-rpath," + lib, "-o", out], check=True)
+    C, L, M, a = 21, 9, 5, 2
+    n = L + M
+    env = dict(os.environ, QCX_SHARDS="4", QCX_SHARD_DEVICES="0")
+    r = subprocess.run([out, str(C), str(L), str(M), str(a), "12345"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.split()
+    got = np.array([int(x, 16) for x in lines[:2 << n]], dtype=np.uint64)
+    want = np.zeros(2 << n); ob.reset(want, n)
+    ob.quantum_computation(want, n, M, C, a, ref_intpow=True)
+    assert np.array_equal(got, want.view(np.uint64))
+    assert int(lines[-1]) == ob.measure(want, n, ob.Rng(12345).uniform())
+
+
+def test_host_driver_sharded():
+    exe = os.path.join(ROOT, "host", "qcx_shor")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "host"), "-s"], check=True)
+    import json
+    strip = lambda t: [ln for ln in t.splitlines() if not ln.startswith("{")]
+    found = 0
+    for seed in ("1", "2", "3", "4", "5", "6"):
+        args = [exe, "-C", "21", "-L", "9", "-M", "5", "-a", "2", "-s", seed, "-j"]
+        single = subprocess.run(args, capture_output=True, text=True, timeout=120)
+        shard = subprocess.run(args + ["-g", "4", "-d", "0"], capture_output=True, text=True, timeout=120)
+        # same seed -> same measured states, same attempts, same verdict: only the JSON line's timing and shard fields differ
+        assert single.returncode == shard.returncode and single.returncode in (0, 3), shard.stderr
+        assert strip(single.stdout) == strip(shard.stdout)
+        js = json.loads([ln for ln in shard.stdout.splitlines() if ln.startswith("{")][0])
+        assert js["shards"] == 4 and js["exchanges"] >= 1
+        if shard.returncode == 0:
+            found += 1
+            assert "Factors of 21 found: (3, 7)" in shard.stdout or "Factors of 21 found: (7, 3)" in shard.stdout
+    assert found >= 1

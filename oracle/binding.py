@@ -72,6 +72,10 @@ def lib():
         L.orc_norm2.argtypes = [dp, C.c_uint]; L.orc_norm2.restype = C.c_double
         L.orc_fill_random.argtypes = [dp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double]
         L.orc_polar.argtypes = [C.c_double, dp, dp]
+        L.orc_basis_iqft_window.argtypes = [C.c_uint64, C.c_uint, C.c_uint, C.c_uint64, C.c_uint64, dp]
+        L.orc_basis_iqft_window.restype = None
+        L.orc_shor_front_window.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_int, C.c_uint64, C.c_uint64, dp]
+        L.orc_shor_front_window.restype = None
         L.orc_ref_intpow.argtypes = [C.c_double, C.c_double]; L.orc_ref_intpow.restype = C.c_uint
         L.orc_modpow.argtypes = [C.c_ulonglong] * 3; L.orc_modpow.restype = C.c_ulonglong
         L.orc_gcd.argtypes = [C.c_uint, C.c_uint]; L.orc_gcd.restype = C.c_uint
@@ -174,6 +178,22 @@ def measure_range(a, first, count, last_excluded, cum_in, r):
     idx = C.c_uint64(0); cum = C.c_double(0.0)
     hit = lib().orc_measure_range(_dp(a), first, count, last_excluded, cum_in, r, C.byref(idx), C.byref(cum))
     return bool(hit), int(idx.value), float(cum.value)
+
+
+def basis_iqft_window(x, n, M, first, count):
+    """amplitudes [first, first+count) of inverse_QFT applied to the basis state |x>, one scalar chain per index"""
+    out = np.empty(2 * count, dtype=np.float64)
+    lib().orc_basis_iqft_window(int(x), n, M, int(first), int(count), _dp(out))
+    return out
+
+
+def shor_front_window(n, M, Cn, a, first, count, ref_intpow=False):
+    """amplitudes [first, first+count) after the Hadamard layer and the modular-multiply ladder of quantum_computation
+    on the reset state (valid for gcd(a, C) = 1 and C <= 2^M)"""
+    assert gcd(a, Cn) == 1 and Cn <= (1 << M)
+    out = np.empty(2 * count, dtype=np.float64)
+    lib().orc_shor_front_window(n, M, Cn, a, int(ref_intpow), int(first), int(count), _dp(out))
+    return out
 
 
 def polar(theta):

@@ -364,6 +364,92 @@ void orc_pair_quantum_computation(double *amp, unsigned n, unsigned M, unsigned 
 }
 
 /* ------------------------------------------------------------------------ */
+/* per-index evaluation of whole circuits on a BASIS-STATE input             */
+/*                                                                           */
+/* Applied to a basis state, every Hadamard of inverse_QFT (Q:678-690) meets */
+/* a pair of which exactly one member is non-zero (the bits it has not yet   */
+/* reached still carry the input's values), so the amplitude of output index */
+/* i is one scalar chain of the reference's per-gate sums -- the same        */
+/* expressions as orc_pair_hadamard / orc_pair_cphase above, with the        */
+/* partner's (+0, +0) written out.  This lets tests check windows of a 2^28  */
+/* or 2^30 result bit for bit without any 2^n array on the host; the CPU     */
+/* suite pins these chains to the full pairwise oracle at sizes it can hold. */
+/* ------------------------------------------------------------------------ */
+static void chain_hadamard(double *ar, double *ai, unsigned in_bit, unsigned out_bit)
+{
+    const double s = M_SQRT1_2, z = 0.0;
+    /* the pair (lo = element with the target bit 0, hi = with 1); the input sits in lo or hi, the other is +0 */
+    const double lr = in_bit ? 0.0 : *ar, li = in_bit ? 0.0 : *ai, hr = in_bit ? *ar : 0.0, hi = in_bit ? *ai : 0.0;
+    double o_r = 0.0, o_i = 0.0;
+    if (!out_bit) {
+        o_r += (s * lr) - (z * li);   o_i += (s * li) + (z * lr);     /* row i0, column i0 */
+        o_r += (s * hr) - (z * hi);   o_i += (s * hi) + (z * hr);     /* row i0, column i1 */
+    } else {
+        o_r += (s * lr) - (z * li);   o_i += (s * li) + (z * lr);     /* row i1, column i0 */
+        o_r += (-s * hr) - (z * hi);  o_i += (-s * hi) + (z * hr);    /* row i1, column i1 */
+    }
+    *ar = o_r; *ai = o_i;
+}
+
+static void chain_cphase(double *ar, double *ai, int selected, double theta)
+{
+    const double one = 1.0, z = 0.0;
+    double er, ei, nr = 0.0, ni = 0.0;
+    orc_polar(theta, &er, &ei);
+    if (selected) { nr += (er * *ar) - (ei * *ai);   ni += (er * *ai) + (ei * *ar); }
+    else          { nr += (one * *ar) - (z * *ai);   ni += (one * *ai) + (z * *ar); }
+    *ar = nr; *ai = ni;
+}
+
+/* amplitudes [first, first + count) of inverse_QFT (Q:678-690) applied to the basis state |x> of an n-qubit register
+ * whose M register is bits [0, M) */
+void orc_basis_iqft_window(uint64_t x, unsigned n, unsigned M, uint64_t first, uint64_t count, double *out)
+{
+    const uint64_t mlow = ((uint64_t)1 << M) - 1;
+    for (uint64_t w = 0; w < count; w++) {
+        const uint64_t i = first + w;
+        double ar = 1.0, ai = 0.0;
+        if ((i & mlow) != (x & mlow)) { out[2 * w] = 0.0; out[2 * w + 1] = 0.0; continue; }     /* the M register is not touched */
+        for (int l = (int)n - 1; l >= (int)M; l--) {
+            chain_hadamard(&ar, &ai, bit_of(x, (unsigned)l), bit_of(i, (unsigned)l));
+            for (int k = l - 1; k >= (int)M; k--)       /* bit l is final (= i's), bit k still the input's (= x's) */
+                chain_cphase(&ar, &ai, bit_of(i, (unsigned)l) && bit_of(x, (unsigned)k), ladder_theta((unsigned)(l - k)));
+        }
+        out[2 * w] = ar; out[2 * w + 1] = ai;
+    }
+}
+
+/* amplitudes [first, first + count) after the first two stages of quantum_computation (Q:712-731) on the reset state
+ * |0...01>: the Hadamard layer over the L register, then the controlled modular multiplies (exact powers or the
+ * reference's INT_POW).  Index (l << M | f) is non-zero iff f = prod over the set bits j of l of atox_j, mod C,
+ * applied to 1 in ascending j; its value is the chain of L Hadamards that all find their input in the lo element. */
+void orc_shor_front_window(unsigned n, unsigned M, unsigned C, unsigned a, int ref_intpow,
+                           uint64_t first, uint64_t count, double *out)
+{
+    const unsigned L = n - M;
+    const uint64_t mlow = ((uint64_t)1 << M) - 1;
+    double ar = 1.0, ai = 0.0;
+    for (unsigned l = M; l < n; l++) chain_hadamard(&ar, &ai, 0, 0);
+    /* (out_bit 0 and 1 give the same value when the input is in lo: s*lo + s*0 and s*lo + (-s)*0 differ only in the
+     * sign of a zero term that the leading "0 +" absorbs; checked in the CPU suite against the pairwise oracle) */
+    unsigned long long atox[64];
+    unsigned xr = 1;
+    for (unsigned j = 0; j < L && j < 64; j++) { atox[j] = ctrl_power(a, xr, j, C, ref_intpow) % C; xr *= 2; }
+    for (uint64_t w = 0; w < count; w++) {
+        const uint64_t i = first + w, l = i >> M;
+        unsigned long long f = 1;
+        int moved_ok = 1;
+        for (unsigned j = 0; j < L; j++)
+            if ((l >> j) & 1) {
+                if (f < C) f = (atox[j] * f) % C;           /* Q:631-634: residues >= C stay */
+            }
+        (void)moved_ok;
+        if ((i & mlow) == f && f <= mlow) { out[2 * w] = ar; out[2 * w + 1] = ai; }
+        else { out[2 * w] = 0.0; out[2 * w + 1] = 0.0; }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
 /* measurement, norm                                                         */
 /* ------------------------------------------------------------------------ */
 int orc_measure_range(const double *amp, uint64_t first, uint64_t count,

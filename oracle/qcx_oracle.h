@@ -108,6 +108,10 @@ double orc_norm2(const double *amp, unsigned n);        /* T:28-37, sequential *
 /* CPU twin of the product's device-side synthetic-state generator */
 void orc_fill_random(double *amp, uint64_t first, uint64_t count, uint64_t seed, double scale);
 
+/* whole circuits on a basis-state input, evaluated per output index (no 2^n array): tests at n = 28 / 30 */
+void orc_basis_iqft_window(uint64_t x, unsigned n, unsigned M, uint64_t first, uint64_t count, double *out);
+void orc_shor_front_window(unsigned n, unsigned M, unsigned C, unsigned a, int ref_intpow,
+                           uint64_t first, uint64_t count, double *out);
 void orc_polar(double theta, double *re, double *im);   /* gsl_complex_polar(1, theta) as gcc -O2 + glibc evaluate it */
 
 /* ---- host-side scalar helpers restated from the reference ---------------- */

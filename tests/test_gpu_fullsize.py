@@ -185,3 +185,65 @@ def test_shor_n24_circuit_vs_oracle(qc, ob):
         # period 6: the measured x~/2^L sits next to a multiple of 1/6
         w = qc.read_omega(idx, reg)
         assert min(abs(w - k / 6.0) for k in range(7)) < 2.0 ** -(L - 3)
+
+
+# ---- BASELINE config 3 at its full size: the n = 28 inverse-QFT schedule (28 H + 378 controlled phases, Q:678-690) -------
+def _basis_state(qc, reg, x):
+    qc.reset_register(reg)                      # |0...01>
+    if x != 1:
+        reg.write(np.array([0.0, 0.0]), first=1)
+        reg.write(np.array([1.0, 0.0]), first=x)
+
+
+@pytest.mark.parametrize("mode", [0, -1], ids=["fused passes (default)", "one launch per gate"])
+def test_config3_iqft_n28_on_basis_states_vs_oracle(qc, ob, mode):
+    """On a basis state every Hadamard of the schedule meets a pair with one zero member, so each output amplitude is
+    one scalar chain of the reference's sums: the oracle evaluates windows of the 2^28 result per index
+    (orc_basis_iqft_window, pinned to the full oracle in tests/test_oracle_pinning.py) and the GPU result -- through the
+    DEFAULT path of qcx_inverse_QFT, the fused passes, and through one launch per gate -- must carry the same bits."""
+    n = 28
+    rs = np.random.RandomState(28)
+    with qc.Register(n, 0) as reg:
+        reg.set_fusion(mode)
+        for x in (0, (1 << n) - 1, 0x5A5A5A5 & ((1 << n) - 1), (1 << (n - 1)) | 1):
+            _basis_state(qc, reg, x)
+            qc.inverse_QFT(reg)
+            assert abs(reg.norm2() - 1.0) < 1e-12
+            starts = {0, (1 << n) - (1 << W), x & ~((1 << W) - 1)} | {int(v) << W for v in rs.randint(0, 1 << (n - W), 4)}
+            for s in sorted(starts):
+                got = reg.read(s, 1 << W)
+                assert np.array_equal(bits(got), bits(ob.basis_iqft_window(x, n, 0, s, 1 << W))), (mode, x, s)
+
+
+def test_config3_iqft_n28_dense_input_fused_equals_per_gate(qc, ob):
+    """a dense random input: the default (fused) path and one launch per gate give the same bits, and the norm is kept"""
+    n = 28
+    rs = np.random.RandomState(3)
+    with qc.Register(n, 0) as a, qc.Register(n, 0) as b:
+        a.fill_random(11); b.fill_random(11)
+        n0 = a.norm2()
+        b.set_fusion(-1)
+        qc.inverse_QFT(a); qc.inverse_QFT(b)
+        assert abs(a.norm2() - n0) < 1e-12 and abs(b.norm2() - n0) < 1e-12
+        for s in sorted({0, (1 << n) - (1 << W)} | {int(v) << W for v in rs.randint(0, 1 << (n - W), 8)}):
+            assert np.array_equal(bits(a.read(s, 1 << W)), bits(b.read(s, 1 << W))), s
+
+
+# ---- BASELINE config 5's circuit at n = 30 (L = 25, M = 5): the Hadamard layer + the modular-multiply ladder vs the oracle
+@pytest.mark.parametrize("mode", [1, -1], ids=["queued -> fused passes", "one launch per gate"])
+def test_config5_front_n30_vs_oracle(qc, ob, mode):
+    L, M, Cn, a = N_FULL - 5, 5, 21, 2
+    n = L + M
+    rs = np.random.RandomState(5)
+    with qc.Register(L, M) as reg:
+        reg.set_fusion(mode)
+        qc.reset_register(reg)
+        for l in range(M, n):
+            qc.hadamard_gate(l, reg)                                          # Q:720-722
+        atox = a % Cn
+        for l in range(M, n):
+            qc.c_amodc_gate(Cn, atox, l, reg)                                 # Q:728-731 with exact powers
+            atox = atox * atox % Cn
+        assert abs(reg.norm2() - 1.0) < 1e-12
+        for s in sorted({0, (1 << n) - (1 << W)} | {int(v) << W for v in rs.randint(0, 1 << (n - W), 6)}):
+            assert np.array_equal(bits(reg.read(s, 1 << W)), bits(ob.shor_front_window(n, M, Cn, a, s, 1 << W))), (mode, s)

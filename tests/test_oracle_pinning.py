@@ -225,3 +225,35 @@ def test_measure_edges(ob):
     assert ob.measure(z, n, 0.5) == 7 and z[14] == 1.0   # never reached: falls through to the last index
     hit, idx, cum = ob.measure_range(a[8:], 4, 4, 7, 0.0, 0.5)
     assert hit and idx == 5 and cum == 1.0
+
+
+# ---- per-index chain evaluators (used by the full-size GPU tests) pinned to the full pairwise oracle ----------------
+@pytest.mark.parametrize("n,M", [(5, 0), (9, 0), (10, 3), (12, 5), (14, 0)])
+def test_basis_state_iqft_chain_equals_the_full_oracle(ob, n, M):
+    rs = np.random.RandomState(n * 31 + M)
+    xs = {0, 1, (1 << n) - 1, 1 << (n - 1)} | {int(v) for v in rs.randint(0, 1 << n, 5)}
+    for x in sorted(xs):
+        full = np.zeros(2 << n)
+        full[2 * x] = 1.0
+        ob.iqft(full, n, M)
+        got = ob.basis_iqft_window(x, n, M, 0, 1 << n)
+        assert np.array_equal(got.view(np.uint64), full.view(np.uint64)), (n, M, x)
+        w = ob.basis_iqft_window(x, n, M, 37, 200) if n >= 9 else None
+        if w is not None:
+            assert np.array_equal(w.view(np.uint64), full[74:474].view(np.uint64))
+
+
+@pytest.mark.parametrize("L,M,Cn,a,quirk", [(3, 4, 15, 7, False), (6, 5, 21, 2, False), (8, 5, 21, 2, False), (5, 5, 21, 2, True),
+                                             (7, 6, 35, 2, False), (9, 5, 21, 5, False)])
+def test_shor_front_chain_equals_the_full_oracle(ob, L, M, Cn, a, quirk):
+    n = L + M
+    full = np.zeros(2 << n); ob.reset(full, n)
+    for l in range(M, n):
+        ob.hadamard(full, n, l)
+    x = 1
+    for l in range(M, n):
+        atox = ob.ref_intpow(a, x) if quirk else ob.modpow(a, 1 << (l - M), Cn)
+        ob.camodc(full, n, M, Cn, atox, l)
+        x *= 2
+    got = ob.shor_front_window(n, M, Cn, a, 0, 1 << n, ref_intpow=quirk)
+    assert np.array_equal(got.view(np.uint64), full.view(np.uint64))

@@ -7,12 +7,21 @@
  * cpu_baseline leg may load it; the product (libqcx.so, quantumcomputer_amd/,
  * host/) never links, imports or executes anything under oracle/.
  *
- * Pinning status: the reference cannot be compiled in this image (it needs
- * GSL 2.6, which is absent, and writing a stand-in for it is not allowed), so
- * there is no oracle/_ref.  The oracle is pinned by the reference's own
- * known-answer material (Q:25-29, Q:78-79, report Table I, report SIV.A) and by
- * the reference outputs recorded in SURVEY.md Appendix C, committed as
- * tests/golden/survey_appendix_c.json.  See DESIGN.md "Oracle and pinning".
+ * PARITY UNPINNED.  The reference cannot be compiled in this image (it needs
+ * GSL 2.6, which is absent; a stand-in for a missing library is not allowed),
+ * so there is no oracle/_ref, and the reference holds no golden vectors or
+ * tests of its own for this path.  What the oracle IS checked against
+ * (tests/test_oracle_pinning.py, tests/test_independent_derivation.py):
+ *   - the reference's published known answers (Q:25-29, Q:78-79, report
+ *     Table I and SIV.A) -- scenarios, not vectors;
+ *   - an independent second derivation: dense Kronecker-product operators
+ *     built from the base matrices of Q:210-225 (agreement to 1e-13), the
+ *     DFT-matrix identity of the inverse-QFT schedule, numpy's running sum
+ *     for the measurement rule;
+ *   - tests/golden/survey_appendix_c.json: values the survey session read off
+ *     a build of qc_shor.c against a GSL stand-in; no generator is committed,
+ *     so by this project's rules they pin nothing -- kept as regression values.
+ * See DESIGN.md "Oracle and pinning".
  *
  * Two forms of every gate are provided:
  *   orc_lit_*   the LITERAL algorithm: scan index pairs, build a COO sparse

@@ -96,11 +96,15 @@ def test_golden_reference_overflow_behaviour(ob):
 
 
 def test_report_probability_conservation_and_table1(ob):
-    # Report sIV.A: |sum P - 1| <= 2.4e-15 while factoring 39 with 12 qubits
-    s = shor_state(ob, 39, 6, 6, 2)
-    # (the report does not state L, M or a for that run; same order of magnitude is what can be pinned)
-    assert abs(ob.norm2(s, 12) - 1.0) <= 4 * GOLD["report"]["max_total_probability_deviation_12_qubits"]
-    # Table I: omega uniform over {0, 1/4, 1/2, 3/4}
+    """Report sIV.A / Fig. 2: total probability tracked gate by gate while factoring 39 with 12 qubits and 52 gate
+    applications (8 + 8 + 36, i.e. L = 8, M = 4: Fig. 2; M = 4 cannot hold 39, which the reference only
+    warns about, Q:343): min deviation 2e-16, max 2.4e-15.  The report does not give the trial integer, so the run
+    itself cannot be reproduced; what is pinned is the published ORDER OF MAGNITUDE on every 12-qubit shape at hand
+    (LABELLED: parameters below are ours, not the report's)."""
+    bound = 4 * GOLD["report"]["max_total_probability_deviation_12_qubits"]
+    for C, L, M, a in ((39, 6, 6, 2), (39, 6, 6, 7), (15, 8, 4, 7), (21, 7, 5, 2)):
+        assert abs(ob.norm2(shor_state(ob, C, L, M, a), 12) - 1.0) <= bound
+    # Table I: omega uniform over {0, 1/4, 1/2, 3/4} (the seeded statistics are in tests/test_independent_derivation.py)
     pr = xtilde_probs(shor_state(ob, 15, 3, 4, 7), 3, 4)
     assert sorted(pr) == [0, 2, 4, 6] and all(abs(v - 0.25) < 1e-15 for v in pr.values())
 

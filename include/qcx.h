@@ -76,6 +76,11 @@ int  qcx_M_size(const qcx_register *reg);
 int  qcx_register_create_sharded(int L_size, int M_size, unsigned nshards, const int *devices, qcx_register **out);
 unsigned qcx_register_shards(const qcx_register *reg);      /* 1 for an unsharded register */
 int  qcx_sharded_stats(qcx_register *reg, unsigned long *exchanges, unsigned long *pack_passes);
+/* Multi-path striping for fewer shards than GPUs on the node: the listed GPUs (which hold no shard)
+ * relay a share of every chunk of every trade, so that a pair of shards exchanges over several xGMI links instead of its
+ * one direct link.  nrelays = 0 turns it off (default; QCX_SHARD_RELAYS="4,5,6,7" sets it at creation).  Results are
+ * the same bits either way. */
+int  qcx_sharded_set_relays(qcx_register *reg, unsigned nrelays, const int *devices);
 /* launch on a caller-owned hipStream_t (NULL = the register's own stream) */
 int  qcx_register_set_stream(qcx_register *reg, void *hip_stream);
 int  qcx_synchronize(qcx_register *reg);

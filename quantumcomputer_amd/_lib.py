@@ -36,6 +36,7 @@ SIGNATURES = {
     "qcx_register_create_sharded": (_i, [_i, _i, _u, C.POINTER(_i), C.POINTER(_p)]),
     "qcx_register_shards": (_u, [_p]),
     "qcx_sharded_stats": (_i, [_p, C.POINTER(_ul), C.POINTER(_ul)]),
+    "qcx_sharded_set_relays": (_i, [_p, _u, C.POINTER(_i)]),
     "qcx_num_qubits": (_u, [_p]),
     "qcx_num_states": (_ul, [_p]),
     "qcx_L_size": (_i, [_p]),
@@ -93,6 +94,7 @@ _EXTRA = {
     "qcx_measure_last_stats": (_i, [C.POINTER(_u), C.POINTER(_u)]),
     "qcx_sharded_trace": (_i, [_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "qcx_sharded_restore_identity": (_i, [_p]),
+    "qcx_sharded_relay_stats": (_i, [_p, C.POINTER(_u), C.POINTER(_ul)]),
     "qcx_sharded_layout": (_i, [_p, C.POINTER(_u), _u]),
 }
 

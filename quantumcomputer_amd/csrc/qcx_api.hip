@@ -726,7 +726,27 @@ extern "C" int qcx_register_create_sharded(int L, int M, unsigned nshards, const
     const int s = sh_create(L, M, nshards, devices, &r->sh);
     if (s != QCX_NO_ERROR) { free(r); return s; }
     if (!r->sh->dry && (hipEventCreate(&r->ev0) != hipSuccess || hipEventCreate(&r->ev1) != hipSuccess)) { sh_free(r->sh); free(r); return QCX_HIP_ERROR; }
+    if (const char *e = getenv("QCX_SHARD_RELAYS")) {             // "4,5,6,7": GPUs without a shard that relay stripes of every trade
+        int devs[8], nr = 0;
+        for (const char *p = e; *p && nr < 8; nr++) { devs[nr] = atoi(p); while (*p && *p != ',') p++; if (*p == ',') p++; }
+        const int rs = sh_set_relays(r->sh, (unsigned)nr, devs);
+        if (rs != QCX_NO_ERROR) { sh_free(r->sh); (void)hipEventDestroy(r->ev0); (void)hipEventDestroy(r->ev1); free(r); return rs; }
+    }
     *out = r;
+    return QCX_NO_ERROR;
+}
+
+extern "C" int qcx_sharded_set_relays(qcx_register *r, unsigned nrelays, const int *devices)
+{
+    if (!r || !r->sh) return QCX_BAD_ARGUMENTS;
+    return sh_set_relays(r->sh, nrelays, devices);
+}
+
+extern "C" int qcx_sharded_relay_stats(qcx_register *r, unsigned *nrelays, unsigned long *relayed_bytes)     // diagnostics
+{
+    if (!r || !r->sh) return QCX_BAD_ARGUMENTS;
+    if (nrelays) *nrelays = (unsigned)r->sh->relay_dev.size();
+    if (relayed_bytes) *relayed_bytes = r->sh->relayed_bytes;
     return QCX_NO_ERROR;
 }
 

@@ -1340,9 +1340,14 @@ __global__ __launch_bounds__(BLOCK) void k_swap_bits(const amp_t *__restrict__ s
 // contiguous in the destination.
 // ---------------------------------------------------------------------------
 struct PushDst { amp_t *dst[16]; };
+// Multi-path striping: with fewer shards than GPUs on the node, the chunk for another shard is cut into
+// a direct stripe (blocks [0, nb_direct) of the chunk, stored into the owner's buffer as above) and one stripe per RELAY
+// GPU, stored into that GPU's staging area instead (slot = me * W + chunk, `stage_amps` amplitudes each); the host then
+// forwards the staged stripes to their owners.  Each stripe rides a different xGMI link out of this GPU.
+struct PushRelay { amp_t *stage[8]; unsigned nrelays; uint32_t nb_direct, nb_relay; uint64_t stage_amps; };
 
 template <int BLOCK, bool DEAL>     // DEAL needs BLOCK | 2^zone_lo; small shards take the plain element order
-__global__ __launch_bounds__(BLOCK) void k_pack_push(const amp_t *__restrict__ src, PushDst D, uint64_t count, SwapBits S,
+__global__ __launch_bounds__(BLOCK) void k_pack_push(const amp_t *__restrict__ src, PushDst D, PushRelay Rl, uint64_t count, SwapBits S,
                                                        unsigned zone_lo, unsigned klog, unsigned me)
 {
     const unsigned W = 1u << klog;
@@ -1355,7 +1360,17 @@ __global__ __launch_bounds__(BLOCK) void k_pack_push(const amp_t *__restrict__ s
             const uint64_t x = ((i >> S.a[m]) ^ (i >> S.b[m])) & 1u;
             i ^= (x << S.a[m]) | (x << S.b[m]);
         }
-        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), D.dst[chunk] + (((uint64_t)me << zone_lo) | low));
+        amp_t *to = D.dst[chunk] + (((uint64_t)me << zone_lo) | low);
+        if (DEAL && Rl.nrelays && chunk != me) {
+            const uint64_t lb = low / BLOCK;                            // block of the chunk: uniform over the workgroup
+            if (lb >= Rl.nb_direct) {
+                unsigned path = (unsigned)((lb - Rl.nb_direct) / Rl.nb_relay);
+                if (path >= Rl.nrelays) path = Rl.nrelays - 1;            // (the last relay takes the remainder)
+                const uint64_t first = ((uint64_t)Rl.nb_direct + (uint64_t)path * Rl.nb_relay) * BLOCK;
+                to = Rl.stage[path] + (uint64_t)(me * W + chunk) * Rl.stage_amps + (low - first);
+            }
+        }
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), to);
     }
 }
 

@@ -44,6 +44,14 @@ struct ShardSet {
     unsigned min_evict = 0, zone_lo = 0;
     unsigned long exchanges = 0, pack_passes = 0;
     std::vector<hipEvent_t>  ev_a, ev_b;
+    // multi-path striping: GPUs that hold no shard relay a share of every chunk (qcx_sharded_set_relays)
+    std::vector<int>         relay_dev;
+    std::vector<hipStream_t> relay_st;
+    std::vector<hipEvent_t>  relay_ev;
+    std::vector<amp_t *>     relay_stage;
+    uint32_t nb_direct = 0, nb_relay = 0;         // blocks of 256 amplitudes of a chunk: direct stripe, each relay's stripe
+    uint64_t stage_amps = 0;                      // amplitudes per staging slot (the last relay's stripe, the longest)
+    unsigned long relayed_bytes = 0;
     int      fusion = 1;                          // 1: each shard's gate list goes through the fused-pass scheduler; -1/0: one launch per gate
     size_t   max_queue = 8192;
     std::string trace;
@@ -58,10 +66,23 @@ static void sh_identity_perm(ShardSet *sh)
     for (unsigned q = 0; q < sh->n; q++) { sh->perm[q] = q; sh->inv[q] = q; }
 }
 
+static void sh_drop_relays(ShardSet *sh)
+{
+    for (size_t i = 0; i < sh->relay_dev.size(); i++) {
+        (void)hipSetDevice(sh->relay_dev[i]);
+        if (i < sh->relay_st.size() && sh->relay_st[i]) { (void)hipStreamSynchronize(sh->relay_st[i]); (void)hipStreamDestroy(sh->relay_st[i]); }
+        if (i < sh->relay_ev.size() && sh->relay_ev[i]) (void)hipEventDestroy(sh->relay_ev[i]);
+        if (i < sh->relay_stage.size() && sh->relay_stage[i]) (void)hipFree(sh->relay_stage[i]);
+    }
+    sh->relay_dev.clear(); sh->relay_st.clear(); sh->relay_ev.clear(); sh->relay_stage.clear();
+    sh->nb_direct = sh->nb_relay = 0; sh->stage_amps = 0;
+}
+
 static void sh_free(ShardSet *sh)
 {
     if (!sh) return;
     if (!sh->dry) {
+        sh_drop_relays(sh);
         for (unsigned r = 0; r < sh->W; r++) {
             if (r < sh->dev.size()) (void)hipSetDevice(sh->dev[r]);
             if (r < sh->st.size() && sh->st[r]) { (void)hipStreamSynchronize(sh->st[r]); (void)qcx_shard_release_stream(sh->st[r]); }
@@ -265,22 +286,50 @@ static int sh_exchange(ShardSet *sh, const SwapList &swaps)
         PushDst D;
         memset(&D, 0, sizeof D);
         for (unsigned c = 0; c < W; c++) D.dst[c] = sh->buf[sh->cur ^ 1][c];
+        PushRelay Rl;
+        memset(&Rl, 0, sizeof Rl);
+        const unsigned R = (sh->zone_lo >= 8) ? (unsigned)sh->relay_dev.size() : 0u;
+        if (R) {
+            Rl.nrelays = R; Rl.nb_direct = sh->nb_direct; Rl.nb_relay = sh->nb_relay; Rl.stage_amps = sh->stage_amps;
+            for (unsigned i = 0; i < R; i++) Rl.stage[i] = sh->relay_stage[i];
+        }
         const uint64_t count = (uint64_t)1 << sh->n_local;
         for (unsigned r = 0; r < W; r++) {
             SH_DEV(sh, r);
             if (sh->zone_lo >= 8)
                 hipLaunchKernelGGL((k_pack_push<256, true>), dim3(grid_for(count, 256, 0, 256)), dim3(256), 0, sh->st[r],
-                                   (const amp_t *)sh->buf[sh->cur][r], D, count, S, sh->zone_lo, sh->k, r);
+                                   (const amp_t *)sh->buf[sh->cur][r], D, Rl, count, S, sh->zone_lo, sh->k, r);
             else
                 hipLaunchKernelGGL((k_pack_push<64, false>), dim3(grid_for(count, 64, 0, 64)), dim3(64), 0, sh->st[r],
-                                   (const amp_t *)sh->buf[sh->cur][r], D, count, S, sh->zone_lo, sh->k, r);
+                                   (const amp_t *)sh->buf[sh->cur][r], D, Rl, count, S, sh->zone_lo, sh->k, r);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(sh->ev_b[r], sh->st[r]));
         }
-        // (2) a shard's new buffer is complete when every shard has pushed
+        // (1b) the relays forward their staged stripes to the owners once every shard has pushed
+        if (R) {
+            const uint64_t per_chunk_blocks = ((uint64_t)1 << sh->zone_lo) / 256;
+            for (unsigned i = 0; i < R; i++) {
+                HIP_TRY(hipSetDevice(sh->relay_dev[i]));
+                for (unsigned r = 0; r < W; r++) HIP_TRY(hipStreamWaitEvent(sh->relay_st[i], sh->ev_b[r], 0));
+                const uint64_t b0 = (uint64_t)sh->nb_direct + (uint64_t)i * sh->nb_relay;
+                const uint64_t b1 = (i + 1 == R) ? per_chunk_blocks : b0 + sh->nb_relay;
+                const size_t bytes = (size_t)(b1 - b0) * 256 * sizeof(amp_t);
+                for (unsigned r = 0; r < W && bytes; r++)
+                    for (unsigned c = 0; c < W; c++) {
+                        if (c == r) continue;
+                        amp_t *to = sh->buf[sh->cur ^ 1][c] + (((uint64_t)r << sh->zone_lo) | (b0 * 256));
+                        const amp_t *from = sh->relay_stage[i] + (uint64_t)(r * W + c) * sh->stage_amps;
+                        HIP_TRY(hipMemcpyAsync(to, from, bytes, hipMemcpyDeviceToDevice, sh->relay_st[i]));
+                        sh->relayed_bytes += bytes;
+                    }
+                HIP_TRY(hipEventRecord(sh->relay_ev[i], sh->relay_st[i]));
+            }
+        }
+        // (2) a shard's new buffer is complete when every shard has pushed (and every relay has forwarded)
         for (unsigned r = 0; r < W; r++) {
             SH_DEV(sh, r);
             for (unsigned c = 0; c < W; c++) if (c != r) HIP_TRY(hipStreamWaitEvent(sh->st[r], sh->ev_b[c], 0));
+            for (unsigned i = 0; i < R; i++) HIP_TRY(hipStreamWaitEvent(sh->st[r], sh->relay_ev[i], 0));
         }
         sh->cur ^= 1;
     }
@@ -400,6 +449,56 @@ static int sh_sync(ShardSet *sh)
     QCX_TRY(sh_flush(sh));
     if (sh->dry) return QCX_NO_ERROR;
     for (unsigned r = 0; r < sh->W; r++) { SH_DEV(sh, r); HIP_TRY(hipStreamSynchronize(sh->st[r])); }
+    return QCX_NO_ERROR;
+}
+
+// Relay GPUs for multi-path striping.  Shares: with R relays and W shards the direct link of a pair carries the
+// fraction a = (W-1)/(R+W-1) of its chunk and every relay 1/(R+W-1) of EVERY chunk, which loads all links out of a GPU
+// equally (a relay link carries the stripes of the W-1 destinations).  Both hops of a relayed stripe cost link time,
+// so the model gain is  1 / (2 a)  for W = 2 (3.5x with 6 relays) and shrinks as W grows (tools/model_sharded.py).
+static int sh_set_relays(ShardSet *sh, unsigned nrelays, const int *devices)
+{
+    if (sh->dry) return QCX_NO_ERROR;
+    QCX_TRY(sh_sync(sh));
+    sh_drop_relays(sh);
+    if (!nrelays) return QCX_NO_ERROR;
+    if (nrelays > 8 || !devices) return QCX_BAD_ARGUMENTS;
+    if (sh->zone_lo < 8) return QCX_NO_ERROR;                      // tiny shards: nothing worth striping
+    const uint64_t blocks = ((uint64_t)1 << sh->zone_lo) / 256;
+    if (blocks < 2 * (uint64_t)(nrelays + 1)) return QCX_NO_ERROR;
+    const unsigned R = nrelays, W = sh->W;
+    uint64_t nb_relay = blocks / (R + W - 1);
+    if (!nb_relay) nb_relay = 1;
+    uint64_t nb_direct = blocks - nb_relay * R;                   // direct takes what the relays leave (>= its share)
+    const uint64_t last = blocks - nb_direct - nb_relay * (R - 1);
+    sh->nb_direct = (uint32_t)nb_direct; sh->nb_relay = (uint32_t)nb_relay;
+    sh->stage_amps = std::max(nb_relay, last) * 256;
+    int ndev = 0;
+    QCX_TRY(qcx_device_count(&ndev));
+    for (unsigned i = 0; i < R; i++) {
+        if (devices[i] < 0 || devices[i] >= ndev) { sh_drop_relays(sh); set_error("relay device %d: %d visible", devices[i], ndev); return QCX_HIP_ERROR; }
+        sh->relay_dev.push_back(devices[i]);
+        sh->relay_st.push_back(nullptr); sh->relay_ev.push_back(nullptr); sh->relay_stage.push_back(nullptr);
+        hipError_t e = hipSetDevice(devices[i]);
+        for (unsigned c = 0; c < W && e == hipSuccess; c++) {
+            if (sh->dev[c] == devices[i]) continue;
+            hipError_t pe = hipDeviceEnablePeerAccess(sh->dev[c], 0);            // relay -> owners (forwarding)
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) e = pe;
+            (void)hipGetLastError();
+            if (e == hipSuccess) e = hipSetDevice(sh->dev[c]);
+            if (e == hipSuccess) { pe = hipDeviceEnablePeerAccess(devices[i], 0);  // shards -> relay (staging stores)
+                                   if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) e = pe; (void)hipGetLastError(); }
+            if (e == hipSuccess) e = hipSetDevice(devices[i]);
+        }
+        if (e == hipSuccess) e = hipStreamCreate(&sh->relay_st[i]);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sh->relay_ev[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipMalloc(&sh->relay_stage[i], (size_t)W * W * sh->stage_amps * sizeof(amp_t));
+        if (e != hipSuccess) {
+            set_error("relay on device %d: %s", devices[i], hipGetErrorString(e));
+            sh_drop_relays(sh);
+            return e == hipErrorOutOfMemory ? QCX_INSUFFICIENT_MEMORY : QCX_HIP_ERROR;
+        }
+    }
     return QCX_NO_ERROR;
 }
 

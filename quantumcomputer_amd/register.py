@@ -141,6 +141,16 @@ class Register:
         check(lib().qcx_sharded_stats(self._h, C.byref(e), C.byref(p)), "qcx_sharded_stats")
         return e.value, p.value
 
+    def set_relays(self, devices):
+        """multi-path striping: GPUs without a shard relay a share of every trade ([] = off)"""
+        dv = (C.c_int * max(len(devices), 1))(*devices)
+        check(lib().qcx_sharded_set_relays(self._h, len(devices), dv), "qcx_sharded_set_relays")
+
+    def relay_stats(self):
+        n, b = C.c_uint(0), C.c_ulong(0)
+        check(lib().qcx_sharded_relay_stats(self._h, C.byref(n), C.byref(b)), "qcx_sharded_relay_stats")
+        return n.value, b.value
+
     def sharded_trace(self):
         """diagnostics: the steps a dry-run sharded register has scheduled since the last call, as text"""
         need = C.c_size_t(0)

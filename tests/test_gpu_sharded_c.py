@@ -169,3 +169,25 @@ def test_host_driver_sharded():
             found += 1
             assert "Factors of 21 found: (3, 7)" in shard.stdout or "Factors of 21 found: (7, 3)" in shard.stdout
     assert found >= 1
+
+
+@pytest.mark.parametrize("shards,n,relays", [(2, 14, 1), (2, 16, 6), (4, 16, 4), (8, 18, 2)])
+def test_multi_path_striping_gives_the_same_bits(qc, ob, shards, n, relays):
+    """relays (here: the same GPU again) carry a share of every chunk of every trade through staging buffers and a
+    forwarding copy; the amplitudes must come out exactly as without them"""
+    with qc.Register(n, 0, shards=shards, devices=[0]) as reg:
+        reg.set_relays([0] * relays)
+        assert reg.relay_stats()[0] == relays
+        reg.fill_random(8)
+        want = ob.fill_random(n, 8)
+        for _ in range(2):
+            for q in list(range(n - 1, n - 6, -1)) + [0, 5, n - 1]:
+                qc.hadamard_gate(q, reg); ob.hadamard(want, n, q)
+            qc.c_phase_shift_gate(n - 1, 2, 0.7, reg); ob.cphase(want, n, n - 1, 2, 0.7)
+        assert np.array_equal(bits(reg.read()), bits(want))
+        ex, _ = reg.sharded_stats()
+        assert ex >= 2 and reg.relay_stats()[1] > 0                          # stripes really went through the relays
+        reg.set_relays([])                                                     # and off again
+        for q in (n - 1, n - 2):
+            qc.hadamard_gate(q, reg); ob.hadamard(want, n, q)
+        assert np.array_equal(bits(reg.read()), bits(want))

@@ -95,13 +95,40 @@ def run(world, n_local, sweeps, gate_gbs, link_gbs, slices_log2, overlap):
         sharded.dist = real
 
 
+def c_path_striping_model(n_local, gate_gbs, link_gbs, gpus_on_node=8):
+    """The one-process sharded register (csrc/qcx_sharded.inc.h): a trade is ONE pack+push kernel per GPU; a pair of shards
+    moves S = 16 * 2^(n_local - k) bytes each way.  Without relays that rides the pair's one direct link.  With R relay GPUs
+    (the GPUs of the node that hold no shard) the direct link carries the share a = (W-1)/(R+W-1) and each relay link
+    1/(R+W-1) of each of the W-1 chunks; a relayed stripe costs two hops, done one after the other (push, then forward).
+    MODEL, not a measurement: link_gbs per direction per link, no protocol overhead."""
+    print("one-process sharded register, time of one trade (model):")
+    for W in (2, 4, 8):
+        k = W.bit_length() - 1
+        S = 16.0 * 2.0 ** (n_local - k)
+        direct_ms = S / (link_gbs * 1e9) * 1e3
+        pack_ms = 32.0 * 2.0 ** n_local / (gate_gbs * 1e9) * 1e3           # the same pass run locally (HBM-bound floor)
+        R = gpus_on_node - W
+        line = f"  W={W}: chunk {S / 2**30:.1f} GiB per pair, direct link only {max(direct_ms, pack_ms):7.1f} ms"
+        if R > 0:
+            a = (W - 1) / (R + W - 1)
+            hop_ms = a * S / (link_gbs * 1e9) * 1e3                         # every link out of a GPU carries a * S in phase A ...
+            line += f"; {R} relays: direct share {a:.3f}, two phases of {hop_ms:6.1f} ms = {max(2 * hop_ms, pack_ms):7.1f} ms ({direct_ms / (2 * hop_ms):.2f}x)"
+        else:
+            line += "; no idle GPU to relay through (all links already busy)"
+        print(line)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n-local", type=int, default=30)
     ap.add_argument("--sweeps", type=int, default=6)
     ap.add_argument("--gate-gbs", type=float, default=6430.0)
     ap.add_argument("--link-gbs", type=float, default=70.0)
+    ap.add_argument("--c-path", action="store_true", help="only the striping model of the one-process sharded register")
     a = ap.parse_args()
+    if a.c_path:
+        c_path_striping_model(a.n_local, a.gate_gbs, a.link_gbs)
+        return
     base = None
     for world in (1, 2, 4, 8):
         for sl, ov in ((3, True), (0, False)):

@@ -125,7 +125,10 @@ int  qcx_measure_state_r(qcx_register *reg, double r, unsigned long *state_num);
 /* ---- state access (replaces gsl_vector_complex_get/set uses, T:7-37) ------- */
 int  qcx_state_read(qcx_register *reg, unsigned long first, unsigned long count, double *out_re_im);
 int  qcx_state_write(qcx_register *reg, unsigned long first, unsigned long count, const double *in_re_im);
-int  qcx_norm2(qcx_register *reg, double *total_probability);                      /* T:28-37 */
+int  qcx_norm2(qcx_register *reg, double *total_probability);                      /* T:28-37, summed as a tree (fast) */
+/* the same total with the reference's own summation order (index-ascending, one addition per amplitude): the bits
+ * check_normalisation prints (T:28-37) */
+int  qcx_total_probability(qcx_register *reg, double *total_probability);
 /* State files (golden vectors, debugging, checkpoint): a 64-byte header ("QCXSTATE", version,
  * L, M, 2^n, FNV-1a 64 checksum) followed by the amplitudes as interleaved little-endian binary64 (re, im).  Streamed
  * in 64 MiB pieces.  Load requires a register of the same L and M and verifies the checksum. */

@@ -127,7 +127,7 @@ static inline void display_state(Register reg)
 static inline void check_normalisation(Register reg)
 {
     double total = 0.0;
-    qcx_compat_die(qcx_norm2(reg.handle, &total), "check_normalisation");
+    qcx_compat_die(qcx_total_probability(reg.handle, &total), "check_normalisation");     /* sequential sum, as T:28-37 */
     printf("Total Probability: %.16f\n", total);
 }
 

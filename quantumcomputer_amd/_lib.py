@@ -60,6 +60,7 @@ SIGNATURES = {
     "qcx_state_read": (_i, [_p, _ul, _ul, _p]),
     "qcx_state_write": (_i, [_p, _ul, _ul, _p]),
     "qcx_norm2": (_i, [_p, C.POINTER(_d)]),
+    "qcx_total_probability": (_i, [_p, C.POINTER(_d)]),
     "qcx_device_pointer": (_p, [_p]),
     "qcx_state_fill_random": (_i, [_p, _u64]),
     "qcx_shard_fill_random": (_i, [_p, _u, _u64, _u64, _d, _p]),

@@ -114,10 +114,13 @@ struct Tune {
     long meas_min_log2 = 12;   // shards below 2^this amplitudes use the single-wave scan (tools/probe_shots.py)
 };
 static Tune g_tune;
+static std::mutex g_tune_mutex;
+// every entry point works on ONE consistent snapshot of the tunables (qcx_tune_set may run on another thread)
+static Tune tune_now() { std::lock_guard<std::mutex> lock(g_tune_mutex); return g_tune; }
 
 extern "C" int qcx_tune_set(const char *key, long value)
 {
-#define K(name) if (!strcmp(key, #name)) { g_tune.name = value; return QCX_NO_ERROR; }
+#define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); g_tune.name = value; return QCX_NO_ERROR; }
     K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_camruns) K(fuse_pipe) K(fuse_pipe_grid) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ)
 #undef K
     return QCX_BAD_ARGUMENTS;
@@ -125,7 +128,7 @@ extern "C" int qcx_tune_set(const char *key, long value)
 
 extern "C" long qcx_tune_get(const char *key)
 {
-#define K(name) if (!strcmp(key, #name)) return g_tune.name;
+#define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); return g_tune.name; }
     K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_camruns) K(fuse_pipe) K(fuse_pipe_grid) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ)
 #undef K
     return -1;
@@ -338,7 +341,7 @@ extern "C" int qcx_shard_hadamard(void *amp, unsigned n_local, unsigned q, void 
     amp_t *a = (amp_t *)amp;
     const uint64_t namps = (uint64_t)1 << n_local, npairs = namps >> 1;
 
-    Tune t = g_tune;                                 // local copy: the entry point is re-entrant
+    Tune t = tune_now();                             // local copy: the entry point is re-entrant
     if (t.h_variant == 0) {                          // auto: the measured plan
         const HPlan pl = h_plan(q);
         t.h_variant = pl.wave_form ? 2 : 1;
@@ -375,33 +378,33 @@ extern "C" int qcx_shard_hadamard(void *amp, unsigned n_local, unsigned q, void 
 }
 
 template <int NB, int APT, bool NT, int BLOCK>
-static void launch_phase_cfg(amp_t *a, unsigned b0, unsigned b1, double c, double s, uint64_t count, hipStream_t st)
+static void launch_phase_cfg(const Tune &t, amp_t *a, unsigned b0, unsigned b1, double c, double s, uint64_t count, hipStream_t st)
 {
-    const unsigned grid = grid_for(count, (uint64_t)BLOCK * APT, g_tune.ph_grid_cap, BLOCK);
+    const unsigned grid = grid_for(count, (uint64_t)BLOCK * APT, t.ph_grid_cap, BLOCK);
     unsigned glog, slog;
-    long want = g_tune.ph_streams_log2;
+    long want = t.ph_streams_log2;
     if (want < 0) want = (NB == 0 || b0 >= 8) ? 1 : 2;
     stream_map(grid, (uint64_t)grid * BLOCK * APT, count, want, &glog, &slog);
     hipLaunchKernelGGL((k_phase<NB, APT, NT, BLOCK>), dim3(grid), dim3(BLOCK), 0, st, a, b0, b1, c, s, count, glog, slog);
 }
 
 template <int NB, int APT, bool NT>
-static void launch_phase_blk(amp_t *a, unsigned b0, unsigned b1, double c, double s, uint64_t count, hipStream_t st)
+static void launch_phase_blk(const Tune &t, amp_t *a, unsigned b0, unsigned b1, double c, double s, uint64_t count, hipStream_t st)
 {
-    if (g_tune.ph_block == 64) launch_phase_cfg<NB, APT, NT, 64>(a, b0, b1, c, s, count, st);
-    else launch_phase_cfg<NB, APT, NT, 256>(a, b0, b1, c, s, count, st);
+    if (t.ph_block == 64) launch_phase_cfg<NB, APT, NT, 64>(t, a, b0, b1, c, s, count, st);
+    else launch_phase_cfg<NB, APT, NT, 256>(t, a, b0, b1, c, s, count, st);
 }
 
 template <int NB>
-static void launch_phase(amp_t *a, unsigned b0, unsigned b1, double c, double s, uint64_t count, hipStream_t st)
+static void launch_phase(const Tune &t, amp_t *a, unsigned b0, unsigned b1, double c, double s, uint64_t count, hipStream_t st)
 {
-    long apt = g_tune.ph_apt;
+    long apt = t.ph_apt;
     while (apt > 1 && count < (uint64_t)256 * (uint64_t)apt) apt >>= 1;
     // nontemporal only when the touched runs are whole 128-B lines (lowest mask bit >= 3, or no mask)
-    const bool nt = g_tune.ph_nt != 0 && (NB == 0 || b0 >= 3);
-    if (apt >= 4)      { if (nt) launch_phase_blk<NB, 4, true>(a, b0, b1, c, s, count, st); else launch_phase_blk<NB, 4, false>(a, b0, b1, c, s, count, st); }
-    else if (apt == 2) { if (nt) launch_phase_blk<NB, 2, true>(a, b0, b1, c, s, count, st); else launch_phase_blk<NB, 2, false>(a, b0, b1, c, s, count, st); }
-    else               { if (nt) launch_phase_blk<NB, 1, true>(a, b0, b1, c, s, count, st); else launch_phase_blk<NB, 1, false>(a, b0, b1, c, s, count, st); }
+    const bool nt = t.ph_nt != 0 && (NB == 0 || b0 >= 3);
+    if (apt >= 4)      { if (nt) launch_phase_blk<NB, 4, true>(t, a, b0, b1, c, s, count, st); else launch_phase_blk<NB, 4, false>(t, a, b0, b1, c, s, count, st); }
+    else if (apt == 2) { if (nt) launch_phase_blk<NB, 2, true>(t, a, b0, b1, c, s, count, st); else launch_phase_blk<NB, 2, false>(t, a, b0, b1, c, s, count, st); }
+    else               { if (nt) launch_phase_blk<NB, 1, true>(t, a, b0, b1, c, s, count, st); else launch_phase_blk<NB, 1, false>(t, a, b0, b1, c, s, count, st); }
 }
 
 extern "C" int qcx_shard_phase(void *amp, unsigned n_local, uint64_t mask, double cos_t, double sin_t, void *stream)
@@ -416,9 +419,10 @@ extern "C" int qcx_shard_phase(void *amp, unsigned n_local, uint64_t mask, doubl
     if (nb >= 1) b0 = (unsigned)__builtin_ctzll(mask);
     if (nb == 2) b1 = 63u - (unsigned)__builtin_clzll(mask);
     const uint64_t count = ((uint64_t)1 << n_local) >> nb;
-    if (nb == 0) launch_phase<0>(a, 0, 0, cos_t, sin_t, count, st);
-    else if (nb == 1) launch_phase<1>(a, b0, 0, cos_t, sin_t, count, st);
-    else launch_phase<2>(a, b0, b1, cos_t, sin_t, count, st);
+    const Tune t = tune_now();
+    if (nb == 0) launch_phase<0>(t, a, 0, 0, cos_t, sin_t, count, st);
+    else if (nb == 1) launch_phase<1>(t, a, b0, 0, cos_t, sin_t, count, st);
+    else launch_phase<2>(t, a, b0, b1, cos_t, sin_t, count, st);
     HIP_TRY(hipGetLastError());
     return QCX_NO_ERROR;
 }
@@ -447,6 +451,7 @@ extern "C" int qcx_shard_camodc(void *amp, unsigned n_local, unsigned M, unsigne
     A %= C;
     hipStream_t st = (hipStream_t)stream;
     amp_t *a = (amp_t *)amp;
+    const Tune tn = tune_now();
 
     CamodcParams P;
     P.M = M;
@@ -474,7 +479,7 @@ extern "C" int qcx_shard_camodc(void *amp, unsigned n_local, unsigned M, unsigne
         P.Cd = C / P.d;
         P.inv = modinv_u32(A / P.d, P.Cd);
         P.ntiles = ctl_tiles;
-        const unsigned grid = grid_for(P.ntiles, 1, g_tune.cam_grid_cap);
+        const unsigned grid = grid_for(P.ntiles, 1, tn.cam_grid_cap);
         hipLaunchKernelGGL((k_camodc<256>), dim3(grid), dim3(256), lds, st, a, P);
         HIP_TRY(hipGetLastError());
         return QCX_NO_ERROR;
@@ -514,7 +519,7 @@ extern "C" int qcx_shard_camodc(void *amp, unsigned n_local, unsigned M, unsigne
     Pt.d = 1; Pt.Cd = C; Pt.inv = 0;
     if (ctl >= 0 && ctl < (int)M) Pt.ctl = -1;               // the table already encodes the control
     Pt.ntiles = (Pt.ctl >= (int)M) ? all_tiles >> 1 : all_tiles;
-    const unsigned grid = grid_for(Pt.ntiles, 1, g_tune.cam_grid_cap);
+    const unsigned grid = grid_for(Pt.ntiles, 1, tn.cam_grid_cap);
     hipLaunchKernelGGL((k_camodc_table<256>), dim3(grid), dim3(256), lds, st, a, Pt, w->tab, w->tab + blk + 1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));                       // rare path: finish before the table can be replaced
@@ -570,14 +575,15 @@ extern "C" int qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_
     if (first_global >= last_excluded) count = 0;
     else if (last_excluded - first_global < count) count = last_excluded - first_global;
     if (count == 0) { *found = 0; *index = 0; *cum_out = cum_in; return QCX_NO_ERROR; }
-    const bool parallel = g_tune.meas_parallel != 0 && count >= ((uint64_t)1 << g_tune.meas_min_log2);
+    const Tune tn = tune_now();
+    const bool parallel = tn.meas_parallel != 0 && count >= ((uint64_t)1 << tn.meas_min_log2);
     if (!parallel) {
         // small shards: the strictly sequential single-wave scan
         hipLaunchKernelGGL(k_measure_scan, dim3(1), dim3(64), 0, st, (const amp_t *)amp, count, cum_in, r, w->mout);
     } else {
         // exact parallel form (qcx_kernels.h, K4b): block binade guesses -> integer block increments -> chain
         // block size: the chain costs ~14 ns per block, the one block that is rescanned sequentially ~28 ns per amplitude
-        unsigned blog = (unsigned)g_tune.meas_block_log;
+        unsigned blog = (unsigned)tn.meas_block_log;
         if (blog == 0) {
             unsigned bits = 0;
             while (bits < 63 && ((uint64_t)1 << bits) < count) bits++;
@@ -951,7 +957,7 @@ extern "C" int qcx_fusion_plan(unsigned n_local, unsigned M, unsigned count, con
     QCX_TRY(descs_to_gates(n_local, M, count, gates, q));
     std::vector<FuseAction> acts;
     std::vector<FuseOp> ops;
-    fuse_plan(&tmp, q, acts, ops);
+    fuse_plan(&tmp, tune_now(), q, acts, ops);
     *n_actions = (unsigned)acts.size();
     *n_records = ops.size();
     if (acts.size() > max_actions || ops.size() > max_records || (!actions && !acts.empty()) || (!records && !ops.empty()))
@@ -1284,6 +1290,34 @@ extern "C" int qcx_norm2(qcx_register *r, double *out)
     if (r->sh) return sh_norm2(r->sh, out);
     FLUSH(r);
     return qcx_shard_norm2(r->amp, r->n, out, r->stream);
+}
+
+// T:28-37 exactly: the reference's check_normalisation adds |amp|^2 one by one in index order.  The exact scan of the
+// measurement (run to the end: r = +inf is never reached) returns that very sum, bit for bit; qcx_norm2 above is the
+// faster tree sum.
+extern "C" int qcx_total_probability(qcx_register *r, double *out)
+{
+    if (!r || !out) return QCX_BAD_ARGUMENTS;
+    int found = 0; uint64_t idx = 0; double cum = 0.0;
+    if (r->sh) {
+        ShardSet *sh = r->sh;
+        QCX_TRY(sh_identity(sh));
+        if (sh->dry) return QCX_UNSUPPORTED;
+        QCX_TRY(sh_sync(sh));
+        for (unsigned s = 0; s < sh->W; s++) {
+            HIP_TRY(hipSetDevice(sh->dev[s]));
+            double c2 = cum;
+            QCX_TRY(qcx_shard_measure_scan(sh->buf[sh->cur][s], sh->n_local, (uint64_t)s << sh->n_local, r->dim, cum, INFINITY,
+                                           &found, &idx, &c2, sh->st[s]));
+            cum = c2;
+        }
+        *out = cum;
+        return QCX_NO_ERROR;
+    }
+    FLUSH(r);
+    QCX_TRY(qcx_shard_measure_scan(r->amp, r->n, 0, r->dim, 0.0, INFINITY, &found, &idx, &cum, r->stream));
+    *out = cum;
+    return QCX_NO_ERROR;
 }
 
 extern "C" int qcx_state_fill_random(qcx_register *r, uint64_t seed)

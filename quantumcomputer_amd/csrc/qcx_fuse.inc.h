@@ -109,7 +109,7 @@ static void build_pass_ops(const qcx_register *r, const std::vector<QGate> &gate
 
 // ROUNDS form: group a pass's records into rounds of at most two distinct H bits (the round's register bits);
 // inside a round consecutive phases that rotate the same registers form runs (FUSE_PRUN)
-static void to_rounds(const std::vector<FuseOp> &legacy, unsigned T, std::vector<FuseOp> &out, std::vector<unsigned char> &blob)
+static void to_rounds(const Tune &tn, const std::vector<FuseOp> &legacy, unsigned T, std::vector<FuseOp> &out, std::vector<unsigned char> &blob)
 {
     std::vector<FuseOp> cur;
     std::vector<unsigned> rb;
@@ -161,7 +161,7 @@ static void to_rounds(const std::vector<FuseOp> &legacy, unsigned T, std::vector
             // fold a run of >= 2 consecutive permutation-type multiplies with the same modulus into one gather
             FuseCamExtra X0; memcpy(&X0, &o.c, sizeof X0);
             size_t lj = li;
-            while (g_tune.fuse_camruns && lj < legacy.size() && legacy[lj].type == FUSE_CAMODC) {
+            while (tn.fuse_camruns && lj < legacy.size() && legacy[lj].type == FUSE_CAMODC) {
                 FuseCamExtra X; memcpy(&X, &legacy[lj].c, sizeof X);
                 if (X.d != 1 || X.C != X0.C || X.C > 256 || (legacy[lj].a & 0xffu) != (o.a & 0xffu)) break;
                 lj++;
@@ -212,16 +212,16 @@ static bool launch_rounds_kernel(int occ, unsigned grid, size_t lds, hipStream_t
     }
 }
 
-static int launch_pass(qcx_register *r, const FusePass &P_in, const FuseOp *d_ops, bool nopipe)
+static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, const FuseOp *d_ops, bool nopipe)
 {
     FusePass P = P_in;
     const unsigned n = r->n;
     const uint64_t ntiles = (uint64_t)1 << (n - P.T);
-    const unsigned grid = grid_for(ntiles, 1, g_tune.fuse_grid_cap);
+    const unsigned grid = grid_for(ntiles, 1, tn.fuse_grid_cap);
     const size_t lut_only = ((size_t)2 << std::min(12u, (unsigned)r->M)) + 16;    // source table of a modular-multiply step
     size_t lut_bytes = lut_only + (size_t)P.cam_ctl_local[1];                      // + tables of folded multiply runs
     P.xm_off = 0;
-    P.dbg = (uint32_t)g_tune.fuse_dbg;
+    P.dbg = (uint32_t)tn.fuse_dbg;
     if (P.xm_cnt) {                                                                // + the records' outside-tile masks (phase runs)
         P.xm_off = (uint32_t)((lut_bytes + 7) & ~(size_t)7);
         lut_bytes = P.xm_off + 8 * ((size_t)P.xm_cnt + 66);          // padded: lanes look up to 64 entries past a run
@@ -229,11 +229,11 @@ static int launch_pass(qcx_register *r, const FusePass &P_in, const FuseOp *d_op
     const size_t lds = ((size_t)16 << P.T) + lut_bytes;
     // 4 amplitudes per thread (all loads of a tile in flight at once, few registers): block = 2^T / 4
 #define QCX_FUSE_LAUNCH(B, TTv) do { \
-        if (g_tune.fuse_pipe && !nopipe && ntiles >= 4096) { \
-            const unsigned pg = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)g_tune.fuse_pipe_grid); \
+        if (tn.fuse_pipe && !nopipe && ntiles >= 4096) { \
+            const unsigned pg = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)tn.fuse_pipe_grid); \
             hipLaunchKernelGGL((k_fused_pipe<B, TTv>), dim3(pg), dim3(B), 2 * ((size_t)16 << P.T) + lut_bytes, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); \
-        } else if (P.cam_ctl_local[0] && g_tune.fuse_ldsdma && g_tune.fuse_rounds_occ >= 6 && launch_rounds_kernel<B, TTv>((int)g_tune.fuse_rounds_occ, grid, lds, r->stream, r->amp, n, P, d_ops, ntiles)) { \
-        } else if (g_tune.fuse_ldsdma) hipLaunchKernelGGL((k_fused<B, TTv, true>), dim3(grid), dim3(B), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); \
+        } else if (P.cam_ctl_local[0] && tn.fuse_ldsdma && tn.fuse_rounds_occ >= 6 && launch_rounds_kernel<B, TTv>((int)tn.fuse_rounds_occ, grid, lds, r->stream, r->amp, n, P, d_ops, ntiles)) { \
+        } else if (tn.fuse_ldsdma) hipLaunchKernelGGL((k_fused<B, TTv, true>), dim3(grid), dim3(B), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); \
         else hipLaunchKernelGGL((k_fused<B, TTv, false>), dim3(grid), dim3(B), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); } while (0)
     switch (P.T) {
     case 12: QCX_FUSE_LAUNCH(1024, 12); break;
@@ -250,10 +250,10 @@ static int launch_pass(qcx_register *r, const FusePass &P_in, const FuseOp *d_op
 // The planner: cut a gate list into actions (fused passes and stand-alone gates) and emit every pass's records.
 // Pure host code (no HIP call): qcx_fusion_plan exposes it so that the CPU-only tests can check the records against
 // the oracle with an emulator of the pass kernels (tests/fuse_emulator.py).
-static void fuse_plan(const qcx_register *r, const std::vector<QGate> &gates, std::vector<FuseAction> &acts, std::vector<FuseOp> &all_ops)
+static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<QGate> &gates, std::vector<FuseAction> &acts, std::vector<FuseOp> &all_ops)
 {
     const unsigned n = r->n;
-    unsigned T = (unsigned)g_tune.fuse_T, c_def = (unsigned)g_tune.fuse_c;
+    unsigned T = (unsigned)tn.fuse_T, c_def = (unsigned)tn.fuse_c;
     if (T > 12) T = 12;
     if (T < 1) T = 1;
     if (T > n) T = n;
@@ -290,10 +290,10 @@ static void fuse_plan(const qcx_register *r, const std::vector<QGate> &gates, st
         // A pass dominated by controlled phases is bound by FP64 issue and latency, not by HBM: it runs better on
         // smaller tiles (256-thread workgroups: smaller barrier domains, more of them resident), at the price of
         // fewer hot bits per pass; and never on the pipelined kernel.
-        const unsigned Tp = (unsigned)g_tune.fuse_T_phase;
-        if (Tp >= 9 && Tp <= 12 && Tp <= n && g_tune.fuse_rounds && n_other == 0 &&
-            n_ph >= (size_t)g_tune.fuse_phase_ratio * std::max<size_t>(n_h, 1)) {
-            c = std::min((unsigned)g_tune.fuse_c_phase, Tp); budget = Tp - c;
+        const unsigned Tp = (unsigned)tn.fuse_T_phase;
+        if (Tp >= 9 && Tp <= 12 && Tp <= n && tn.fuse_rounds && n_other == 0 &&
+            n_ph >= (size_t)tn.fuse_phase_ratio * std::max<size_t>(n_h, 1)) {
+            c = std::min((unsigned)tn.fuse_c_phase, Tp); budget = Tp - c;
             grow(c, budget);
             act.nopipe = 1;
         }
@@ -313,12 +313,12 @@ static void fuse_plan(const qcx_register *r, const std::vector<QGate> &gates, st
         legacy.clear();
         build_pass_ops(r, gates, first, i, c, hbits, legacy);
         act.op_off = all_ops.size();
-        bool rounds = g_tune.fuse_rounds && act.P.T >= 10 && act.P.T <= 12;
+        bool rounds = tn.fuse_rounds && act.P.T >= 10 && act.P.T <= 12;
         if (rounds) {
             // ROUNDS form: phases run as "phase runs", which need the records' outside-tile masks in LDS next to the
             // tiles (8 B per record); when that would cost a resident workgroup the pass uses the plain gate list
             std::vector<unsigned char> blob;
-            to_rounds(legacy, act.P.T, all_ops, blob);
+            to_rounds(tn, legacy, act.P.T, all_ops, blob);
             const size_t nrec = all_ops.size() - act.op_off;
             const size_t lds = 2 * ((size_t)16 << act.P.T) + (size_t)act.P.cam_ctl_local[3] + blob.size() + 64 + 8 * (nrec + 66);
             const size_t limit = (size_t)160 * 1024 / (act.P.T == 12 ? 1 : act.P.T == 11 ? 2 : 4);
@@ -373,7 +373,8 @@ static int fuse_flush(qcx_register *r)
     gates.swap(gq->gates);                       // the queue is empty from here on (re-entrancy safe)
     std::vector<FuseAction> acts;
     std::vector<FuseOp> all_ops;
-    fuse_plan(r, gates, acts, all_ops);
+    const Tune tn = tune_now();
+    fuse_plan(r, tn, gates, acts, all_ops);
 
     if (!all_ops.empty()) {
         if (gq->ev_valid) HIP_TRY(hipEventSynchronize(gq->ev));       // the previous flush may still read the buffers
@@ -396,7 +397,7 @@ static int fuse_flush(qcx_register *r)
     }
     for (const FuseAction &act : acts) {
         if (!act.fused) { QCX_TRY(launch_standalone(r, gates[act.gate])); continue; }
-        QCX_TRY(launch_pass(r, act.P, gq->d_ops + act.op_off, act.nopipe != 0));
+        QCX_TRY(launch_pass(r, tn, act.P, gq->d_ops + act.op_off, act.nopipe != 0));
         gq->passes_launched++;
         gq->gates_fused += act.ngates;
     }
@@ -411,6 +412,6 @@ static int fuse_push(qcx_register *r, const QGate &g)
 {
     if (!r->queue) r->queue = new GateQueue();
     r->queue->gates.push_back(g);
-    if (r->queue->gates.size() >= (size_t)g_tune.fuse_max_queue) return fuse_flush(r);
+    if (r->queue->gates.size() >= (size_t)tune_now().fuse_max_queue) return fuse_flush(r);
     return QCX_NO_ERROR;
 }

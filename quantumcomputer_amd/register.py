@@ -168,6 +168,13 @@ class Register:
         check(lib().qcx_sharded_layout(self._h, perm, self.num_qubits), "qcx_sharded_layout")
         return list(perm)
 
+    def total_probability(self):
+        """Total probability summed in the reference's order (testing_and_debug.c:28-37: index-ascending, one addition
+        per amplitude) -- the exact scan of the measurement run to the end."""
+        out = C.c_double(0.0)
+        check(lib().qcx_total_probability(self._h, C.byref(out)), "qcx_total_probability")
+        return out.value
+
     def set_fusion(self, enable=True):
         """Fused LDS-tile passes (bit-identical results).  True/1: every gate call is queued; False/0 (default): only
         the whole-circuit calls (inverse_QFT, quantum_computation) run as fused passes; -1: strictly one kernel launch
@@ -280,7 +287,7 @@ def display_state(reg, file=None, limit=None):
 def check_normalisation(reg, file=None):
     """testing_and_debug.c:28-37: prints the total probability with 16 decimals and returns it"""
     import sys
-    total = reg.norm2()
+    total = reg.total_probability()
     print("Total Probability: %.16f" % total, file=file or sys.stdout)
     return total
 

@@ -148,3 +148,24 @@ def test_shor_state_n30_measurement_is_fast_and_periodic(qc):
     assert min(abs(w - k / 6.0) for k in range(7)) < 2.0 ** -20
     assert dt < 2.0, f"measurement took {dt:.2f} s"
     print("n=30 measure seconds:", dt, "slow/blocks:", last_stats(qc))
+
+
+@pytest.mark.parametrize("n", [3, 9, 13, 18, 22])
+def test_total_probability_is_the_references_sequential_sum(qc, ob, n):
+    """check_normalisation (testing_and_debug.c:28-37) adds |amp|^2 in index order; qcx_total_probability returns that
+    sum bit for bit (the exact measurement scan run to the end), on a plain and on a sharded register"""
+    with qc.Register(n, 0) as reg:
+        reg.fill_random(n)
+        for q in (0, n - 1):
+            qc.hadamard_gate(q, reg)
+        want = ob.fill_random(n, n)
+        for q in (0, n - 1):
+            ob.hadamard(want, n, q)
+        assert reg.total_probability() == ob.norm2(want, n)
+        assert abs(reg.norm2() - ob.norm2(want, n)) < 1e-13
+    if n >= 13:
+        with qc.Register(n, 0, shards=4, devices=[0]) as reg:
+            reg.fill_random(n)
+            for q in (0, n - 1):
+                qc.hadamard_gate(q, reg)
+            assert reg.total_probability() == ob.norm2(want, n)

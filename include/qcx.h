@@ -203,7 +203,7 @@ typedef struct {
     unsigned first_gate, ngates;    /* the gates of the list this action covers (in order, no gaps between actions) */
     unsigned T, c, nh;              /* tile = 2^T amplitudes: the c lowest index bits + nh higher bits hbit[0..nh) */
     unsigned char hbit[16];
-    unsigned nopipe;                /* 1: one tile per workgroup (phase-dominated pass), 0: pipelined kernel */
+    unsigned nopipe;                /* 1: phase-dominated pass, planned on the smaller tile (fuse_T_phase) */
     unsigned rounds_form;           /* 1: records in ROUNDS form (rounds / items / runs), 0: plain gate list */
     size_t   rec_off, rec_cnt;      /* this pass's records (tables included) inside `records` */
     unsigned nops;                  /* records the kernel walks (the rest, if any, are tables) */

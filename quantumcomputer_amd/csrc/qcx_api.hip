@@ -98,8 +98,6 @@ struct Tune {
     long fuse_T      = 11;     // fused passes: tile = 2^T amplitudes in LDS (8..12)
     long fuse_c      = 4;      // fused passes: contiguous low bits of a tile (runs of 16 * 2^c bytes)
     long fuse_grid_cap = 24576; // workgroups of the one-tile-per-workgroup form (each walks several tiles: the table fill at kernel start is amortised)
-    long fuse_pipe   = 0;      // 1: persistent double-buffered form (fill of tile i+1 under tile i) instead of several resident one-tile workgroups
-    long fuse_pipe_grid = 1024; // workgroups of the persistent form
     long fuse_rounds_occ = 8;  // rounds-form passes: k_fused_rounds built for this many waves per SIMD (6, 7, 8; 0 = the general kernel)
     long fuse_T_phase = 10;    // tile bits of phase-dominated passes (one tile per workgroup, not pipelined); 0 = same as the rest
     long fuse_c_phase = 4;
@@ -121,7 +119,7 @@ static Tune tune_now() { std::lock_guard<std::mutex> lock(g_tune_mutex); return 
 extern "C" int qcx_tune_set(const char *key, long value)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); g_tune.name = value; return QCX_NO_ERROR; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_camruns) K(fuse_pipe) K(fuse_pipe_grid) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ)
 #undef K
     return QCX_BAD_ARGUMENTS;
 }
@@ -129,7 +127,7 @@ extern "C" int qcx_tune_set(const char *key, long value)
 extern "C" long qcx_tune_get(const char *key)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); return g_tune.name; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_camruns) K(fuse_pipe) K(fuse_pipe_grid) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ)
 #undef K
     return -1;
 }

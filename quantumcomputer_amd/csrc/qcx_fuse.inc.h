@@ -52,7 +52,7 @@ struct FuseAction {
     size_t   gate;
     FusePass P;
     size_t   op_off, op_cnt, ngates, first_gate;
-    int      nopipe;         // phase-heavy pass: the one-tile-per-workgroup kernel (more resident waves) instead of the pipelined one
+    int      nopipe;         // phase-dominated pass (planned on the smaller tile of fuse_T_phase); reported by qcx_fusion_plan
 };
 
 static int launch_standalone(qcx_register *r, const QGate &g)
@@ -214,6 +214,7 @@ static bool launch_rounds_kernel(int occ, unsigned grid, size_t lds, hipStream_t
 
 static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, const FuseOp *d_ops, bool nopipe)
 {
+    (void)nopipe;
     FusePass P = P_in;
     const unsigned n = r->n;
     const uint64_t ntiles = (uint64_t)1 << (n - P.T);
@@ -229,10 +230,7 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
     const size_t lds = ((size_t)16 << P.T) + lut_bytes;
     // 4 amplitudes per thread (all loads of a tile in flight at once, few registers): block = 2^T / 4
 #define QCX_FUSE_LAUNCH(B, TTv) do { \
-        if (tn.fuse_pipe && !nopipe && ntiles >= 4096) { \
-            const unsigned pg = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)tn.fuse_pipe_grid); \
-            hipLaunchKernelGGL((k_fused_pipe<B, TTv>), dim3(pg), dim3(B), 2 * ((size_t)16 << P.T) + lut_bytes, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); \
-        } else if (P.cam_ctl_local[0] && tn.fuse_ldsdma && tn.fuse_rounds_occ >= 6 && launch_rounds_kernel<B, TTv>((int)tn.fuse_rounds_occ, grid, lds, r->stream, r->amp, n, P, d_ops, ntiles)) { \
+        if (P.cam_ctl_local[0] && tn.fuse_ldsdma && tn.fuse_rounds_occ >= 6 && launch_rounds_kernel<B, TTv>((int)tn.fuse_rounds_occ, grid, lds, r->stream, r->amp, n, P, d_ops, ntiles)) { \
         } else if (tn.fuse_ldsdma) hipLaunchKernelGGL((k_fused<B, TTv, true>), dim3(grid), dim3(B), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); \
         else hipLaunchKernelGGL((k_fused<B, TTv, false>), dim3(grid), dim3(B), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); } while (0)
     switch (P.T) {

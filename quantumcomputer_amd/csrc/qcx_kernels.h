@@ -1171,7 +1171,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void
 // thread: BLOCK = 2^TT / 4).  One tile per workgroup at a time, LDS-DMA fill, a grid of a few workgroups per CU
 // slot that walk the tiles (the table fill below is paid once per workgroup, not once per tile).  Load / process /
 // store phases of the resident workgroups overlap each other; measured, that beats the double-buffered pipeline
-// inside one workgroup (k_fused_pipe) as soon as enough workgroups are resident, so this kernel carries nothing but
+// inside one workgroup (the round-1 pipelined form, removed) as soon as enough workgroups are resident, so this kernel carries nothing but
 // the rounds interpreter and is held to OCC waves per SIMD.
 template <int BLOCK, int TT, int OCC, bool CAM>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) void k_fused_rounds(
@@ -1224,90 +1224,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
     }
 }
 
-// Pipelined form of the fused pass: a persistent workgroup walks its tiles with two LDS buffers; the
-// LDS-DMA fill of tile i+1 is in flight while tile i is being processed and stored.  vmcnt counts
-// stores as well, so the wait before using a buffer is "all but the EPT youngest" (the stores of the
-// previous tile, issued after the fill).
-template <int BLOCK, int TT>
-__global__ __launch_bounds__(BLOCK, 4) void k_fused_pipe(amp_t *__restrict__ amp, unsigned n, FusePass P,
-                                                        const FuseOp *__restrict__ ops, uint64_t ntiles, const FuseOp *ops_asm)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char qcx_lds_raw[];
-    amp_t *buf0 = reinterpret_cast<amp_t *>(qcx_lds_raw);
-    constexpr unsigned tsize = 1u << TT;
-    constexpr unsigned EPT = tsize / BLOCK;
-    static_assert(EPT >= 1 && EPT <= 8, "tile / block geometry");
-    unsigned short *lut = reinterpret_cast<unsigned short *>(buf0 + 2 * tsize);   // behind both tile buffers
-    unsigned char *camtab = reinterpret_cast<unsigned char *>(lut) + P.cam_ctl_local[3];   // tables of folded multiply runs
-    for (unsigned b = threadIdx.x; b < (unsigned)P.cam_ctl_local[1]; b += BLOCK)
-        camtab[b] = reinterpret_cast<const unsigned char *>(ops + P.cam_ctl_local[2])[b];
-    uint64_t *xm = P.xm_cnt ? reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(lut) + P.xm_off) : nullptr;
-    for (unsigned b = threadIdx.x; b < P.xm_cnt + 66u && P.xm_cnt; b += BLOCK) xm[b] = b < P.xm_cnt ? ops[b].mask : 0;    // + padding
-    __syncthreads();
-    const unsigned c = P.c, nh = P.nh;
-    const unsigned lowmask = (1u << c) - 1u;
-    auto scatter = [&](unsigned e) -> uint64_t {
-        uint64_t off = e & lowmask;
-        for (unsigned j = 0; j < nh; j++) off |= (uint64_t)((e >> (c + j)) & 1u) << P.hbit[j];
-        return off;
-    };
-    auto tile_base = [&](uint64_t t) -> uint64_t {
-        uint64_t base = t << c;
-        for (unsigned j = 0; j < nh; j++) base = insert_zero(base, P.hbit[j]);
-        return base;
-    };
-    const uint64_t off_t = scatter(threadIdx.x);
-    uint64_t off_k[EPT];
-#pragma unroll
-    for (unsigned k = 0; k < EPT; k++) off_k[k] = scatter(k * BLOCK);
-    const unsigned wbase = (threadIdx.x >> 6) * 64;
-
-    auto fill = [&](amp_t *dst, uint64_t base) {
-        const amp_t *g = amp + (base | off_t);
-#pragma unroll
-        for (unsigned k = 0; k < EPT; k++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + off_k[k]),
-                                             (__attribute__((address_space(3))) void *)(dst + k * BLOCK + wbase), 16, 0, 2);
-    };
-
-    uint64_t t = blockIdx.x;
-    if (t >= ntiles) return;
-    unsigned cur = 0;
-    fill(buf0, tile_base(t));
-    bool stores_pending = false;
-    for (; t < ntiles; t += gridDim.x) {
-        amp_t *tile = buf0 + cur * tsize;
-        const uint64_t base = tile_base(t);
-        // the fill of this tile is older than the stores of the previous one
-        if (stores_pending) { if constexpr (EPT == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-                              else if constexpr (EPT == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                              else if constexpr (EPT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                              else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                       // fill visible to all waves; all waves done reading the other buffer
-        const uint64_t tn = t + gridDim.x;
-        if (tn < ntiles) fill(buf0 + (cur ^ 1) * tsize, tile_base(tn));
-
-        if constexpr ((1u << TT) == 4u * BLOCK) {
-            if (P.cam_ctl_local[0]) fuse_apply_rounds<BLOCK, TT>(tile, lut, camtab, xm, P, ops, ops_asm, base);
-            else fuse_apply_ops<BLOCK, TT, EPT>(tile, lut, P, ops, base, off_t, off_k, tsize, EPT);
-        } else {
-            fuse_apply_ops<BLOCK, TT, EPT>(tile, lut, P, ops, base, off_t, off_k, tsize, EPT);
-        }
-
-        amp_t *g = amp + (base | off_t);
-        amp_t v[EPT];
-#pragma unroll
-        for (unsigned k = 0; k < EPT; k++) v[k] = tile[k * BLOCK + threadIdx.x];
-        if (tn < ntiles) {
-            // keep the fill of the next tile OLDER than these stores in the vmcnt order: it already is
-        }
-#pragma unroll
-        for (unsigned k = 0; k < EPT; k++) __builtin_nontemporal_store(v[k], g + off_k[k]);
-        stores_pending = true;
-        cur ^= 1;
-    }
-}
+// (A persistent, double-buffered form of the pass -- the LDS-DMA fill of tile i+1 in flight while tile i is processed and
+// stored, the wait before use a COUNTED s_waitcnt vmcnt(stores issued after the fill) -- existed in round 1 and is gone:
+// measured slower than this kernel, and the counted wait is not safe on gfx950.  A wave's loads and stores do not
+// complete in one common order, so "all but the N youngest" may leave some of the older LOADS outstanding while the
+// younger stores have already been acknowledged; round 2 saw exactly that as wrong amplitudes at n = 28 in a
+// register-prefetch variant of an all-Hadamard pass, and the compiler itself always waits vmcnt(0) when loads and
+// stores of one wave are pending together.  A wave that has stores in flight can only wait for ALL of its
+// vector-memory operations; DESIGN.md s4 has the numbers of that experiment.)
 
 // ---------------------------------------------------------------------------
 // X1  local index-bit permutation (pack pass of the sharded qubit remap): dst[j] = src[j with the bit

@@ -14,8 +14,8 @@ def bits(a):
 
 @pytest.fixture()
 def tune_guard(qc):
-    keys = ("fuse_T", "fuse_c", "fuse_grid_cap", "fuse_max_queue", "fuse_rounds", "fuse_pipe", "fuse_ldsdma", "fuse_camruns",
-            "fuse_T_phase", "fuse_c_phase", "fuse_phase_ratio", "fuse_pipe_grid", "fuse_rounds_occ")
+    keys = ("fuse_T", "fuse_c", "fuse_grid_cap", "fuse_max_queue", "fuse_rounds", "fuse_ldsdma", "fuse_camruns",
+            "fuse_T_phase", "fuse_c_phase", "fuse_phase_ratio", "fuse_rounds_occ")
     old = {k: qc.lib().qcx_tune_get(k.encode()) for k in keys}
     yield
     qc.tune(**old)
@@ -64,13 +64,12 @@ def test_random_programs_fused_bit_exact(qc, ob, L, M, Cn):
         assert stats[0] > 0 and stats[1] >= stats[0]
 
 
-@pytest.mark.parametrize("rounds,pipe,dma,tphase", [(1, 1, 1, 10), (1, 1, 1, 0), (0, 1, 1, 10), (1, 0, 1, 10), (0, 0, 0, 0), (1, 0, 0, 0),
-                                                     (1, 1, 1, 11), (1, 1, 1, 12)])
-def test_kernel_forms(qc, ob, tune_guard, rounds, pipe, dma, tphase):
-    """rounds / per-gate op form, persistent double-buffered / plain kernel, LDS-DMA / register fill, and the tile
-    size of phase-dominated passes (0: same kernel as the rest; ratio 1 so that the random programs reach it)"""
-    qc.tune(fuse_rounds=rounds, fuse_pipe=pipe, fuse_ldsdma=dma, fuse_T_phase=tphase, fuse_phase_ratio=1)
-    rs = np.random.RandomState(rounds * 8 + pipe * 4 + dma * 2 + tphase)
+@pytest.mark.parametrize("rounds,dma,tphase", [(1, 1, 10), (1, 1, 0), (0, 1, 10), (0, 0, 0), (1, 0, 0), (1, 1, 11), (1, 1, 12)])
+def test_kernel_forms(qc, ob, tune_guard, rounds, dma, tphase):
+    """rounds / per-gate op form, LDS-DMA / register fill, and the tile size of phase-dominated passes (0: same kernel
+    as the rest; ratio 1 so that the random programs reach it)"""
+    qc.tune(fuse_rounds=rounds, fuse_ldsdma=dma, fuse_T_phase=tphase, fuse_phase_ratio=1)
+    rs = np.random.RandomState(rounds * 8 + dma * 2 + tphase)
     for (L, M, Cn) in ((13, 5, 21), (16, 4, 15), (20, 0, 1)):
         prog = random_program(rs, L + M, M, Cn, 90)
         got, want, _ = run_both(qc, ob, L, M, Cn, prog, 11)

@@ -12,7 +12,7 @@ import sys
 from collections import defaultdict
 
 NAMES = ("k_h_pair", "k_h_wave", "k_phase", "k_camodc_table", "k_camodc_oop", "k_camodc", "k_measure", "k_meas_", "k_norm",
-         "k_fill_random", "k_set_one", "k_fused_rounds", "k_fused_pipe", "k_fused", "k_swap_bits", "k_pack")
+         "k_fill_random", "k_set_one", "k_fused_rounds", "k_fused", "k_swap_bits", "k_pack")
 
 
 def short(name):

@@ -25,7 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="gpurun_out/tune_fuse.json")
     ap.add_argument("--geoms", default="12:4,12:5,12:6,11:4,11:5,11:3,12:3,10:4")
-    ap.add_argument("--tune", default="", help="extra tunables, e.g. fuse_pipe=0,fuse_pipe_grid=768")
+    ap.add_argument("--tune", default="", help="extra tunables, e.g. fuse_rounds_occ=7,fuse_grid_cap=16384")
     a = ap.parse_args()
     geoms = [tuple(int(x) for x in g.split(":")) for g in a.geoms.split(",")]
     if a.tune:

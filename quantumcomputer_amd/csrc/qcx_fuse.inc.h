@@ -37,6 +37,14 @@ static void queue_free(GateQueue *gq)
     delete gq;
 }
 
+// bytes of the scratch area behind a pass's tile: the source table of a single modular multiply (2 bytes per residue of
+// the M register) or, for a folded run of them, one byte per 2^M-block of the largest tile (the run's per-block factor)
+static size_t cam_lut_bytes(unsigned M)
+{
+    const unsigned m = std::min(12u, M);
+    return std::max((size_t)2 << m, (size_t)1 << (12u - m)) + 16;
+}
+
 static bool camodc_closed_form(unsigned n, unsigned M, unsigned C, unsigned A, unsigned ctl)
 {
     (void)A;
@@ -219,7 +227,7 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
     const unsigned n = r->n;
     const uint64_t ntiles = (uint64_t)1 << (n - P.T);
     const unsigned grid = grid_for(ntiles, 1, tn.fuse_grid_cap);
-    const size_t lut_only = ((size_t)2 << std::min(12u, (unsigned)r->M)) + 16;    // source table of a modular-multiply step
+    const size_t lut_only = cam_lut_bytes((unsigned)r->M);                         // scratch of the modular-multiply steps
     size_t lut_bytes = lut_only + (size_t)P.cam_ctl_local[1];                      // + tables of folded multiply runs
     P.xm_off = 0;
     P.dbg = (uint32_t)tn.fuse_dbg;
@@ -306,7 +314,7 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         act.ngates = i - first; act.first_gate = first;
         act.P.has_cam = n_other ? 1u : 0u;
         act.P.c = c; act.P.nh = (uint32_t)hbits.size(); act.P.T = c + act.P.nh;
-        act.P.cam_ctl_local[3] = (int32_t)(((size_t)2 << std::min(12u, (unsigned)r->M)) + 16);   // table area sits behind the lut
+        act.P.cam_ctl_local[3] = (int32_t)cam_lut_bytes((unsigned)r->M);           // table area sits behind the lut
         for (unsigned j = 0; j < act.P.nh; j++) act.P.hbit[j] = (uint8_t)hbits[j];
         legacy.clear();
         build_pass_ops(r, gates, first, i, c, hbits, legacy);

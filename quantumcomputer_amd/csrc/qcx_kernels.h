@@ -1053,27 +1053,37 @@ __device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, unsigned short *l
             const FuseOp *rec = ops + i + 1;
             const unsigned M = rec[0].a & 0xffu, blkmask = (1u << M) - 1u;
             const unsigned Cn = reinterpret_cast<const FuseCamExtra *>(&rec[0].c)->C;
-            unsigned x0 = 1, x1 = 1, x2 = 1, x3 = 1;
-            for (unsigned g = 0; g < cnt; g++) {
-                const uint64_t mext = rec[g].mask;
-                if ((base & mext) != mext) continue;                      // outside control is 0 for this tile
-                const int cl = (int)((rec[g].a >> 8) & 0xffu) - 1;
-                const unsigned char *tb = tabs + g * cpad;
-                const unsigned e0 = threadIdx.x, e1 = BLOCK + threadIdx.x, e2 = 2 * BLOCK + threadIdx.x, e3 = 3 * BLOCK + threadIdx.x;
-                if (cl < 0 || ((e0 >> cl) & 1u)) x0 = tb[x0];
-                if (cl < 0 || ((e1 >> cl) & 1u)) x1 = tb[x1];
-                if (cl < 0 || ((e2 >> cl) & 1u)) x2 = tb[x2];
-                if (cl < 0 || ((e3 >> cl) & 1u)) x3 = tb[x3];
+            // The factor depends on the index only through the control bits, i.e. through the 2^M-BLOCK an amplitude
+            // sits in (controls are L-register qubits, at or above M): it is walked once per block by the first
+            // 2^(T-M) threads and left in LDS (the scratch behind the tile), not once per amplitude by everybody.
+            unsigned char *xblk = reinterpret_cast<unsigned char *>(lut);
+            for (unsigned b = threadIdx.x; b < ((1u << TT) >> M); b += BLOCK) {
+                const unsigned e = b << M;
+                unsigned x = 1;
+                for (unsigned g = 0; g < cnt; g++) {
+                    const uint64_t mext = rec[g].mask;
+                    if ((base & mext) != mext) continue;                  // outside control is 0 for this tile
+                    const int cl = (int)((rec[g].a >> 8) & 0xffu) - 1;
+                    if (cl < 0 || ((e >> cl) & 1u)) x = tabs[g * cpad + x];
+                }
+                xblk[b] = (unsigned char)x;
             }
-            const unsigned xs[4] = {x0, x1, x2, x3};
+            __syncthreads();
+            const float rc = 1.0f / (float)Cn;
             amp_t acc[4];
             bool wr[4];
 #pragma unroll
             for (unsigned k = 0; k < 4; k++) {
                 const unsigned e = k * BLOCK + threadIdx.x, f = e & blkmask;
-                wr[k] = (xs[k] != 1u) && (f < Cn);
+                const unsigned x = xblk[e >> M];
+                wr[k] = (x != 1u) && (f < Cn);
                 if (wr[k]) {
-                    const amp_t sv = tile[(e - f) + (xs[k] * f) % Cn];
+                    // (x * f) mod C for x, f < C <= 256: quotient estimate from the float reciprocal, off by at most one
+                    const unsigned v = x * f;
+                    unsigned q = (unsigned)((float)v * rc);
+                    int rem = (int)v - (int)(q * Cn);
+                    if (rem < 0) rem += (int)Cn; else if (rem >= (int)Cn) rem -= (int)Cn;
+                    const amp_t sv = tile[(e - f) + (unsigned)rem];
                     acc[k].x = 0.0 + sv.x; acc[k].y = 0.0 + sv.y;
                 }
             }

@@ -15,7 +15,7 @@ def bits(a):
 @pytest.fixture()
 def tune_guard(qc):
     keys = ("fuse_T", "fuse_c", "fuse_grid_cap", "fuse_max_queue", "fuse_rounds", "fuse_ldsdma", "fuse_camruns",
-            "fuse_T_phase", "fuse_c_phase", "fuse_phase_ratio", "fuse_rounds_occ")
+            "fuse_T_phase", "fuse_c_phase", "fuse_phase_ratio", "fuse_rounds_occ", "fuse_hsweep_T", "fuse_hsweep_c")
     old = {k: qc.lib().qcx_tune_get(k.encode()) for k in keys}
     yield
     qc.tune(**old)
@@ -76,7 +76,7 @@ def test_kernel_forms(qc, ob, tune_guard, rounds, dma, tphase):
         assert np.array_equal(bits(got), bits(want)), (L, M)
 
 
-@pytest.mark.parametrize("T,c", [(8, 2), (9, 4), (10, 6), (11, 3), (12, 4), (12, 6), (12, 0), (10, 10)])
+@pytest.mark.parametrize("T,c", [(8, 2), (9, 4), (10, 6), (11, 3), (12, 3), (12, 4), (12, 6), (12, 0), (10, 10)])
 def test_every_tile_geometry(qc, ob, tune_guard, T, c):
     qc.tune(fuse_T=T, fuse_c=c)
     rs = np.random.RandomState(T * 16 + c)
@@ -292,3 +292,26 @@ def test_rounds_kernel_builds(qc, ob, tune_guard, occ):
         prog = random_program(rs, L + M, M, Cn, 80)
         got, want, _ = run_both(qc, ob, L, M, Cn, prog, 17)
         assert np.array_equal(bits(got), bits(want)), (occ, L, M)
+
+
+def test_pure_hadamard_sweep_takes_the_three_pass_geometry_and_keeps_the_bits(qc, tune_guard):
+    """a queue of nothing but Hadamards is planned on 2^12-amplitude tiles with 128-B runs when that saves passes (30
+    qubits: 3 instead of 4); same bits as one launch per gate, at full size"""
+    n = 28
+    with qc.Register(n, 0) as r1, qc.Register(n, 0) as r2:
+        r1.fill_random(6); r2.fill_random(6)
+        r2.set_fusion(True)
+        p0 = r2.fusion_stats()[0]
+        for q in range(n):
+            qc.hadamard_gate(q, r1); qc.hadamard_gate(q, r2)
+        r2.flush()
+        assert r2.fusion_stats()[0] - p0 == 3              # 12 + 9 + 7 gates
+        for s in (0, 4321 << 13, (1 << n) - (1 << 13), 1 << 26):
+            assert np.array_equal(bits(r1.read(s, 1 << 13)), bits(r2.read(s, 1 << 13)))
+        qc.tune(fuse_hsweep_T=0)                             # the switch: back to the default geometry
+        p0 = r2.fusion_stats()[0]
+        for q in range(n):
+            qc.hadamard_gate(q, r1); qc.hadamard_gate(q, r2)
+        r2.flush()
+        assert r2.fusion_stats()[0] - p0 == 4
+        assert np.array_equal(bits(r1.read(0, 1 << 13)), bits(r2.read(0, 1 << 13)))

@@ -96,6 +96,7 @@ _EXTRA = {
     "qcx_sharded_trace": (_i, [_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "qcx_sharded_restore_identity": (_i, [_p]),
     "qcx_sharded_relay_stats": (_i, [_p, C.POINTER(_u), C.POINTER(_ul)]),
+    "qcx_sharded_overlap_stats": (_i, [_p, C.POINTER(_u), C.POINTER(_ul)]),
     "qcx_sharded_layout": (_i, [_p, C.POINTER(_u), _u]),
 }
 

@@ -765,6 +765,14 @@ extern "C" int qcx_sharded_set_relays(qcx_register *r, unsigned nrelays, const i
     return sh_set_relays(r->sh, nrelays, devices);
 }
 
+extern "C" int qcx_sharded_overlap_stats(qcx_register *r, unsigned *slices_log2, unsigned long *gates_in_windows)     // diagnostics
+{
+    if (!r || !r->sh) return QCX_BAD_ARGUMENTS;
+    if (slices_log2) *slices_log2 = r->sh->sigma;
+    if (gates_in_windows) *gates_in_windows = r->sh->overlapped_gates;
+    return QCX_NO_ERROR;
+}
+
 extern "C" int qcx_sharded_relay_stats(qcx_register *r, unsigned *nrelays, unsigned long *relayed_bytes)     // diagnostics
 {
     if (!r || !r->sh) return QCX_BAD_ARGUMENTS;

@@ -42,6 +42,14 @@ struct ShardSet {
     std::vector<unsigned>    perm, inv;          // logical -> physical, physical -> logical
     std::vector<SGate>       queue;
     unsigned min_evict = 0, zone_lo = 0;
+    // exchange/compute overlap: the top sigma local bits are SPECTATORS (never traded); a slice = one
+    // value of them = 2^slice_bits consecutive amplitudes of a shard.  A trade is done slice by slice on a second stream
+    // per shard, with the gates before / after it running on the slices that are not in flight.
+    unsigned sigma = 0, slice_bits = 0;
+    bool     overlap = true;
+    unsigned long overlapped_gates = 0;
+    std::vector<hipStream_t> xs;                 // per shard: the stream the pack+push kernels run on
+    std::vector<hipEvent_t>  ev_pre, ev_push;    // [shard * 8 + slice]: pre-window gates done / slice pushed
     unsigned long exchanges = 0, pack_passes = 0;
     std::vector<hipEvent_t>  ev_a, ev_b;
     // multi-path striping: GPUs that hold no shard relay a share of every chunk (qcx_sharded_set_relays)
@@ -59,7 +67,27 @@ struct ShardSet {
 
 #define SH_DEV(sh, r) do { if (!(sh)->dry) HIP_TRY(hipSetDevice((sh)->dev[r])); } while (0)
 
-static void sh_set_phys(ShardSet *sh, unsigned logical, unsigned pos) { sh->perm[logical] = pos; sh->inv[pos] = logical; }
+// spectator bits: QCX_SHARD_SLICES_LOG2 (default 3 -> 8 slices)
+static unsigned sh_default_sigma()
+{
+    unsigned sigma = 3;
+    if (const char *e = getenv("QCX_SHARD_SLICES_LOG2")) sigma = (unsigned)std::min(3, std::max(0, atoi(e)));
+    return sigma;
+}
+
+// fix the slice geometry (fewer spectator bits than asked when the register is too small for them).  The trade zone
+// moves with it, so this is only legal in the identity layout with nothing queued.
+static void sh_set_slices(ShardSet *sh, unsigned sigma)
+{
+    const unsigned k = sh->k;
+    for (;; sigma--) {
+        sh->min_evict = std::max<unsigned>((sh->n_local >= sigma + 2 * k + 6) ? 6u : 0u, sh->M);   // never trade away the M register or runs < 1 KiB
+        if (sigma == 0 || sh->n_local >= sigma + sh->min_evict + 2 * k) break;
+    }
+    sh->sigma = sigma;
+    sh->slice_bits = sh->n_local - sigma;
+    sh->zone_lo = sh->slice_bits - k;               // the trade zone: the top k bits of a slice
+}
 
 static void sh_identity_perm(ShardSet *sh)
 {
@@ -89,6 +117,11 @@ static void sh_free(ShardSet *sh)
             for (int b = 0; b < 2; b++) if (r < sh->buf[b].size() && sh->buf[b][r]) (void)hipFree(sh->buf[b][r]);
             if (r < sh->ev_a.size() && sh->ev_a[r]) (void)hipEventDestroy(sh->ev_a[r]);
             if (r < sh->ev_b.size() && sh->ev_b[r]) (void)hipEventDestroy(sh->ev_b[r]);
+            for (unsigned e = 8 * r; e < 8 * r + 8; e++) {
+                if (e < sh->ev_pre.size() && sh->ev_pre[e]) (void)hipEventDestroy(sh->ev_pre[e]);
+                if (e < sh->ev_push.size() && sh->ev_push[e]) (void)hipEventDestroy(sh->ev_push[e]);
+            }
+            if (r < sh->xs.size() && sh->xs[r]) { (void)hipStreamSynchronize(sh->xs[r]); (void)hipStreamDestroy(sh->xs[r]); }
             if (r < sh->st.size() && sh->st[r]) (void)hipStreamDestroy(sh->st[r]);
         }
     }
@@ -106,17 +139,20 @@ static int sh_create(int L, int M, unsigned nshards, const int *devices, ShardSe
     if (sh->n <= sh->k) { delete sh; return QCX_BAD_ARGUMENTS; }
     sh->n_local = sh->n - sh->k;
     const unsigned k = sh->k;
-    sh->min_evict = std::max<unsigned>((sh->n_local >= 2 * k + 6) ? 6u : 0u, sh->M);     // never trade away the M register or runs < 1 KiB
+    sh_set_slices(sh, sh_default_sigma());
     if (sh->n_local < sh->min_evict + 2 * k) {
         set_error("register too small for %u shards (need n_local - max(M, 6) >= 2 log2(shards))", nshards);
         delete sh; return QCX_BAD_ARGUMENTS;
     }
     if ((unsigned)M > 12) { set_error("sharded register: M <= 12"); delete sh; return QCX_UNSUPPORTED; }
-    sh->zone_lo = sh->n_local - k;
     sh->perm.resize(sh->n); sh->inv.resize(sh->n);
     sh_identity_perm(sh);
     sh->dry = devices && devices[0] < 0;
-    if (sh->dry) { *out = sh; return QCX_NO_ERROR; }
+    if (sh->dry) {
+        if (const char *e = getenv("QCX_SHARD_OVERLAP")) sh->overlap = atoi(e) != 0;
+        if (!sh->overlap) sh_set_slices(sh, 0);
+        *out = sh; return QCX_NO_ERROR;
+    }
     int ndev = 0;
     { const int s = qcx_device_count(&ndev); if (s != QCX_NO_ERROR) { delete sh; return s; } }
     sh->dev.resize(nshards);
@@ -127,7 +163,15 @@ static int sh_create(int L, int M, unsigned nshards, const int *devices, ShardSe
             delete sh; return QCX_HIP_ERROR;
         }
     }
+    // exchange windows pay when a trade crosses xGMI (tens of ms at n_local = 30); with every shard on ONE device a trade
+    // is a local pass as fast as a gate and the windows only fragment the gate lists (measured at n = 30, 8 shards on one
+    // GPU: fused sweep 31.8 -> 39.6 ms, Shor circuit 86 -> 97 ms).  QCX_SHARD_OVERLAP=0|1 overrides.
+    sh->overlap = false;
+    for (unsigned r = 1; r < nshards; r++) sh->overlap |= sh->dev[r] != sh->dev[0];
+    if (const char *e = getenv("QCX_SHARD_OVERLAP")) sh->overlap = atoi(e) != 0;
+    if (!sh->overlap) sh_set_slices(sh, 0);            // slices only serve the windows
     sh->st.assign(nshards, nullptr); sh->ev_a.assign(nshards, nullptr); sh->ev_b.assign(nshards, nullptr);
+    sh->xs.assign(nshards, nullptr); sh->ev_pre.assign(8 * nshards, nullptr); sh->ev_push.assign(8 * nshards, nullptr);
     sh->buf[0].assign(nshards, nullptr); sh->buf[1].assign(nshards, nullptr);
     int prev = 0;
     (void)hipGetDevice(&prev);
@@ -148,6 +192,11 @@ static int sh_create(int L, int M, unsigned nshards, const int *devices, ShardSe
         if (e == hipSuccess) e = hipStreamCreate(&sh->st[r]);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sh->ev_a[r], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sh->ev_b[r], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipStreamCreate(&sh->xs[r]);
+        for (unsigned q = 8 * r; q < 8 * r + 8 && e == hipSuccess; q++) {
+            e = hipEventCreateWithFlags(&sh->ev_pre[q], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&sh->ev_push[q], hipEventDisableTiming);
+        }
         for (int b = 0; b < 2 && e == hipSuccess; b++) {
             e = hipMalloc(&sh->buf[b][r], bytes);
             if (e == hipSuccess) e = hipMemsetAsync(sh->buf[b][r], 0, bytes, sh->st[r]);
@@ -164,60 +213,86 @@ static int sh_create(int L, int M, unsigned nshards, const int *devices, ShardSe
 }
 
 // ---- one gate list on every shard ------------------------------------------------------------------------------------
-// resolve a queued gate for shard r under the CURRENT layout: false = the gate is the identity on this shard
-static bool sh_resolve(const ShardSet *sh, const SGate &g, unsigned r, qcx_gate_desc *d)
+// A queued gate under a given layout, in PHYSICAL index bits (the layout may change before the gate runs: the gates
+// of an exchange's pre-window are resolved before the trade is booked).
+struct POp { uint32_t type; unsigned p1, p2; double c, s; unsigned C, A; };
+
+static POp sh_phys(const ShardSet *sh, const SGate &g)
 {
-    const unsigned nl = sh->n_local;
+    POp o; memset(&o, 0, sizeof o);
+    o.type = g.type; o.p1 = sh->perm[g.q]; o.p2 = (g.type == FUSE_PHASE) ? sh->perm[g.q2] : 0;
+    o.c = g.c; o.s = g.s; o.C = g.C; o.A = g.A;
+    return o;
+}
+
+// the operation on a VIEW of 2^nbits consecutive amplitudes of shard r (the whole shard, or slice sidx of it): index
+// bits at or above nbits are constants of the view -- spectator bits come from the slice number, the rest from the
+// shard id.  false = the gate is the identity on this view
+static bool sh_desc(const ShardSet *sh, const POp &o, unsigned r, unsigned nbits, unsigned sidx, qcx_gate_desc *d)
+{
+    auto outside = [&](unsigned pq) -> unsigned {
+        return pq >= sh->n_local ? (r >> (pq - sh->n_local)) & 1u : (sidx >> (pq - nbits)) & 1u;
+    };
     memset(d, 0, sizeof *d);
-    if (g.type == FUSE_H) { d->type = 0; d->q = sh->perm[g.q]; return true; }
-    if (g.type == FUSE_PHASE) {
-        d->type = 1; d->c = g.c; d->s = g.s;
-        for (unsigned lq : {g.q, g.q2}) {
-            const unsigned pq = sh->perm[lq];
-            if (pq >= nl) { if (!((r >> (pq - nl)) & 1u)) return false; }
+    if (o.type == FUSE_H) { d->type = 0; d->q = o.p1; return true; }              // (the scheduler keeps p1 < nbits)
+    if (o.type == FUSE_PHASE) {
+        d->type = 1; d->c = o.c; d->s = o.s;
+        for (unsigned pq : {o.p1, o.p2}) {
+            if (pq >= nbits) { if (!outside(pq)) return false; }
             else d->mask |= (uint64_t)1 << pq;
         }
         return true;
     }
-    d->type = 2; d->C = g.C; d->A = g.A;
-    const unsigned pc = sh->perm[g.q];
-    if (pc >= nl) { if (!((r >> (pc - nl)) & 1u)) return false; d->q = 0xffffffffu; }
-    else d->q = pc;
+    d->type = 2; d->C = o.C; d->A = o.A;
+    if (o.p1 >= nbits) { if (!outside(o.p1)) return false; d->q = 0xffffffffu; }
+    else d->q = o.p1;
     return true;
 }
 
-static void sh_trace_ops(ShardSet *sh, const SGate *g, size_t cnt)
+static void sh_trace_ops(ShardSet *sh, const std::vector<POp> &ops)
 {
     char line[160];
-    snprintf(line, sizeof line, "ops %zu\n", cnt); sh->trace += line;
-    for (size_t i = 0; i < cnt; i++) {
-        if (g[i].type == FUSE_H) snprintf(line, sizeof line, "h %u\n", sh->perm[g[i].q]);
-        else if (g[i].type == FUSE_PHASE) snprintf(line, sizeof line, "p %u %u %a %a\n", sh->perm[g[i].q], sh->perm[g[i].q2], g[i].c, g[i].s);
-        else snprintf(line, sizeof line, "c %u %u %u\n", g[i].C, g[i].A, sh->perm[g[i].q]);
+    snprintf(line, sizeof line, "ops %zu\n", ops.size()); sh->trace += line;
+    for (const POp &o : ops) {
+        if (o.type == FUSE_H) snprintf(line, sizeof line, "h %u\n", o.p1);
+        else if (o.type == FUSE_PHASE) snprintf(line, sizeof line, "p %u %u %a %a\n", o.p1, o.p2, o.c, o.s);
+        else snprintf(line, sizeof line, "c %u %u %u\n", o.C, o.A, o.p1);
         sh->trace += line;
     }
 }
 
+// the operations on one view of shard r, on that shard's compute stream
+static int sh_run_view(ShardSet *sh, const std::vector<POp> &ops, unsigned r, amp_t *a, unsigned nbits, unsigned sidx)
+{
+    std::vector<qcx_gate_desc> descs;
+    for (const POp &o : ops) { qcx_gate_desc d; if (sh_desc(sh, o, r, nbits, sidx, &d)) descs.push_back(d); }
+    if (descs.empty()) return QCX_NO_ERROR;
+    if (sh->fusion > 0 && descs.size() > 1)
+        return qcx_shard_run_fused(a, nbits, sh->M, (unsigned)descs.size(), descs.data(), sh->st[r]);
+    for (const qcx_gate_desc &d : descs) {
+        if (d.type == 0) QCX_TRY(qcx_shard_hadamard(a, nbits, d.q, sh->st[r]));
+        else if (d.type == 1) QCX_TRY(qcx_shard_phase(a, nbits, d.mask, d.c, d.s, sh->st[r]));
+        else QCX_TRY(qcx_shard_camodc(a, nbits, sh->M, d.C, d.A, d.q == 0xffffffffu ? -1 : (int)d.q, sh->st[r]));
+    }
+    return QCX_NO_ERROR;
+}
+
+static std::vector<POp> sh_phys_list(const ShardSet *sh, const SGate *g, size_t cnt)
+{
+    std::vector<POp> ops;
+    for (size_t i = 0; i < cnt; i++) ops.push_back(sh_phys(sh, g[i]));
+    return ops;
+}
+
+// a gate list on every whole shard
 static int sh_run_ops(ShardSet *sh, const SGate *g, size_t cnt)
 {
     if (!cnt) return QCX_NO_ERROR;
-    if (sh->dry) { sh_trace_ops(sh, g, cnt); return QCX_NO_ERROR; }
-    std::vector<qcx_gate_desc> descs;
+    const std::vector<POp> ops = sh_phys_list(sh, g, cnt);
+    if (sh->dry) { sh_trace_ops(sh, ops); return QCX_NO_ERROR; }
     for (unsigned r = 0; r < sh->W; r++) {
         SH_DEV(sh, r);
-        descs.clear();
-        for (size_t i = 0; i < cnt; i++) { qcx_gate_desc d; if (sh_resolve(sh, g[i], r, &d)) descs.push_back(d); }
-        if (descs.empty()) continue;
-        amp_t *a = sh->buf[sh->cur][r];
-        if (sh->fusion > 0 && descs.size() > 1) {
-            QCX_TRY(qcx_shard_run_fused(a, sh->n_local, sh->M, (unsigned)descs.size(), descs.data(), sh->st[r]));
-            continue;
-        }
-        for (const qcx_gate_desc &d : descs) {
-            if (d.type == 0) QCX_TRY(qcx_shard_hadamard(a, sh->n_local, d.q, sh->st[r]));
-            else if (d.type == 1) QCX_TRY(qcx_shard_phase(a, sh->n_local, d.mask, d.c, d.s, sh->st[r]));
-            else QCX_TRY(qcx_shard_camodc(a, sh->n_local, sh->M, d.C, d.A, d.q == 0xffffffffu ? -1 : (int)d.q, sh->st[r]));
-        }
+        QCX_TRY(sh_run_view(sh, ops, r, sh->buf[sh->cur][r], sh->n_local, 0));
     }
     return QCX_NO_ERROR;
 }
@@ -239,17 +314,24 @@ static SwapList sh_plan_give(const ShardSet *sh, std::vector<unsigned> pos)
     return swaps;
 }
 
-static void sh_book(ShardSet *sh, const SwapList &swaps, bool trade)
+static void sh_book_vec(std::vector<unsigned> &perm, std::vector<unsigned> &inv, const SwapList &swaps, bool trade,
+                        unsigned k, unsigned zone_lo, unsigned n_local)
 {
+    auto set_phys = [&](unsigned logical, unsigned pos) { perm[logical] = pos; inv[pos] = logical; };
     for (const auto &ab : swaps) {
-        const unsigned la = sh->inv[ab.first], lb = sh->inv[ab.second];
-        sh_set_phys(sh, la, ab.second); sh_set_phys(sh, lb, ab.first);
+        const unsigned la = inv[ab.first], lb = inv[ab.second];
+        set_phys(la, ab.second); set_phys(lb, ab.first);
     }
     if (trade)
-        for (unsigned j = 0; j < sh->k; j++) {
-            const unsigned lt = sh->inv[sh->zone_lo + j], lr = sh->inv[sh->n_local + j];
-            sh_set_phys(sh, lt, sh->n_local + j); sh_set_phys(sh, lr, sh->zone_lo + j);
+        for (unsigned j = 0; j < k; j++) {
+            const unsigned lt = inv[zone_lo + j], lr = inv[n_local + j];
+            set_phys(lt, n_local + j); set_phys(lr, zone_lo + j);
         }
+}
+
+static void sh_book(ShardSet *sh, const SwapList &swaps, bool trade)
+{
+    sh_book_vec(sh->perm, sh->inv, swaps, trade, sh->k, sh->zone_lo, sh->n_local);
 }
 
 static void sh_swapbits_arg(const SwapList &swaps, size_t lo, size_t hi, SwapBits *S)
@@ -269,74 +351,104 @@ static void sh_trace_swaps(ShardSet *sh, const char *what, const SwapList &swaps
     sh->trace += "\n";
 }
 
-// pack (the transpositions) + trade of all k shard-id bits with the trade zone, as one kernel per shard
-static int sh_exchange(ShardSet *sh, const SwapList &swaps)
+// pack (the transpositions) + trade of all k shard-id bits with the trade zone: one k_pack_push per shard and SLICE, on
+// the shard's exchange stream, with `pre` (resolved under the layout before the trade) run on every slice before it
+// leaves and `post` (resolved under the layout after it) on every slice after it has arrived -- both on the compute
+// stream, so the transfer of one slice hides behind the gates of the others.  Slices are independent: every gate of a
+// window acts inside a slice (the scheduler only admits such gates), the trade maps slice s of every shard onto slice
+// s of every shard.  Relay striping (set_relays) moves whole shards: no slices then.
+static int sh_exchange(ShardSet *sh, const SwapList &swaps, const std::vector<POp> &pre, const std::vector<POp> &post)
 {
-    if (sh->dry) { sh_trace_swaps(sh, "pack", swaps, 0, swaps.size()); sh->trace += "trade\n"; }
-    else {
+    if (sh->dry) {
+        if (!pre.empty()) sh_trace_ops(sh, pre);
+        sh_trace_swaps(sh, "pack", swaps, 0, swaps.size());
+        { char t[32]; snprintf(t, sizeof t, "trade %u\n", sh->zone_lo); sh->trace += t; }      // the trade zone: zone_lo .. zone_lo + k
+        if (!post.empty()) sh_trace_ops(sh, post);
+    } else {
         const unsigned W = sh->W;
+        const unsigned R = (sh->zone_lo >= 8) ? (unsigned)sh->relay_dev.size() : 0u;
+        const unsigned S = 1u << sh->sigma;                 // (relays are only set up with sigma = 0: sh_set_relays)
+        const unsigned vbits = sh->slice_bits;              // bits of one view (a slice, or the whole shard when sigma = 0)
+        const unsigned zlo = sh->zone_lo;                   // its trade zone = its top k bits
         // (1) every shard's earlier work is done before anyone writes into its spare buffer
         for (unsigned r = 0; r < W; r++) { SH_DEV(sh, r); HIP_TRY(hipEventRecord(sh->ev_a[r], sh->st[r])); }
         for (unsigned r = 0; r < W; r++) {
             SH_DEV(sh, r);
-            for (unsigned c = 0; c < W; c++) if (c != r) HIP_TRY(hipStreamWaitEvent(sh->st[r], sh->ev_a[c], 0));
+            for (unsigned c = 0; c < W; c++) HIP_TRY(hipStreamWaitEvent(sh->xs[r], sh->ev_a[c], 0));
         }
-        SwapBits S;
-        sh_swapbits_arg(swaps, 0, swaps.size(), &S);
-        PushDst D;
-        memset(&D, 0, sizeof D);
-        for (unsigned c = 0; c < W; c++) D.dst[c] = sh->buf[sh->cur ^ 1][c];
+        SwapBits Sb;
+        sh_swapbits_arg(swaps, 0, swaps.size(), &Sb);
         PushRelay Rl;
         memset(&Rl, 0, sizeof Rl);
-        const unsigned R = (sh->zone_lo >= 8) ? (unsigned)sh->relay_dev.size() : 0u;
         if (R) {
             Rl.nrelays = R; Rl.nb_direct = sh->nb_direct; Rl.nb_relay = sh->nb_relay; Rl.stage_amps = sh->stage_amps;
             for (unsigned i = 0; i < R; i++) Rl.stage[i] = sh->relay_stage[i];
         }
-        const uint64_t count = (uint64_t)1 << sh->n_local;
-        for (unsigned r = 0; r < W; r++) {
-            SH_DEV(sh, r);
-            if (sh->zone_lo >= 8)
-                hipLaunchKernelGGL((k_pack_push<256, true>), dim3(grid_for(count, 256, 0, 256)), dim3(256), 0, sh->st[r],
-                                   (const amp_t *)sh->buf[sh->cur][r], D, Rl, count, S, sh->zone_lo, sh->k, r);
-            else
-                hipLaunchKernelGGL((k_pack_push<64, false>), dim3(grid_for(count, 64, 0, 64)), dim3(64), 0, sh->st[r],
-                                   (const amp_t *)sh->buf[sh->cur][r], D, Rl, count, S, sh->zone_lo, sh->k, r);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(sh->ev_b[r], sh->st[r]));
-        }
-        // (1b) the relays forward their staged stripes to the owners once every shard has pushed
-        if (R) {
-            const uint64_t per_chunk_blocks = ((uint64_t)1 << sh->zone_lo) / 256;
-            for (unsigned i = 0; i < R; i++) {
-                HIP_TRY(hipSetDevice(sh->relay_dev[i]));
-                for (unsigned r = 0; r < W; r++) HIP_TRY(hipStreamWaitEvent(sh->relay_st[i], sh->ev_b[r], 0));
-                const uint64_t b0 = (uint64_t)sh->nb_direct + (uint64_t)i * sh->nb_relay;
-                const uint64_t b1 = (i + 1 == R) ? per_chunk_blocks : b0 + sh->nb_relay;
-                const size_t bytes = (size_t)(b1 - b0) * 256 * sizeof(amp_t);
-                for (unsigned r = 0; r < W && bytes; r++)
-                    for (unsigned c = 0; c < W; c++) {
-                        if (c == r) continue;
-                        amp_t *to = sh->buf[sh->cur ^ 1][c] + (((uint64_t)r << sh->zone_lo) | (b0 * 256));
-                        const amp_t *from = sh->relay_stage[i] + (uint64_t)(r * W + c) * sh->stage_amps;
-                        HIP_TRY(hipMemcpyAsync(to, from, bytes, hipMemcpyDeviceToDevice, sh->relay_st[i]));
-                        sh->relayed_bytes += bytes;
-                    }
-                HIP_TRY(hipEventRecord(sh->relay_ev[i], sh->relay_st[i]));
+        const uint64_t count = (uint64_t)1 << vbits;
+        auto post_on = [&](unsigned sidx) -> int {          // slice sidx has arrived everywhere: run the post-window on it
+            for (unsigned r = 0; r < W; r++) {
+                SH_DEV(sh, r);
+                for (unsigned c = 0; c < W; c++) HIP_TRY(hipStreamWaitEvent(sh->st[r], sh->ev_push[8 * c + sidx], 0));
+                for (unsigned i = 0; i < R; i++) HIP_TRY(hipStreamWaitEvent(sh->st[r], sh->relay_ev[i], 0));
+                if (!post.empty()) QCX_TRY(sh_run_view(sh, post, r, sh->buf[sh->cur ^ 1][r] + ((uint64_t)sidx << vbits), vbits, sidx));
             }
+            return QCX_NO_ERROR;
+        };
+        for (unsigned sidx = 0; sidx < S; sidx++) {
+            PushDst D;
+            memset(&D, 0, sizeof D);
+            for (unsigned c = 0; c < W; c++) D.dst[c] = sh->buf[sh->cur ^ 1][c] + ((uint64_t)sidx << vbits);
+            for (unsigned r = 0; r < W; r++) {
+                SH_DEV(sh, r);
+                amp_t *src = sh->buf[sh->cur][r] + ((uint64_t)sidx << vbits);
+                if (!pre.empty()) QCX_TRY(sh_run_view(sh, pre, r, src, vbits, sidx));
+                HIP_TRY(hipEventRecord(sh->ev_pre[8 * r + sidx], sh->st[r]));
+                HIP_TRY(hipStreamWaitEvent(sh->xs[r], sh->ev_pre[8 * r + sidx], 0));
+                if (zlo >= 8)
+                    hipLaunchKernelGGL((k_pack_push<256, true>), dim3(grid_for(count, 256, 0, 256)), dim3(256), 0, sh->xs[r],
+                                       (const amp_t *)src, D, Rl, count, Sb, zlo, sh->k, r);
+                else
+                    hipLaunchKernelGGL((k_pack_push<64, false>), dim3(grid_for(count, 64, 0, 64)), dim3(64), 0, sh->xs[r],
+                                       (const amp_t *)src, D, Rl, count, Sb, zlo, sh->k, r);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipEventRecord(sh->ev_push[8 * r + sidx], sh->xs[r]));
+            }
+            // (1b) the relays forward their staged stripes to the owners once every shard has pushed (unsliced only)
+            if (R) {
+                const uint64_t per_chunk_blocks = ((uint64_t)1 << zlo) / 256;
+                for (unsigned i = 0; i < R; i++) {
+                    HIP_TRY(hipSetDevice(sh->relay_dev[i]));
+                    for (unsigned r = 0; r < W; r++) HIP_TRY(hipStreamWaitEvent(sh->relay_st[i], sh->ev_push[8 * r], 0));
+                    const uint64_t b0 = (uint64_t)sh->nb_direct + (uint64_t)i * sh->nb_relay;
+                    const uint64_t b1 = (i + 1 == R) ? per_chunk_blocks : b0 + sh->nb_relay;
+                    const size_t bytes = (size_t)(b1 - b0) * 256 * sizeof(amp_t);
+                    for (unsigned r = 0; r < W && bytes; r++)
+                        for (unsigned c = 0; c < W; c++) {
+                            if (c == r) continue;
+                            amp_t *to = sh->buf[sh->cur ^ 1][c] + (((uint64_t)r << zlo) | (b0 * 256));
+                            const amp_t *from = sh->relay_stage[i] + (uint64_t)(r * W + c) * sh->stage_amps;
+                            HIP_TRY(hipMemcpyAsync(to, from, bytes, hipMemcpyDeviceToDevice, sh->relay_st[i]));
+                            sh->relayed_bytes += bytes;
+                        }
+                    HIP_TRY(hipEventRecord(sh->relay_ev[i], sh->relay_st[i]));
+                }
+            }
+            if (sidx >= 1) QCX_TRY(post_on(sidx - 1));       // ... while slice sidx is in flight
         }
-        // (2) a shard's new buffer is complete when every shard has pushed (and every relay has forwarded)
-        for (unsigned r = 0; r < W; r++) {
-            SH_DEV(sh, r);
-            for (unsigned c = 0; c < W; c++) if (c != r) HIP_TRY(hipStreamWaitEvent(sh->st[r], sh->ev_b[c], 0));
-            for (unsigned i = 0; i < R; i++) HIP_TRY(hipStreamWaitEvent(sh->st[r], sh->relay_ev[i], 0));
-        }
+        QCX_TRY(post_on(S - 1));
         sh->cur ^= 1;
     }
     sh_book(sh, swaps, true);
     sh->exchanges++;
     if (!swaps.empty()) sh->pack_passes++;
+    sh->overlapped_gates += pre.size() + post.size();
     return QCX_NO_ERROR;
+}
+
+static int sh_exchange(ShardSet *sh, const SwapList &swaps)
+{
+    static const std::vector<POp> none;
+    return sh_exchange(sh, swaps, none, none);
 }
 
 // transpositions among local positions on every shard (8 per out-of-place pass)
@@ -370,7 +482,7 @@ static size_t sh_next_use(const std::vector<SGate> &q, unsigned logical, size_t 
 static std::vector<unsigned> sh_choose_give(const ShardSet *sh, const std::vector<SGate> &q, size_t at)
 {
     std::vector<std::pair<size_t, unsigned>> cand;                 // (next use, position)
-    for (unsigned p = sh->min_evict; p < sh->n_local; p++) cand.push_back({sh_next_use(q, sh->inv[p], at), p});
+    for (unsigned p = sh->min_evict; p < sh->slice_bits; p++) cand.push_back({sh_next_use(q, sh->inv[p], at), p});     // (spectator bits are never traded)
     std::sort(cand.begin(), cand.end(), [](const std::pair<size_t, unsigned> &x, const std::pair<size_t, unsigned> &y) {
         return x.first != y.first ? x.first > y.first : x.second > y.second; });
     std::vector<unsigned> give;
@@ -379,19 +491,58 @@ static std::vector<unsigned> sh_choose_give(const ShardSet *sh, const std::vecto
     return give;
 }
 
+// may this queued gate run slice by slice under the current layout?  (an H must not target a spectator bit, nor a
+// qubit of the shard id)
+static bool sh_sliceable(const ShardSet *sh, const SGate &g) { return g.type != FUSE_H || sh->perm[g.q] < sh->slice_bits; }
+
 static int sh_flush(ShardSet *sh)
 {
     if (sh->queue.empty()) return QCX_NO_ERROR;
     std::vector<SGate> q;
     q.swap(sh->queue);
+    const bool windows = sh->overlap && sh->sigma > 0 && sh->relay_dev.empty();
+    auto global_h = [&](const SGate &g) { return g.type == FUSE_H && sh->perm[g.q] >= sh->n_local; };
     size_t i = 0;
     while (i < q.size()) {
         size_t x = i;
-        while (x < q.size() && !(q[x].type == FUSE_H && sh->perm[q[x].q] >= sh->n_local)) x++;
-        QCX_TRY(sh_run_ops(sh, q.data() + i, x - i));
-        if (x == q.size()) break;
-        QCX_TRY(sh_exchange(sh, sh_plan_give(sh, sh_choose_give(sh, q, x))));
-        i = x;                                                       // the H at x is local now
+        while (x < q.size() && !global_h(q[x])) x++;
+        if (x == q.size()) { QCX_TRY(sh_run_ops(sh, q.data() + i, x - i)); break; }
+        // gates that can share the pipeline with the exchange at x: a run before it ...
+        if (!windows) {                                // no overlap: everything up to the gate that needs the trade, the trade, go on
+            QCX_TRY(sh_run_ops(sh, q.data() + i, x - i));
+            QCX_TRY(sh_exchange(sh, sh_plan_give(sh, sh_choose_give(sh, q, x))));
+            i = x;                                     // the H at x is local now and joins what follows
+            continue;
+        }
+        size_t a = x;
+        while (a > i && sh_sliceable(sh, q[a - 1])) a--;
+        QCX_TRY(sh_run_ops(sh, q.data() + i, a - i));
+        const std::vector<POp> pre = sh_phys_list(sh, q.data() + a, x - a);        // under the layout BEFORE the trade
+        const SwapList swaps = sh_plan_give(sh, sh_choose_give(sh, q, x));
+        // ... and a run after it, under the layout the trade leaves behind (peek: book on copies of the two tables)
+        std::vector<unsigned> perm_after = sh->perm, inv_after = sh->inv;
+        sh_book_vec(perm_after, inv_after, swaps, true, sh->k, sh->zone_lo, sh->n_local);
+        auto global_h_after = [&](const SGate &g) { return g.type == FUSE_H && perm_after[g.q] >= sh->n_local; };
+        auto sliceable_after = [&](const SGate &g) { return g.type != FUSE_H || perm_after[g.q] < sh->slice_bits; };
+        size_t b = x;
+        while (b < q.size() && sliceable_after(q[b]) && !global_h_after(q[b])) b++;
+        if (b < q.size() && global_h_after(q[b]))
+            b = x + std::max<size_t>(1, (b - x + 1) / 2);       // the run ends at the NEXT trade: leave it half for its pre-window
+        if (b == x) {                                  // (the H at x targets a spectator bit after the trade: cannot happen --
+            QCX_TRY(sh_exchange(sh, swaps, pre, std::vector<POp>()));       //  give positions lie below the spectators -- but stay safe)
+            i = x;
+            continue;
+        }
+        std::vector<POp> post;
+        {
+            std::vector<unsigned> keep = sh->perm;         // resolve the post-window under the layout after the trade
+            sh->perm.swap(perm_after);
+            post = sh_phys_list(sh, q.data() + x, b - x);
+            sh->perm.swap(perm_after);
+            (void)keep;
+        }
+        QCX_TRY(sh_exchange(sh, swaps, pre, post));
+        i = b;
     }
     return QCX_NO_ERROR;
 }
@@ -422,7 +573,7 @@ static int sh_identity(ShardSet *sh)
             // some rightful shard-id qubits sit in the shard id but in the wrong slot / beside strangers: one trade
             // brings the whole shard id local (giving up positions that hold none of them)
             std::vector<unsigned> cand;
-            for (unsigned p = nl; p-- > sh->min_evict && cand.size() < k;) if (sh->inv[p] < nl) cand.push_back(p);
+            for (unsigned p = sh->slice_bits; p-- > sh->min_evict && cand.size() < k;) if (sh->inv[p] < nl) cand.push_back(p);
             QCX_TRY(sh_exchange(sh, sh_plan_give(sh, cand)));
         }
         std::vector<unsigned> give;
@@ -459,8 +610,10 @@ static int sh_sync(ShardSet *sh)
 static int sh_set_relays(ShardSet *sh, unsigned nrelays, const int *devices)
 {
     if (sh->dry) return QCX_NO_ERROR;
+    QCX_TRY(sh_identity(sh));                      // the trade zone moves with the slice geometry: identity layout, nothing queued
     QCX_TRY(sh_sync(sh));
     sh_drop_relays(sh);
+    sh_set_slices(sh, (nrelays || !sh->overlap) ? 0u : sh_default_sigma());     // relay stripes are cut from whole shards: no slices with relays
     if (!nrelays) return QCX_NO_ERROR;
     if (nrelays > 8 || !devices) return QCX_BAD_ARGUMENTS;
     if (sh->zone_lo < 8) return QCX_NO_ERROR;                      // tiny shards: nothing worth striping

@@ -151,6 +151,12 @@ class Register:
         check(lib().qcx_sharded_relay_stats(self._h, C.byref(n), C.byref(b)), "qcx_sharded_relay_stats")
         return n.value, b.value
 
+    def overlap_stats(self):
+        """(log2 of the slices a trade is cut into, gates that ran inside exchange windows so far)"""
+        sg, g = C.c_uint(0), C.c_ulong(0)
+        check(lib().qcx_sharded_overlap_stats(self._h, C.byref(sg), C.byref(g)), "qcx_sharded_overlap_stats")
+        return sg.value, g.value
+
     def sharded_trace(self):
         """diagnostics: the steps a dry-run sharded register has scheduled since the last call, as text"""
         need = C.c_size_t(0)

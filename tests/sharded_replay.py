@@ -1,7 +1,8 @@
 """Replays the step list of a DRY-RUN sharded register (qcx_register_create_sharded with devices[0] = -1, text from
 qcx_sharded_trace) on the CPU: the whole state is held as one array in PHYSICAL index order (shard id = top k bits), the
 gates are the oracle's, applied at the physical bit positions the schedule names; pack / permute / trade steps are the
-index-bit permutations the kernels k_swap_bits / k_pack_push perform.  If the scheduler's bookkeeping is right, the
+index-bit permutations the kernels k_swap_bits / k_pack_push perform (`trade z`: the k shard-id bits change places with
+the local bits z .. z+k-1).  If the scheduler's bookkeeping is right, the
 array after `restore identity` equals the oracle's result of the same gate list in logical order, bit for bit."""
 import numpy as np
 
@@ -33,7 +34,7 @@ def _phase(state, n, pa, pb, c, s):
 
 def replay(trace, n, k, M, state, ob):
     """apply the trace to `state` (float64, 2 * 2^n, physical order); returns (state, counts of step kinds)"""
-    n_local, zone_lo = n - k, n - 2 * k
+    n_local = n - k
     counts = {"ops": 0, "pack": 0, "trade": 0, "permute": 0, "gates": 0}
     for line in trace.splitlines():
         t = line.split()
@@ -57,6 +58,8 @@ def replay(trace, n, k, M, state, ob):
                 state = _permute(state, n, pairs)
             counts[t[0]] += 1
         elif t[0] == "trade":
+            zone_lo = int(t[1])                    # the k trade-zone bits sit below the spectator bits of a slice
+            assert zone_lo + k <= n_local
             state = _permute(state, n, [(zone_lo + j, n_local + j) for j in range(k)])
             counts["trade"] += 1
         elif t[0] == "reset":

@@ -191,3 +191,38 @@ def test_multi_path_striping_gives_the_same_bits(qc, ob, shards, n, relays):
         for q in (n - 1, n - 2):
             qc.hadamard_gate(q, reg); ob.hadamard(want, n, q)
         assert np.array_equal(bits(reg.read()), bits(want))
+
+
+@pytest.mark.parametrize("slices_log2,overlap", [(0, 1), (1, 1), (2, 1), (3, 1), (3, 0)])
+def test_sliced_exchange_windows(qc, ob, monkeypatch, slices_log2, overlap):
+    """a trade cut into 2^sigma slices on a second stream per shard, with the gates around it run slice by slice in its
+    pre- and post-window: same bits for every slice count, with and without windows"""
+    monkeypatch.setenv("QCX_SHARD_SLICES_LOG2", str(slices_log2))
+    monkeypatch.setenv("QCX_SHARD_OVERLAP", str(overlap))
+    n, M, shards = 18, 4, 4
+    rnd = random.Random(31 + slices_log2)
+    with qc.Register(n - M, M, shards=shards, devices=[0]) as reg:
+        sg, _ = reg.overlap_stats()
+        assert sg == (slices_log2 if overlap else 0)         # slices only serve the windows
+        for trial in range(3):
+            reg.set_fusion(1 if trial != 1 else -1)
+            reg.fill_random(40 + trial)
+            want = ob.fill_random(n, 40 + trial)
+            for _ in range(120):
+                t = rnd.random()
+                if t < 0.45:
+                    q = rnd.choice([n - 1, n - 2, rnd.randrange(n), rnd.randrange(M, n)])      # plenty of global targets
+                    qc.hadamard_gate(q, reg); ob.hadamard(want, n, q)
+                elif t < 0.85:
+                    c, tq = rnd.sample(range(n), 2)
+                    th = rnd.uniform(-3.0, 3.0)
+                    qc.c_phase_shift_gate(c, tq, th, reg); ob.cphase(want, n, c, tq, th)
+                else:
+                    Cn, A, ctl = rnd.randrange(2, 17), rnd.randrange(1, 99), rnd.randrange(M, n)
+                    qc.c_amodc_gate(Cn, A, ctl, reg); ob.camodc(want, n, M, Cn, A, ctl)
+            assert np.array_equal(bits(reg.read()), bits(want)), (slices_log2, overlap, trial)
+        _, in_windows = reg.overlap_stats()
+        ex, _ = reg.sharded_stats()
+        assert ex >= 3
+        if slices_log2 and overlap:
+            assert in_windows > ex                               # gates really ran inside the windows

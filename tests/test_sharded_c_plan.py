@@ -97,3 +97,28 @@ def test_layout_after_a_global_hadamard_and_argument_checks(qc, ob):
             qc.hadamard_gate(n, reg)
         with pytest.raises(qc.QcxError):
             reg.norm2()                                                         # a dry run has no amplitudes: loud, not silent
+
+
+@pytest.mark.parametrize("slices_log2,overlap", [(3, 1), (2, 1), (1, 1), (0, 1), (3, 0)])
+def test_exchange_windows_in_the_schedule(qc, ob, monkeypatch, slices_log2, overlap):
+    """with spectator bits a trade sits between a pre-window (gates resolved under the old layout) and a post-window
+    (new layout); the replay applies them in trace order -- any mistake in which layout a window is resolved under, or in
+    where the trade zone sits below the spectators, breaks the bits"""
+    monkeypatch.setenv("QCX_SHARD_SLICES_LOG2", str(slices_log2))
+    monkeypatch.setenv("QCX_SHARD_OVERLAP", str(overlap))
+    rnd = random.Random(5 + slices_log2)
+    n, M, shards = 15, 3, 4
+    for trial in range(4):
+        prog = []
+        for _ in range(100):
+            t = rnd.random()
+            if t < 0.45:
+                prog.append(("h", rnd.choice([n - 1, n - 2, rnd.randrange(n)])))
+            elif t < 0.85:
+                c, tq = rnd.sample(range(n), 2)
+                prog.append(("p", c, tq, rnd.uniform(-3.0, 3.0)))
+            else:
+                prog.append(("c", rnd.randrange(2, 9), rnd.randrange(1, 50), rnd.randrange(M, n)))
+        got, want, counts, _ = run_dry(qc, ob, n - M, M, shards, prog, seed=trial)
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (slices_log2, overlap, trial)
+        assert counts["trade"] >= 2

@@ -17,6 +17,9 @@
 //     AND writes each amplitude straight into the buffer of the GPU that owns it afterwards -- peer stores over xGMI,
 //     all 7 links of a GPU busy together, no staging buffer, no second pass.  Which local qubits to give up is
 //     decided with look-ahead over the queued gates (Belady: those whose next H lies furthest in the future).
+//     The trade is issued slice by slice (the top sigma local bits are spectators that are never traded) on a second
+//     stream per shard, and the gates next to it in the queue run on the slices that are not in flight: exchange and
+//     compute overlap.  With fewer shards than GPUs, idle GPUs can relay stripes of every chunk (multi-path striping).
 //   * measurement hands the exact running sum from shard to shard in index order (the index the unsharded scan
 //     would pick); norm and read-back flush the queue; measurement and read-back restore the identity layout.
 // Shards may share a device ("virtual" shards: several entries of `devices` equal) -- that is how the path is tested
@@ -51,7 +54,7 @@ struct ShardSet {
     std::vector<hipStream_t> xs;                 // per shard: the stream the pack+push kernels run on
     std::vector<hipEvent_t>  ev_pre, ev_push;    // [shard * 8 + slice]: pre-window gates done / slice pushed
     unsigned long exchanges = 0, pack_passes = 0;
-    std::vector<hipEvent_t>  ev_a, ev_b;
+    std::vector<hipEvent_t>  ev_a;               // per shard: its earlier work is done (recorded at the start of a trade)
     // multi-path striping: GPUs that hold no shard relay a share of every chunk (qcx_sharded_set_relays)
     std::vector<int>         relay_dev;
     std::vector<hipStream_t> relay_st;
@@ -116,7 +119,6 @@ static void sh_free(ShardSet *sh)
             if (r < sh->st.size() && sh->st[r]) { (void)hipStreamSynchronize(sh->st[r]); (void)qcx_shard_release_stream(sh->st[r]); }
             for (int b = 0; b < 2; b++) if (r < sh->buf[b].size() && sh->buf[b][r]) (void)hipFree(sh->buf[b][r]);
             if (r < sh->ev_a.size() && sh->ev_a[r]) (void)hipEventDestroy(sh->ev_a[r]);
-            if (r < sh->ev_b.size() && sh->ev_b[r]) (void)hipEventDestroy(sh->ev_b[r]);
             for (unsigned e = 8 * r; e < 8 * r + 8; e++) {
                 if (e < sh->ev_pre.size() && sh->ev_pre[e]) (void)hipEventDestroy(sh->ev_pre[e]);
                 if (e < sh->ev_push.size() && sh->ev_push[e]) (void)hipEventDestroy(sh->ev_push[e]);
@@ -170,7 +172,7 @@ static int sh_create(int L, int M, unsigned nshards, const int *devices, ShardSe
     for (unsigned r = 1; r < nshards; r++) sh->overlap |= sh->dev[r] != sh->dev[0];
     if (const char *e = getenv("QCX_SHARD_OVERLAP")) sh->overlap = atoi(e) != 0;
     if (!sh->overlap) sh_set_slices(sh, 0);            // slices only serve the windows
-    sh->st.assign(nshards, nullptr); sh->ev_a.assign(nshards, nullptr); sh->ev_b.assign(nshards, nullptr);
+    sh->st.assign(nshards, nullptr); sh->ev_a.assign(nshards, nullptr);
     sh->xs.assign(nshards, nullptr); sh->ev_pre.assign(8 * nshards, nullptr); sh->ev_push.assign(8 * nshards, nullptr);
     sh->buf[0].assign(nshards, nullptr); sh->buf[1].assign(nshards, nullptr);
     int prev = 0;
@@ -191,7 +193,6 @@ static int sh_create(int L, int M, unsigned nshards, const int *devices, ShardSe
         if (status != QCX_NO_ERROR) break;
         if (e == hipSuccess) e = hipStreamCreate(&sh->st[r]);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sh->ev_a[r], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&sh->ev_b[r], hipEventDisableTiming);
         if (e == hipSuccess) e = hipStreamCreate(&sh->xs[r]);
         for (unsigned q = 8 * r; q < 8 * r + 8 && e == hipSuccess; q++) {
             e = hipEventCreateWithFlags(&sh->ev_pre[q], hipEventDisableTiming);

@@ -17,7 +17,8 @@
  *   - an independent second derivation: dense Kronecker-product operators
  *     built from the base matrices of Q:210-225 (agreement to 1e-13), the
  *     DFT-matrix identity of the inverse-QFT schedule, numpy's running sum
- *     for the measurement rule;
+ *     for the measurement rule; a Python-float restatement of Q:393-413 that the
+ *     oracle equals bit for bit (rounding order independent of any C compiler);
  *   - tests/golden/survey_appendix_c.json: values the survey session read off
  *     a build of qc_shor.c against a GSL stand-in; no generator is committed,
  *     so by this project's rules they pin nothing -- kept as regression values.

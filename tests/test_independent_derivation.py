@@ -178,3 +178,72 @@ def test_report_table_one_statistics(ob):
         assert abs(published_mean[w] - 25.0) < 3 * 4.33 / math.sqrt(5)          # the report's sample vs the exact law
         assert abs(xs.mean() - published_mean[w]) < 3 * 4.33 * math.sqrt(2.0 / 5)   # the two samples vs each other
         assert 0.3 < xs.std(ddof=1) / 4.33 < 2.2 and 0.3 < published_sigma[w] / 4.33 < 2.2   # chi-square range for 4 dof
+
+
+# ---- the reference's mat-vec, written out in Python floats (IEEE binary64, no contraction, no vectorisation) -----------------
+def python_matvec(triplets, cur):
+    """Q:393-413 literally: zero the new state; for every stored triplet, in insertion order,
+    new[row] += M * cur[col] as four products and four sums in the order the reference writes them"""
+    dim = len(cur) // 2
+    new = [0.0] * (2 * dim)
+    for row, col, mr, mi in triplets:
+        cr, ci = cur[2 * col], cur[2 * col + 1]
+        new[2 * row] = new[2 * row] + ((mr * cr) - (mi * ci))              # Q:409
+        new[2 * row + 1] = new[2 * row + 1] + ((mr * ci) + (mi * cr))      # Q:412
+    return np.array(new, dtype=np.float64)
+
+
+def scan_triplets(n, free_bits, entry):
+    """the reference's index-pair scan (Q:456-481, Q:529-562): rows ascending, columns ascending, keep (i, j) when they agree
+    on every bit outside `free_bits`; entry(i, j) -> (re, im) of the base matrix element"""
+    keep = ~sum(1 << b for b in free_bits)
+    out = []
+    for i in range(1 << n):
+        for j in range(1 << n):
+            if (i & keep) == (j & keep):
+                mr, mi = entry(i, j)
+                out.append((i, j, mr, mi))
+    return out
+
+
+@pytest.mark.parametrize("n,q", [(3, 0), (5, 2), (6, 5)])
+def test_hadamard_rounding_order_against_python_floats(ob, n, q):
+    s = 0.70710678118654752440                                             # M_SQRT1_2, Q:210-213
+    trip = scan_triplets(n, [q], lambda i, j: ((-s if ((i >> q) & 1) and ((j >> q) & 1) else s), 0.0))
+    a = ob.random_state(n, 3)
+    want = python_matvec(trip, list(a))
+    ob.hadamard(a, n, q)
+    assert np.array_equal(a.view(np.uint64), want.view(np.uint64))
+
+
+@pytest.mark.parametrize("n,c,t,theta", [(4, 3, 1, math.pi / 4), (6, 0, 5, 1.234), (5, 4, 2, math.pi / 2 ** 9)])
+def test_cphase_rounding_order_against_python_floats(ob, n, c, t, theta):
+    er, ei = ob.polar(theta)                                               # gsl_complex_polar(1, theta), Q:526
+
+    def entry(i, j):                                                       # diag(1, 1, 1, e^{i theta}) on (c, t), Q:220-225
+        bi, bj = 2 * ((i >> c) & 1) + ((i >> t) & 1), 2 * ((j >> c) & 1) + ((j >> t) & 1)
+        if bi != bj:
+            return (0.0, 0.0)                                              # explicit zeros are stored and multiplied too
+        return (er, ei) if bi == 3 else (1.0, 0.0)
+    trip = scan_triplets(n, [c, t], entry)
+    a = ob.random_state(n, 4)
+    want = python_matvec(trip, list(a))
+    ob.cphase(a, n, c, t, theta)
+    assert np.array_equal(a.view(np.uint64), want.view(np.uint64))
+
+
+@pytest.mark.parametrize("n,M,Cn,atox,ctl", [(6, 3, 7, 3, 4), (7, 4, 15, 6, 5), (7, 4, 15, 7, 6)])
+def test_camodc_rounding_order_against_python_floats(ob, n, M, Cn, atox, ctl):
+    """Q:608-657: one triplet (j, k, 1 + 0i) per column k in ascending k; colliding rows (non-coprime multiplier) sum in that order"""
+    A = atox % Cn
+    trip = []
+    for k in range(1 << n):
+        f = k & ((1 << M) - 1)
+        j = k
+        if (k >> ctl) & 1 and f < Cn:
+            j = (k - f) | ((A * f) % Cn)
+        trip.append((j, k, 1.0, 0.0))
+    a = ob.random_state(n, 6)
+    want = python_matvec(trip, list(a))
+    ob.camodc(a, n, M, Cn, atox, ctl)
+    assert np.array_equal(a.view(np.uint64), want.view(np.uint64))

@@ -905,15 +905,24 @@ enum : uint32_t { FUSE_PRUN = 4 };
 #define QCX_ZERO_13 QCX_Z1(0) QCX_Z1(2) QCX_Z1(3)
 #define QCX_ZERO_14 QCX_Z1(1) QCX_Z1(2) QCX_Z1(3)
 #define QCX_ZERO_15 QCX_Z1(0) QCX_Z1(1) QCX_Z1(2) QCX_Z1(3)
-// one gate: mask the lanes, rotate, restore EXEC
+// one gate: mask the lanes, rotate, restore EXEC.  A gate without tile-local conditions (its mask word is 0: the usual
+// case, a phase whose target lies outside the tile) skips the two vector instructions of the lane mask and the EXEC
+// round trip: the pass is bound by vector issue, the scalar compare + branch ride the other port.
 #define QCX_GATE(M, ROTS)                                            \
+    "s_cmp_eq_u32 %[" M "], 0\n\t"                                   \
+    "s_cbranch_scc1 6f\n\t"                                         \
     "v_and_b32 %[t], %[" M "], %[p]\n\t"                             \
     "v_cmpx_eq_u32_e32 vcc, %[" M "], %[t]\n\t"                      \
     "s_or_b64 %[tch], %[tch], exec\n\t"                              \
-    "s_cbranch_execz 1f\n\t"                                         \
+    "s_cbranch_execz 1f\n\t"                                        \
     ROTS                                                             \
-    "1:\n\t"                                                         \
-    "s_mov_b64 exec, %[ex]\n\t"
+    "1:\n\t"                                                        \
+    "s_mov_b64 exec, %[ex]\n\t"                                     \
+    "s_branch 7f\n\t"                                               \
+    "6:\n\t"                                                        \
+    "s_or_b64 %[tch], %[tch], exec\n\t"                              \
+    ROTS                                                             \
+    "7:\n\t"
 // H on one of the round's two register bits, in place and without the final "+ 0.0" (the round canonicalises once at
 // its end): the same four products and four sums as h_butterfly
 #define QCX_HBF(AX, AY, BX, BY)                                      \

@@ -226,3 +226,14 @@ def test_sliced_exchange_windows(qc, ob, monkeypatch, slices_log2, overlap):
         assert ex >= 3
         if slices_log2 and overlap:
             assert in_windows > ex                               # gates really ran inside the windows
+
+
+def test_sharded_register_from_plain_c(tmp_path):
+    """tests/c/sharded_api.c: include/qcx.h only, no Python in the loop"""
+    out = str(tmp_path / "sharded_api")
+    lib = os.path.join(ROOT, "quantumcomputer_amd")
+    subprocess.run(["gcc", "-std=gnu11", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c", "sharded_api.c"), "-L", lib, "-lqcx", "-lm",
+                    "-Wl,-rpath," + lib, "-o", out], check=True)
+    r = subprocess.run([out, "11", "5"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr

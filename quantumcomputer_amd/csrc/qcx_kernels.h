@@ -269,6 +269,9 @@ __global__ __launch_bounds__(BLOCK) void k_camodc(amp_t *__restrict__ amp, Camod
     const bool squeeze = P.ctl >= (int)P.M && P.ctl < (int)P.logT;
     for (uint64_t tt = blockIdx.x; tt < P.ntiles; tt += gridDim.x) {
         amp_t *g = camodc_tile(amp, P, tt);
+        // (fill through registers with the DEFAULT cache policy, measured at n = 30: 2.9 ms per gate; an LDS-DMA fill 3.0-3.2 ms;
+        // nontemporal loads 4.1-4.5 ms -- the moved elements are rewritten as PARTIAL lines a moment later and those
+        // writes must still find their lines in L2)
         for (unsigned e = threadIdx.x; e < T; e += BLOCK) tile[e] = g[camodc_elem(squeeze, (unsigned)P.ctl, e)];
         __syncthreads();
         for (unsigned e = threadIdx.x; e < T; e += BLOCK) {

@@ -34,7 +34,7 @@ typedef struct {
     bool seed_given, ref_quirks, json, fusion, per_gate;
     const char *dump_final, *dump_circuit;
     int gpus;                   /* -g N: shard the register over N GPUs (2, 4, 8, 16) from this one process */
-    const char *gpu_list;       /* -d "0,0,1,1": HIP device of each shard (default shard r on device r) */
+    const char *gpu_list;       /* -d "0,0,1,1": HIP device of each shard (default: spread over the visible GPUs) */
 } Options;
 
 typedef struct {
@@ -195,14 +195,14 @@ int main(int argc, char **argv)
     qcx_register *reg = NULL;                                                    /* Q:1316-1324 */
     if (o.gpus > 1) {                       /* one process, N shards: the top log2 N qubits select the GPU */
         int devs[16], nd = 0;
-        for (int i = 0; i < 16; i++) devs[i] = i;
         for (const char *p = o.gpu_list; p && *p && nd < 16; nd++) { devs[nd] = atoi(p); while (*p && *p != ',') p++; if (*p == ',') p++; }
         for (int i = nd; nd > 0 && i < 16; i++) devs[i] = devs[nd - 1];
-        s = qcx_register_create_sharded(o.L, o.M, (unsigned)o.gpus, devs, &reg);
+        /* no -d: the library spreads the shards over the visible GPUs (and checks the exchange between them first) */
+        s = qcx_register_create_sharded(o.L, o.M, (unsigned)o.gpus, nd ? devs : NULL, &reg);
     } else
         s = qcx_register_create(o.L, o.M, &reg);
     if (s != QCX_NO_ERROR) {
-        fprintf(stderr, "Error: could not create the %d-qubit register on the GPU: %s.\n", o.L + o.M, qcx_status_string(s));
+        fprintf(stderr, "Error: could not create the %d-qubit register on the GPU: %s (%s).\n", o.L + o.M, qcx_status_string(s), qcx_last_error());
         qcx_rng_free(rng);
         return s == QCX_INSUFFICIENT_MEMORY ? QCX_INSUFFICIENT_MEMORY : QCX_UNKNOWN_ERROR;
     }

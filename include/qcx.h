@@ -70,10 +70,21 @@ int  qcx_M_size(const qcx_register *reg);
  * index bits).  The handle is an ordinary qcx_register: every function of this header works on it, so the reference's
  * circuit builders and main (Q:678-737, Q:1284-1347) run unchanged on the 8 GPUs of a node.  A Hadamard on a qubit held
  * in the shard id costs one exchange: each GPU's pack pass stores straight into its peers' buffers over xGMI.
- * devices[r] = HIP device of shard r (NULL: shard r on device r; entries may repeat: several shards on one GPU).
+ * devices[r] = HIP device of shard r (entries may repeat: several shards on one GPU).  NULL: the shards are spread over
+ * the visible devices (qcx_spread_devices: 8 shards on 8 GPUs = shard r on device r, on 4 GPUs two neighbours per GPU,
+ * on one GPU all on device 0).
  * Setting QCX_SHARDS=N in the environment makes qcx_register_create do this by itself (QCX_SHARD_DEVICES="0,1,..").
- * Not available on a sharded register: qcx_register_set_stream, qcx_device_pointer (NULL), the event pool. */
+ * Pre-flight check: when the shards sit on more than one device, creation first trades a small register there and back
+ * on the same devices and compares every amplitude, bit for bit, with what the layout says it must be; on a mismatch
+ * creation fails with QCX_HIP_ERROR and qcx_last_error() names the shard (QCX_SHARD_SELFCHECK=0 skips, =1 forces the
+ * check; qcx_sharded_set_relays runs it again through the relays).
+ * Limits: M_size <= 12 (the modular multiply stages whole 2^M blocks in LDS; larger M registers are single-GPU only and
+ * give QCX_UNSUPPORTED here).  Not available on a sharded register: qcx_register_set_stream, qcx_device_pointer (NULL),
+ * the event pool. */
 int  qcx_register_create_sharded(int L_size, int M_size, unsigned nshards, const int *devices, qcx_register **out);
+int  qcx_spread_devices(unsigned nshards, int visible_devices /* <= 0: ask HIP */, int *devices_out /* [nshards] */);
+int  qcx_sharded_selfcheck(qcx_register *reg);             /* the pre-flight exchange check on demand */
+unsigned long qcx_sharded_selfchecks(const qcx_register *reg);   /* checks this register has passed */
 unsigned qcx_register_shards(const qcx_register *reg);      /* 1 for an unsharded register */
 int  qcx_sharded_stats(qcx_register *reg, unsigned long *exchanges, unsigned long *pack_passes);
 /* Multi-path striping for fewer shards than GPUs on the node: the listed GPUs (which hold no shard)

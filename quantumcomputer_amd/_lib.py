@@ -34,6 +34,9 @@ SIGNATURES = {
     "qcx_register_create": (_i, [_i, _i, C.POINTER(_p)]),
     "qcx_register_destroy": (_i, [_p]),
     "qcx_register_create_sharded": (_i, [_i, _i, _u, C.POINTER(_i), C.POINTER(_p)]),
+    "qcx_spread_devices": (_i, [_u, _i, C.POINTER(_i)]),
+    "qcx_sharded_selfcheck": (_i, [_p]),
+    "qcx_sharded_selfchecks": (_ul, [_p]),
     "qcx_register_shards": (_u, [_p]),
     "qcx_sharded_stats": (_i, [_p, C.POINTER(_ul), C.POINTER(_ul)]),
     "qcx_sharded_set_relays": (_i, [_p, _u, C.POINTER(_i)]),
@@ -185,6 +188,28 @@ def lib():
 def check(status, where=""):
     if status != NO_ERROR:
         raise QcxError(status, where)
+
+
+def spread_devices(shards, visible=None):
+    """HIP device of each shard, as qcx_register_create_sharded(devices=NULL) places them: over the largest
+    power-of-two number of devices <= min(shards, visible), neighbouring shards together; one visible GPU gives
+    [0] * shards (the virtual shards of the one-GPU tests).  visible=None asks HIP (needs a GPU); an explicit count is
+    pure arithmetic."""
+    out = (C.c_int * int(shards))()
+    check(lib().qcx_spread_devices(int(shards), 0 if visible is None else int(visible), out), "qcx_spread_devices")
+    return list(out)
+
+
+def idle_devices(shard_devices, count, visible=None):
+    """`count` relay GPUs for multi-path striping: devices that hold no shard first, then (when there are not enough
+    idle ones, e.g. on a one-GPU box) the shard devices again"""
+    if visible is None:
+        n = C.c_int(0)
+        check(lib().qcx_device_count(C.byref(n)), "qcx_device_count")
+        visible = n.value
+    idle = [d for d in range(visible) if d not in set(shard_devices)]
+    pool = idle + sorted(set(shard_devices))
+    return [pool[i % len(pool)] for i in range(count)]
 
 
 def polar(theta):

@@ -781,6 +781,30 @@ extern "C" int qcx_sharded_relay_stats(qcx_register *r, unsigned *nrelays, unsig
     return QCX_NO_ERROR;
 }
 
+// where qcx_register_create_sharded(devices = NULL) puts the shards when `visible` devices can be seen (visible <= 0: ask HIP)
+extern "C" int qcx_spread_devices(unsigned nshards, int visible, int *devices_out)
+{
+    if (!devices_out || nshards < 1 || nshards > 16 || (nshards & (nshards - 1))) return QCX_BAD_ARGUMENTS;
+    if (visible <= 0) { QCX_TRY(qcx_device_count(&visible)); if (visible < 1) { set_error("no HIP device"); return QCX_HIP_ERROR; } }
+    sh_spread(nshards, visible, devices_out);
+    return QCX_NO_ERROR;
+}
+
+// the pre-flight exchange check on demand (it runs by itself at creation when the shards sit on different devices)
+extern "C" int qcx_sharded_selfcheck(qcx_register *r)
+{
+    if (!r || !r->sh) return QCX_BAD_ARGUMENTS;
+    if (r->sh->dry) return QCX_UNSUPPORTED;
+    std::vector<int> rel(r->sh->relay_dev);
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    const int s = sh_selfcheck(r->sh, (unsigned)rel.size(), rel.data());
+    (void)hipSetDevice(prev);
+    return s;
+}
+
+extern "C" unsigned long qcx_sharded_selfchecks(const qcx_register *r) { return (r && r->sh) ? r->sh->selfchecks : 0ul; }
+
 extern "C" unsigned qcx_register_shards(const qcx_register *r) { return r ? (r->sh ? r->sh->W : 1u) : 0u; }
 
 extern "C" int qcx_sharded_stats(qcx_register *r, unsigned long *exchanges, unsigned long *pack_passes)
@@ -821,13 +845,13 @@ extern "C" int qcx_register_create(int L, int M, qcx_register **out)
         const int ns = atoi(e);
         if (ns > 1) {
             int devs[16];
-            for (int i = 0; i < 16; i++) devs[i] = i;
-            if (const char *d = getenv("QCX_SHARD_DEVICES")) {
+            const char *d = getenv("QCX_SHARD_DEVICES");
+            if (d && *d) {
                 int i = 0;
                 for (const char *p = d; *p && i < 16; i++) { devs[i] = atoi(p); while (*p && *p != ',') p++; if (*p == ',') p++; }
-                if (i < ns && i < 16) for (int j = i; j < 16; j++) devs[j] = devs[i ? i - 1 : 0];
+                for (int j = i; j < 16; j++) devs[j] = devs[i ? i - 1 : 0];
             }
-            return qcx_register_create_sharded(L, M, (unsigned)ns, devs, out);
+            return qcx_register_create_sharded(L, M, (unsigned)ns, (d && *d) ? devs : nullptr, out);    // no list: spread over the visible devices
         }
     }
     if (L < 0 || M < 0 || L + M < 1 || L + M > 36) return QCX_BAD_ARGUMENTS;

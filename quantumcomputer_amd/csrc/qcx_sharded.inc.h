@@ -63,6 +63,8 @@ struct ShardSet {
     uint32_t nb_direct = 0, nb_relay = 0;         // blocks of 256 amplitudes of a chunk: direct stripe, each relay's stripe
     uint64_t stage_amps = 0;                      // amplitudes per staging slot (the last relay's stripe, the longest)
     unsigned long relayed_bytes = 0;
+    bool     in_selfcheck = false;                // this set IS the small register of a self-check (no nested checks)
+    unsigned long selfchecks = 0;                 // pre-flight checks this register has passed (qcx_sharded_selfchecks)
     int      fusion = 1;                          // 1: each shard's gate list goes through the fused-pass scheduler; -1/0: one launch per gate
     size_t   max_queue = 8192;
     std::string trace;
@@ -130,7 +132,20 @@ static void sh_free(ShardSet *sh)
     delete sh;
 }
 
-static int sh_create(int L, int M, unsigned nshards, const int *devices, ShardSet **out)
+// Default placement of W shards on the visible devices: over the largest power-of-two number of devices that is at most
+// min(W, visible), neighbouring shards together (W = 8 on 8 GPUs: shard r on device r; on 4: two shards per GPU; on one
+// GPU: everything on device 0 -- the "virtual shards" of the one-GPU tests).  Pure arithmetic: qcx_spread_devices
+// exposes it so that hosts and tests place shards the same way the library does.
+static void sh_spread(unsigned nshards, int ndev, int *out)
+{
+    unsigned m = 1;
+    while (2 * m <= nshards && (int)(2 * m) <= ndev) m *= 2;
+    for (unsigned r = 0; r < nshards; r++) out[r] = (int)(r / (nshards / m));
+}
+
+static int sh_selfcheck(const ShardSet *big, unsigned nrelays, const int *relay_devices);
+
+static int sh_create(int L, int M, unsigned nshards, const int *devices, ShardSet **out, bool selfcheck = true)
 {
     *out = nullptr;
     if (nshards < 2 || nshards > 16 || (nshards & (nshards - 1))) { set_error("sharded register: 2, 4, 8 or 16 shards"); return QCX_BAD_ARGUMENTS; }
@@ -158,8 +173,12 @@ static int sh_create(int L, int M, unsigned nshards, const int *devices, ShardSe
     int ndev = 0;
     { const int s = qcx_device_count(&ndev); if (s != QCX_NO_ERROR) { delete sh; return s; } }
     sh->dev.resize(nshards);
+    if (!devices) {                                  // no placement given: spread over the visible devices
+        if (ndev < 1) { set_error("sharded register: no HIP device"); delete sh; return QCX_HIP_ERROR; }
+        sh_spread(nshards, ndev, sh->dev.data());
+    }
     for (unsigned r = 0; r < nshards; r++) {
-        sh->dev[r] = devices ? devices[r] : (int)r;
+        if (devices) sh->dev[r] = devices[r];
         if (sh->dev[r] < 0 || sh->dev[r] >= ndev) {
             set_error("sharded register: shard %u wants device %d, %d visible", r, sh->dev[r], ndev);
             delete sh; return QCX_HIP_ERROR;
@@ -209,6 +228,21 @@ static int sh_create(int L, int M, unsigned nshards, const int *devices, ShardSe
     }
     (void)hipSetDevice(prev);
     if (status != QCX_NO_ERROR) { sh_free(sh); return status; }
+    // Pre-flight check of the exchange machinery on THESE devices (peer stores into hipMalloc'ed memory of another GPU,
+    // cross-device stream/event ordering): a wrong trade would otherwise still produce plausible-looking numbers.  Runs
+    // when the shards sit on more than one device (QCX_SHARD_SELFCHECK=1 forces it, =0 skips it); creation fails on a
+    // mismatch.
+    if (selfcheck) {
+        bool distinct = false;
+        for (unsigned r = 1; r < nshards; r++) distinct |= sh->dev[r] != sh->dev[0];
+        bool run = distinct;
+        if (const char *e = getenv("QCX_SHARD_SELFCHECK")) run = atoi(e) != 0;
+        if (run) {
+            const int cs = sh_selfcheck(sh, 0, nullptr);
+            (void)hipSetDevice(prev);
+            if (cs != QCX_NO_ERROR) { sh_free(sh); return cs; }
+        }
+    }
     *out = sh;
     return QCX_NO_ERROR;
 }
@@ -653,6 +687,15 @@ static int sh_set_relays(ShardSet *sh, unsigned nrelays, const int *devices)
             return e == hipErrorOutOfMemory ? QCX_INSUFFICIENT_MEMORY : QCX_HIP_ERROR;
         }
     }
+    // the relayed path (staging stores into the relays, forwarding copies) gets the same pre-flight check as the direct one
+    bool run = false;
+    for (unsigned i = 0; i < R; i++) run |= devices[i] != sh->dev[0];
+    for (unsigned r = 1; r < W; r++) run |= sh->dev[r] != sh->dev[0];
+    if (const char *e = getenv("QCX_SHARD_SELFCHECK")) run = atoi(e) != 0;
+    if (run && !sh->in_selfcheck) {
+        const int cs = sh_selfcheck(sh, R, devices);
+        if (cs != QCX_NO_ERROR) { sh_drop_relays(sh); sh_set_slices(sh, sh->overlap ? sh_default_sigma() : 0u); return cs; }
+    }
     return QCX_NO_ERROR;
 }
 
@@ -737,5 +780,85 @@ static int sh_copy(ShardSet *sh, uint64_t first, uint64_t count, double *host, b
         else HIP_TRY(hipMemcpy(d, h, (size_t)cnt * sizeof(amp_t), hipMemcpyHostToDevice));
         at += cnt; left -= cnt;
     }
+    return QCX_NO_ERROR;
+}
+
+// ---- pre-flight self-check -------------------------------------------------------------------------------------------
+// A small register (M = 0, at most 2^(2k+12) amplitudes per shard) on the SAME devices, with the same slice geometry
+// rules and, if asked, the same relays:
+//   (1) fill it with the counter-based generator (its CPU twin gives every expected amplitude, bit for bit);
+//   (2) one trade (pack + push of all k shard-id bits, exactly as a Hadamard on a global qubit would trigger it);
+//       every amplitude must now sit where the booked layout says it does -- checked on the raw shard buffers;
+//   (3) restore the identity layout (more trades and a local permutation) and compare with the generator again.
+// No arithmetic touches the amplitudes, so the comparison is exact.  QCX_SHARD_SELFCHECK_INJECT=1 corrupts one amplitude
+// after step (2): the tests use it to prove that a wrong trade is caught.
+static int sh_selfcheck(const ShardSet *big, unsigned nrelays, const int *relay_devices)
+{
+    const unsigned k = big->k;
+    const unsigned nl = std::min<unsigned>(big->n_local, 2 * k + 12);
+    ShardSet *t = nullptr;
+    int st = sh_create((int)(nl + k), 0, big->W, big->dev.data(), &t, false);
+    if (st != QCX_NO_ERROR) {
+        const std::string why = g_last_error;
+        set_error("sharded register self-check: cannot build the %u-qubit test register (%s)", nl + k, why.c_str());
+        return st;
+    }
+    t->in_selfcheck = true;
+    auto fail = [&](int code) { sh_free(t); return code; };
+    if (nrelays) { st = sh_set_relays(t, nrelays, relay_devices); if (st != QCX_NO_ERROR) return fail(st); }
+    const uint64_t seed = 0x5e1fc4ecULL, per = (uint64_t)1 << nl, dim = per << k;
+    const double scale = sqrt(6.0 / (double)dim);
+    auto expect = [&](uint64_t logical, double *re, double *im) {
+        const uint64_t c = 2 * logical;
+        *re = ((double)(splitmix64(seed + c) >> 11) * 0x1p-53 - 0.5) * scale;
+        *im = ((double)(splitmix64(seed + c + 1) >> 11) * 0x1p-53 - 0.5) * scale;
+    };
+    if ((st = sh_fill_random(t, seed)) != QCX_NO_ERROR) return fail(st);
+    // (2) one trade; give positions as the scheduler would choose them with nothing queued
+    const std::vector<SGate> none;
+    if ((st = sh_exchange(t, sh_plan_give(t, sh_choose_give(t, none, 0)))) != QCX_NO_ERROR) return fail(st);
+    if ((st = sh_sync(t)) != QCX_NO_ERROR) return fail(st);
+    if (const char *e = getenv("QCX_SHARD_SELFCHECK_INJECT"))
+        if (atoi(e)) { (void)hipSetDevice(t->dev[t->W - 1]); (void)hipMemset(t->buf[t->cur][t->W - 1] + (per >> 1), 0x3c, sizeof(amp_t)); }
+    std::vector<double> host(2 * per);
+    uint64_t bad = 0, first_bad = 0; unsigned bad_shard = 0;
+    for (unsigned r = 0; r < t->W; r++) {
+        if (hipSetDevice(t->dev[r]) != hipSuccess ||
+            hipMemcpy(host.data(), t->buf[t->cur][r], per * sizeof(amp_t), hipMemcpyDeviceToHost) != hipSuccess) {
+            set_error("sharded register self-check: read-back of shard %u failed: %s", r, hipGetErrorString(hipGetLastError()));
+            return fail(QCX_HIP_ERROR);
+        }
+        for (uint64_t j = 0; j < per; j++) {
+            const uint64_t phys = ((uint64_t)r << nl) | j;
+            uint64_t logical = 0;
+            for (unsigned q = 0; q < t->n; q++) logical |= ((phys >> t->perm[q]) & 1u) << q;
+            double re, im;
+            expect(logical, &re, &im);
+            if (memcmp(&re, &host[2 * j], 8) || memcmp(&im, &host[2 * j + 1], 8)) { if (!bad++) { first_bad = j; bad_shard = r; } }
+        }
+    }
+    if (bad) {
+        set_error("sharded register self-check FAILED after one trade: %llu amplitudes wrong (first: shard %u on device %d, local index %llu)",
+                  (unsigned long long)bad, bad_shard, t->dev[bad_shard], (unsigned long long)first_bad);
+        return fail(QCX_HIP_ERROR);
+    }
+    // (3) back to the identity layout
+    if ((st = sh_identity(t)) != QCX_NO_ERROR || (st = sh_sync(t)) != QCX_NO_ERROR) return fail(st);
+    for (unsigned r = 0; r < t->W; r++) {
+        if (hipSetDevice(t->dev[r]) != hipSuccess ||
+            hipMemcpy(host.data(), t->buf[t->cur][r], per * sizeof(amp_t), hipMemcpyDeviceToHost) != hipSuccess) return fail(QCX_HIP_ERROR);
+        for (uint64_t j = 0; j < per; j++) {
+            double re, im;
+            expect(((uint64_t)r << nl) | j, &re, &im);
+            if (memcmp(&re, &host[2 * j], 8) || memcmp(&im, &host[2 * j + 1], 8)) { if (!bad++) { first_bad = j; bad_shard = r; } }
+        }
+    }
+    if (bad) {
+        set_error("sharded register self-check FAILED after restoring the identity layout: %llu amplitudes wrong (first: shard %u on device %d, local index %llu)",
+                  (unsigned long long)bad, bad_shard, t->dev[bad_shard], (unsigned long long)first_bad);
+        return fail(QCX_HIP_ERROR);
+    }
+    sh_free(t);
+    const_cast<ShardSet *>(big)->selfchecks++;
     return QCX_NO_ERROR;
 }

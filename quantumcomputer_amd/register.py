@@ -64,8 +64,8 @@ class Register:
 
     def __init__(self, L_size, M_size, shards=1, devices=None):
         """shards > 1: the register is sharded over that many GPUs by this process (qcx_register_create_sharded);
-        devices = HIP device of each shard (default shard r on device r; entries may repeat; [-1] = dry run: the
-        schedule only, see sharded_trace)"""
+        devices = HIP device of each shard (default: spread over the visible GPUs, see spread_devices; entries may
+        repeat; [-1] = dry run: the schedule only, see sharded_trace)"""
         h = C.c_void_p()
         if shards == 1 and devices is None:
             check(lib().qcx_register_create(int(L_size), int(M_size), C.byref(h)), "qcx_register_create")
@@ -140,6 +140,14 @@ class Register:
         e, p = C.c_ulong(0), C.c_ulong(0)
         check(lib().qcx_sharded_stats(self._h, C.byref(e), C.byref(p)), "qcx_sharded_stats")
         return e.value, p.value
+
+    def selfcheck(self):
+        """the pre-flight exchange check on demand (runs by itself at creation when the shards sit on several GPUs)"""
+        check(lib().qcx_sharded_selfcheck(self._h), "qcx_sharded_selfcheck")
+
+    @property
+    def selfchecks(self):
+        return int(lib().qcx_sharded_selfchecks(self._h))
 
     def set_relays(self, devices):
         """multi-path striping: GPUs without a shard relay a share of every trade ([] = off)"""

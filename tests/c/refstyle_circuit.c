@@ -59,7 +59,7 @@ int main(int argc, char **argv)
         return 0;
     }
     double *host = (double *)malloc(reg.num_states * 2 * sizeof(double));
-    if (qcx_state_read(reg.handle, 0, reg.num_states, host) != QCX_NO_ERROR) return 4;
+    if (qcx_state_read(qcx_compat_handle(&reg), 0, reg.num_states, host) != QCX_NO_ERROR) return 4;
     for (unsigned long i = 0; i < 2 * reg.num_states; i++) {
         uint64_t u; memcpy(&u, &host[i], 8);
         printf("%016" PRIx64 "\n", u);

@@ -1,7 +1,8 @@
 /*
  * The sharded register driven from plain C through include/qcx.h only: the same circuit (qcx_quantum_computation, i.e.
  * the schedule of qc_shor.c:712-737) and the same measurement stream on an unsharded register and on registers sharded
- * 2, 4 and 8 ways (all shards on device 0 here), with and without relay striping.  Amplitudes and measured indices must
+ * 2, 4 and 8 ways (spread over the visible GPUs: qcx_spread_devices; one GPU = all on device 0), with and without relay
+ * striping (relays = GPUs that hold no shard, or device 0 again when there is none).  Amplitudes and measured indices must
  * be identical, bit for bit.  Prints "ok" and exits 0, or says what differed.  tests/test_gpu_sharded_c.py runs it.
  */
 #include <stdio.h>
@@ -36,13 +37,21 @@ int main(int argc, char **argv)
     }
     CHECK(qcx_register_destroy(plain));
 
-    const int devs[16] = {0};
+    int visible = 0;
+    CHECK(qcx_device_count(&visible));
     for (unsigned shards = 2; shards <= 8; shards *= 2) {
         for (int relays = 0; relays <= 1; relays++) {
             qcx_register *reg = NULL;
-            CHECK(qcx_register_create_sharded(L, M, shards, devs, &reg));
+            int devs[16];
+            CHECK(qcx_spread_devices(shards, visible, devs));
+            CHECK(qcx_register_create_sharded(L, M, shards, relays ? devs : NULL, &reg));      /* NULL = the same spreading */
             if (qcx_register_shards(reg) != shards) { fprintf(stderr, "shards\n"); return 1; }
-            if (relays) { const int rd[2] = {0, 0}; CHECK(qcx_sharded_set_relays(reg, 2, rd)); }
+            if (relays) {                        /* two relays: the highest-numbered GPUs that hold no shard, else device 0 */
+                int rd[2] = {0, 0}, used = devs[shards - 1] + 1;
+                if (visible - used >= 1) rd[0] = visible - 1;
+                if (visible - used >= 2) rd[1] = visible - 2; else rd[1] = rd[0];
+                CHECK(qcx_sharded_set_relays(reg, 2, rd));
+            }
             CHECK(qcx_reset_register(reg));
             CHECK(qcx_quantum_computation(C, a, 0, reg));
             CHECK(qcx_state_read(reg, 0, dim, got));

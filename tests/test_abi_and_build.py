@@ -74,6 +74,27 @@ def test_compat_header_compiles_reference_style_circuit():
         assert r.returncode == 0, r.stderr
 
 
+def test_compat_header_compiles_a_main_shaped_like_the_reference():
+    """tests/c/refstyle_main.c: a main() with the reference's own declarations and call sequence (qc_shor.c:1284-1347:
+    gsl_rng_alloc(gsl_rng_mt19937), gsl_rng_set, gsl_vector_complex_alloc x 2, gsl_spmatrix_complex_alloc_nzmax,
+    current_state / new_state, the four frees) and no qcx_* call in it compiles warning-free against qcx_compat.h, as
+    do tests/c/refstyle_circuit.c and the operate_matrix / gsl_rng_uniform shims.  Without a GPU the program must fail
+    loudly at its first gate (abort with the library's message), not compute anything."""
+    import tempfile
+    lib = os.path.join(ROOT, "quantumcomputer_amd")
+    with tempfile.TemporaryDirectory() as d:
+        for name in ("refstyle_main.c", "refstyle_circuit.c"):
+            exe = os.path.join(d, name[:-2])
+            r = subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                                os.path.join(ROOT, "tests", "c", name), "-L", lib, "-lqcx", "-lm", "-Wl,-rpath," + lib, "-o", exe],
+                               capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+        import torch
+        if not torch.cuda.is_available():
+            r = subprocess.run([os.path.join(d, "refstyle_main"), "15", "3", "4", "7", "1"], capture_output=True, text=True)
+            assert r.returncode != 0 and "register allocation on the GPU failed" in r.stderr and r.stdout == ""
+
+
 def test_no_gpu_means_loud_failure_not_fallback(qc):
     import torch
     if torch.cuda.is_available():

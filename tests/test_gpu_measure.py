@@ -164,7 +164,7 @@ def test_total_probability_is_the_references_sequential_sum(qc, ob, n):
         assert reg.total_probability() == ob.norm2(want, n)
         assert abs(reg.norm2() - ob.norm2(want, n)) < 1e-13
     if n >= 13:
-        with qc.Register(n, 0, shards=4, devices=[0]) as reg:
+        with qc.Register(n, 0, shards=4, devices=qc.spread_devices(4)) as reg:
             reg.fill_random(n)
             for q in (0, n - 1):
                 qc.hadamard_gate(q, reg)

@@ -1,7 +1,9 @@
 """GPU: the C-ABI sharded register (qcx_register_create_sharded: ONE process, W shards, exchange by k_pack_push stores into
-the peers' buffers) with all shards placed on the one GPU of the box -- the code path of an 8-GPU node except that the
-peer stores stay on the device.  Everything is compared with the oracle bit for bit, through the ordinary entry points
-of include/qcx.h; the reference-style C program and the C host driver are run sharded through QCX_SHARDS / -g."""
+the peers' buffers).  The shards are SPREAD OVER THE VISIBLE GPUS (qc.spread_devices): on a one-GPU box they all land on
+device 0 -- the code path of an 8-GPU node except that the peer stores stay on the device -- and on a multi-GPU box the
+very same tests issue real peer stores over xGMI, cross-device event waits and relay forwarding, without an edit.
+Everything is compared with the oracle bit for bit, through the ordinary entry points of include/qcx.h; the
+reference-style C program and the C host driver are run sharded through QCX_SHARDS / -g."""
 import math
 import os
 import random
@@ -21,7 +23,7 @@ def bits(a):
 @pytest.mark.parametrize("shards,n", [(2, 10), (4, 12), (8, 16), (16, 20)])
 @pytest.mark.parametrize("fusion", [1, -1])
 def test_hadamard_sweeps(qc, ob, shards, n, fusion):
-    with qc.Register(n, 0, shards=shards, devices=[0]) as reg:
+    with qc.Register(n, 0, shards=shards, devices=qc.spread_devices(shards)) as reg:
         assert reg.shards == shards
         reg.set_fusion(fusion)
         reg.fill_random(5)
@@ -41,7 +43,7 @@ def test_shor_circuit_and_measurement(qc, ob, shards, C, L, M, a):
     if n - (shards.bit_length() - 1) - max(M, 6) < 2 * (shards.bit_length() - 1):
         pytest.skip("register too small for that many shards")
     rng, orng = qc.Rng(12345), ob.Rng(12345)
-    with qc.Register(L, M, shards=shards, devices=[0]) as reg:
+    with qc.Register(L, M, shards=shards, devices=qc.spread_devices(shards)) as reg:
         picks = []
         for shot in range(4):
             qc.reset_register(reg)
@@ -57,7 +59,7 @@ def test_shor_circuit_and_measurement(qc, ob, shards, C, L, M, a):
 
 def test_measurement_edges(qc, ob):
     n = 12
-    with qc.Register(n, 0, shards=4, devices=[0]) as reg:
+    with qc.Register(n, 0, shards=4, devices=qc.spread_devices(4)) as reg:
         for r in (0.0, 1e-300, 0.25, 0.5, 0.999999999, 1.0 - 2.0 ** -53):
             reg.fill_random(9)
             for q in (n - 1, 3, n - 2):
@@ -72,7 +74,7 @@ def test_measurement_edges(qc, ob):
 @pytest.mark.parametrize("shards,n,M", [(2, 9, 0), (4, 12, 3), (4, 13, 5), (8, 16, 4)])
 def test_random_programs(qc, ob, shards, n, M):
     rnd = random.Random(7 * shards + n)
-    with qc.Register(n - M, M, shards=shards, devices=[0]) as reg:
+    with qc.Register(n - M, M, shards=shards, devices=qc.spread_devices(shards)) as reg:
         for trial in range(6):
             reg.set_fusion(1 if trial % 2 == 0 else -1)
             reg.fill_random(trial)
@@ -96,7 +98,7 @@ def test_random_programs(qc, ob, shards, n, M):
 
 def test_state_io_and_timers(qc, ob, tmp_path):
     n = 12
-    with qc.Register(n, 0, shards=4, devices=[0]) as reg, qc.Register(n, 0) as plain:
+    with qc.Register(n, 0, shards=4, devices=qc.spread_devices(4)) as reg, qc.Register(n, 0) as plain:
         reg.fill_random(2)
         qc.hadamard_gate(n - 1, reg)                                            # leaves a swapped layout behind
         want = ob.fill_random(n, 2); ob.hadamard(want, n, n - 1)
@@ -121,7 +123,7 @@ def test_state_io_and_timers(qc, ob, tmp_path):
 def test_inverse_qft_entry_point(qc, ob):
     L, M = 9, 4
     n = L + M
-    with qc.Register(L, M, shards=4, devices=[0]) as reg:
+    with qc.Register(L, M, shards=4, devices=qc.spread_devices(4)) as reg:
         reg.fill_random(4)
         qc.inverse_QFT(reg)
         want = ob.fill_random(n, 4); ob.iqft(want, n, M)
@@ -138,7 +140,8 @@ def test_reference_style_c_program_sharded_by_environment(ob, tmp_path):
                     "-Wl,-rpath," + lib, "-o", out], check=True)
     C, L, M, a = 21, 9, 5, 2
     n = L + M
-    env = dict(os.environ, QCX_SHARDS="4", QCX_SHARD_DEVICES="0")
+    env = dict(os.environ, QCX_SHARDS="4")           # (no device list: the library spreads the shards over the visible GPUs)
+    env.pop("QCX_SHARD_DEVICES", None)
     r = subprocess.run([out, str(C), str(L), str(M), str(a), "12345"], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0, r.stderr
     lines = r.stdout.split()
@@ -159,7 +162,7 @@ def test_host_driver_sharded():
     for seed in ("1", "2", "3", "4", "5", "6"):
         args = [exe, "-C", "21", "-L", "9", "-M", "5", "-a", "2", "-s", seed, "-j"]
         single = subprocess.run(args, capture_output=True, text=True, timeout=120)
-        shard = subprocess.run(args + ["-g", "4", "-d", "0"], capture_output=True, text=True, timeout=120)
+        shard = subprocess.run(args + ["-g", "4"], capture_output=True, text=True, timeout=120)      # spread over the visible GPUs
         # same seed -> same measured states, same attempts, same verdict: only the JSON line's timing and shard fields differ
         assert single.returncode == shard.returncode and single.returncode in (0, 3), shard.stderr
         assert strip(single.stdout) == strip(shard.stdout)
@@ -173,10 +176,11 @@ def test_host_driver_sharded():
 
 @pytest.mark.parametrize("shards,n,relays", [(2, 14, 1), (2, 16, 6), (4, 16, 4), (8, 18, 2)])
 def test_multi_path_striping_gives_the_same_bits(qc, ob, shards, n, relays):
-    """relays (here: the same GPU again) carry a share of every chunk of every trade through staging buffers and a
+    """relays (GPUs without a shard; on a one-GPU box the same GPU again) carry a share of every chunk of every trade through staging buffers and a
     forwarding copy; the amplitudes must come out exactly as without them"""
-    with qc.Register(n, 0, shards=shards, devices=[0]) as reg:
-        reg.set_relays([0] * relays)
+    devs = qc.spread_devices(shards)
+    with qc.Register(n, 0, shards=shards, devices=devs) as reg:
+        reg.set_relays(qc.idle_devices(devs, relays))                          # idle GPUs first; on one GPU: device 0 again
         assert reg.relay_stats()[0] == relays
         reg.fill_random(8)
         want = ob.fill_random(n, 8)
@@ -201,7 +205,7 @@ def test_sliced_exchange_windows(qc, ob, monkeypatch, slices_log2, overlap):
     monkeypatch.setenv("QCX_SHARD_OVERLAP", str(overlap))
     n, M, shards = 18, 4, 4
     rnd = random.Random(31 + slices_log2)
-    with qc.Register(n - M, M, shards=shards, devices=[0]) as reg:
+    with qc.Register(n - M, M, shards=shards, devices=qc.spread_devices(shards)) as reg:
         sg, _ = reg.overlap_stats()
         assert sg == (slices_log2 if overlap else 0)         # slices only serve the windows
         for trial in range(3):
@@ -237,3 +241,25 @@ def test_sharded_register_from_plain_c(tmp_path):
                     "-Wl,-rpath," + lib, "-o", out], check=True)
     r = subprocess.run([out, "11", "5"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
+
+
+@pytest.mark.parametrize("shards,n", [(2, 12), (4, 20), (8, 30)])
+def test_exchange_selfcheck_passes_and_catches_a_wrong_trade(qc, monkeypatch, shards, n):
+    """the pre-flight check of qcx_register_create_sharded (runs by itself when the shards sit on several GPUs; forced
+    here so that a one-GPU box exercises it too): trade a small register there and back, compare every amplitude with
+    the generator bit for bit.  With a corrupted amplitude injected after the trade, creation must FAIL."""
+    n = min(n, 24)
+    monkeypatch.setenv("QCX_SHARD_SELFCHECK", "1")
+    with qc.Register(n, 0, shards=shards) as reg:                       # devices=None: the library's own spreading
+        assert reg.shards == shards and reg.selfchecks == 1
+        reg.selfcheck()
+        assert reg.selfchecks == 2
+        devs = qc.spread_devices(shards)
+        reg.set_relays(qc.idle_devices(devs, 2))                        # ... and once more through the relays
+        assert reg.selfchecks == 3
+    monkeypatch.setenv("QCX_SHARD_SELFCHECK_INJECT", "1")
+    with pytest.raises(qc.QcxError, match="self-check FAILED"):
+        qc.Register(n, 0, shards=shards)
+    monkeypatch.setenv("QCX_SHARD_SELFCHECK", "0")                     # skipped: creation succeeds again
+    with qc.Register(n, 0, shards=shards) as reg:
+        assert reg.selfchecks == 0

@@ -1,7 +1,11 @@
-"""GPU: the multi-PROCESS sharded path rehearsed on one GPU -- 2 and 4 ranks, each its own process with its own HIP
-context and libqcx, all on cuda:0, rendezvous over gloo (the exchange is staged through the host because gloo has no
-device all-to-all; under nccl/RCCL the same code sends device buffers).  Same scenarios as the CPU gloo suite
-(tests/test_sharded_gloo.py), this time with the HIP kernels doing the work."""
+"""GPU: the multi-PROCESS sharded path -- 2 and 4 ranks, each its own process with its own HIP context and libqcx.
+  * box with at least `world` GPUs: rank r on cuda:r, backend nccl (= RCCL over xGMI), device buffers straight into
+    all_to_all_single -- the production path of bench.py --gpus N, overlapped sliced exchange included;
+  * one-GPU box: all ranks on cuda:0, rendezvous over gloo, the exchange staged through the host (gloo has no device
+    all-to-all) -- a rehearsal of the same host logic.
+Which of the two ran is decided by torch.cuda.device_count() alone (QCX_TEST_BACKEND=gloo forces the rehearsal), so the
+first multi-GPU box that runs `pytest -m gpu` exercises RCCL with more than one rank without anyone editing a test.
+Same scenarios as the CPU gloo suite (tests/test_sharded_gloo.py), with the HIP kernels doing the work."""
 import os
 import sys
 
@@ -20,15 +24,22 @@ def _gpu_worker(rank, world, port, scenario, q):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    use_nccl = pick_backend(world, torch.cuda.device_count()) == "nccl"
+    dev = rank if use_nccl else 0
+    torch.cuda.set_device(dev)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if use_nccl:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle import binding as ob
         from quantumcomputer_amd.sharded import HipEngine, ShardedRegister
 
         def make(L, M, **kw):
             reg = ShardedRegister(L, M, **kw)
-            assert isinstance(reg.engine, HipEngine) and reg.shard.is_cuda and reg._host_staged
+            assert isinstance(reg.engine, HipEngine) and reg.shard.is_cuda and reg.shard.device.index == dev
+            assert reg._host_staged == (not use_nccl)
             return reg
         out = scenario(rank, world, ob, make)
         if rank == 0:
@@ -38,6 +49,13 @@ def _gpu_worker(rank, world, port, scenario, q):
         q.put(("err", f"rank {rank}: {e}\n{traceback.format_exc()}"))
     finally:
         dist.destroy_process_group()
+
+
+def pick_backend(world, visible_gpus):
+    """nccl with one GPU per rank when the box has them, else the one-GPU gloo rehearsal"""
+    if os.environ.get("QCX_TEST_BACKEND", "") == "gloo":
+        return "gloo"
+    return "nccl" if visible_gpus >= world else "gloo"
 
 
 def run_gpu(world, scenario):

@@ -1,7 +1,8 @@
 """GPU: the sharded register's sliced exchange (views, pack kernel, per-slice gate launches, measurement
-hand-off) on real HIP kernels with 2 and 4 VIRTUAL ranks: threads of one process sharing the one GPU of the
-test box, with torch.distributed replaced by an in-process stand-in that performs the same data movement
-(chunk c of rank r <-> chunk r of rank c).  RCCL itself is not involved -- that is the driver's 8-GPU run."""
+hand-off) on real HIP kernels with 2 and 4 VIRTUAL ranks: threads of one process (rank r on GPU r mod visible GPUs:
+all on the one GPU of a one-GPU box), with torch.distributed replaced by an in-process stand-in that performs the same
+data movement (chunk c of rank r <-> chunk r of rank c).  RCCL itself is not involved here -- with one GPU per rank
+tests/test_gpu_sharded_multiproc.py runs the same scenarios over nccl."""
 import threading
 
 import numpy as np
@@ -33,8 +34,12 @@ class FakeDist:
     def get_rank(self, group=None): return self.tls.rank
     def get_global_rank(self, group, r): return r
 
+    def _sync_all(self):
+        for d in range(self.torch.cuda.device_count()):          # ranks may sit on different GPUs (multi-GPU box)
+            self.torch.cuda.synchronize(d)
+
     def _exchange(self, payload):
-        self.torch.cuda.synchronize()
+        self._sync_all()
         self.slots[self.tls.rank] = payload
         self.barrier_obj.wait()
         got = list(self.slots)
@@ -47,13 +52,13 @@ class FakeDist:
         n = src.numel() // W
         for c in range(W):
             dst[c * n:(c + 1) * n].copy_(allsrc[c][r * n:(r + 1) * n])
-        self.torch.cuda.synchronize()
+        self._sync_all()
         self.barrier_obj.wait()                      # nobody overwrites a source that is still being read
         return _Work()
 
     def all_reduce(self, t, op=None, group=None):
         vals = self._exchange(t.clone())
-        t.copy_(sum(vals))
+        t.copy_(sum(v.to(t.device) for v in vals))
 
     def broadcast(self, t, src, group=None):
         vals = self._exchange(t.clone())
@@ -75,7 +80,7 @@ def run_virtual(world, body):
 
     def worker(rank):
         try:
-            torch.cuda.set_device(0)
+            torch.cuda.set_device(rank % torch.cuda.device_count())      # spread over the visible GPUs (one GPU: all on 0)
             fake.tls.rank = rank
             out[rank] = body(rank, sharded.ShardedRegister)
         except Exception as e:      # pragma: no cover

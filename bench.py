@@ -24,8 +24,15 @@ Extra objects on the JSON line:
                 workload: tier T3 = pairwise in place, OpenMP over the host cores (the headline `value`),
                 T2 = the reference's COO mat-vec alone, T1 = the literal reference algorithm.
   fused_sweep   (N = 1) the same 30 gate calls with qcx_set_fusion(1): passes, GB/s per pass, roofline fraction.
+  configs       (N = 1) the other BASELINE.json configurations that fit one GPU, driver-timed: config 2 (n=26 H sweep),
+                config 3 (n=28 qcx_inverse_QFT: fused passes = the default, one launch per gate, and -- when the build
+                has it -- the opt-in tolerance mode), config 5 on one GPU (n=30 qcx_quantum_computation(21, 2) +
+                measure_state).  Each with ms, passes, GB/s per pass, FP64-op/s and the fraction of each roof.
   config4       (N > 1) BASELINE config 4: H on every global qubit vs a local one at n = 29 + log2 N
                 (n = 32 on 8 GPUs), exchange GB/s per GPU.
+  c_host        (N > 1) the same sweep and the config-4 shape through the ONE-process C-ABI sharded register
+                (qcx_register_create_sharded: peer stores over xGMI, no RCCL), run by a fresh child process of rank 0
+                before rank 0 touches a GPU; the register checks its exchange bit for bit at creation.
 """
 import argparse
 import json
@@ -110,6 +117,26 @@ def load_traffic():
     return None, None
 
 
+def run_c_host(args):
+    """rank 0, before it touches a GPU: the C-host leg in a fresh child process; returns its JSON object"""
+    cmd = [sys.executable, os.path.abspath(__file__), "--c-host-child", "--gpus", str(args.gpus), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--n-local", str(args.n_local)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                           "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "QCX_FORCE_DEVICE")}
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           timeout=float(os.environ.get("QCX_BENCH_CHOST_TIMEOUT_S", "200")))
+    except subprocess.TimeoutExpired:
+        return {"error": "the C-host child timed out"}
+    for ln in reversed(r.stdout.decode(errors="replace").splitlines()):
+        if ln.startswith("{"):
+            try:
+                return json.loads(ln)
+            except ValueError:
+                break
+    return {"error": f"the C-host child failed (exit {r.returncode}): {r.stderr.decode(errors='replace')[-400:]}"}
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -178,7 +205,13 @@ def main():
     ap.add_argument("--no-config4", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path (ShardedRegister) even at world size 1")
     ap.add_argument("--cpu-n", type=int, default=0, help="register size of the CPU sample (0: 30 if the host has the memory, else 28)")
+    ap.add_argument("--no-configs", action="store_true", help="N = 1: skip the configs object (BASELINE configs 2, 3, 5)")
+    ap.add_argument("--no-c-host", action="store_true", help="N > 1: skip the one-process C-host leg")
+    ap.add_argument("--c-host-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.c_host_child:
+        return c_host_child(args)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
@@ -189,11 +222,15 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    # N > 1: the one-process C host over the same GPUs, in a fresh child process, before this rank initialises a GPU
+    # (the other ranks wait for rank 0 in the rendezvous meanwhile)
+    c_host = run_c_host(args) if (world > 1 and rank == 0 and not args.no_c_host) else None
+
     import torch
     import quantumcomputer_amd as qc
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("QCX_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))     # (override: test rigs only)
     args.gpus = world
     ndev = torch.cuda.device_count()
@@ -226,6 +263,7 @@ def main():
             if record_base is not None:
                 reg.event_record(record_base + n)
 
+        norm_before = reg.norm2()                        # (the synthetic fill is normalised only in expectation)
         for _ in range(args.warmup):
             sweep()
         reg.synchronize(); torch.cuda.synchronize()
@@ -261,6 +299,7 @@ def main():
             reg.set_fusion(False)
         reg.close()
         exchanges = 0
+        configs = None if (args.no_configs or args.n_local != 30) else single_gpu_configs(qc)
     else:
         import datetime
         import torch.distributed as dist
@@ -295,6 +334,8 @@ def main():
             for q in range(n):
                 reg.hadamard_gate(q)          # queued; executed on flush with look-ahead eviction
 
+        norm_before = reg.norm2()
+        configs = None
         for _ in range(args.warmup):
             sweep()
         reg.synchronize(); dist.barrier(); torch.cuda.synchronize()
@@ -393,11 +434,14 @@ def main():
                                             "not re-measured in this run") if traffic_src else None},
             "per_qubit_gbs": per_q_gbs,
             "fused_sweep": fused,
+            "configs": configs,
+            "total_probability_before": norm_before,
             "total_probability_after": norm,
         }
         if sharded:
             out["exchange_mode"] = exchange_mode
             out["config4"] = config4
+            out["c_host"] = c_host
         if not args.no_cpu_baseline and args.gpus == 1:
             cpu_n = args.cpu_n or (30 if mem_available_gib() >= 48 else 28)
             out["cpu_baseline"] = cpu_baseline(cpu_n)
@@ -410,6 +454,160 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+
+
+# ---- legs that run with a GPU in hand (called from main after its imports, or in the C-host child process) -----------
+FP64_VECTOR_PEAK = 39.3e12     # v_mul/v_add_f64: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (MI355X_MICROARCH.md); an FMA counts once
+
+
+def single_gpu_configs(qc, reps=3):
+    """BASELINE.json configs 2, 3 and 5 (one-GPU form) through the C ABI, timed with HIP events on the register's stream
+    (qcx_timer_start/stop); min over `reps`.  Algorithmic figures: a pass or a Hadamard moves 32 B per amplitude; a
+    controlled phase performs 6 FP64 operations on a quarter of the amplitudes, a Hadamard 4 per amplitude."""
+    out = {}
+
+    def timed(reg, fn):
+        best, passes = 1e30, 0
+        for _ in range(reps):
+            reg.synchronize()
+            p0 = reg.fusion_stats()[0]
+            reg.timer_start(); fn(); ms = reg.timer_stop()
+            if ms < best:
+                best, passes = ms, reg.fusion_stats()[0] - p0
+        return best, passes
+
+    def roofs(ms, passes, n, flops, launches_bytes=None):
+        d = {"ms": ms}
+        if passes:
+            gbs = passes * 32.0 * 2.0 ** n / (ms * 1e-3) / 1e9
+            d.update(hbm_passes=passes, hbm_gbs_per_pass=gbs, hbm_roof_frac=gbs / HBM_PEAK_GBS)
+        elif launches_bytes:
+            gbs = launches_bytes / (ms * 1e-3) / 1e9
+            d.update(algorithmic_gbs=gbs, hbm_roof_frac=gbs / HBM_PEAK_GBS)
+        if flops:
+            d.update(fp64_ops=flops, fp64_ops_per_s=flops / (ms * 1e-3), fp64_vector_roof_frac=flops / (ms * 1e-3) / FP64_VECTOR_PEAK)
+        return d
+
+    # config 2: n = 26 Hadamard sweep, one launch per gate
+    n = 26
+    with qc.Register(n, 0) as reg:
+        reg.fill_random(7)
+        sweep = lambda: [qc.hadamard_gate(q, reg) for q in range(n)]
+        sweep()
+        ms, _ = timed(reg, sweep)
+        c2 = roofs(ms, 0, n, 0, n * 32.0 * 2.0 ** n)
+        c2.update(workload="n=26 Hadamard sweep q=0..25, one launch per gate", gates=n, amplitude_updates_per_s=n * 2.0 ** n / (ms * 1e-3))
+        out["config2"] = c2
+
+    # config 3: n = 28 inverse_QFT schedule over all qubits (28 H + 378 controlled phases)
+    n = 28
+    nh, nph = n, n * (n - 1) // 2
+    flops = nph * 6.0 * 2.0 ** (n - 2) + nh * 4.0 * 2.0 ** n
+    alg_bytes = nh * 32.0 * 2.0 ** n + nph * 32.0 * 2.0 ** (n - 2)
+    c3 = {"workload": f"n=28 qcx_inverse_QFT: {nh} H + {nph} controlled phases (Q:678-690 with M = 0)", "gates": nh + nph}
+    modes = [("fused_default", 0), ("per_gate", -1)]
+    if hasattr(qc, "FUSION_TOLERANCE"):
+        modes.append(("tolerance_mode", qc.FUSION_TOLERANCE))
+    with qc.Register(n, 0) as reg:
+        for label, mode in modes:
+            reg.set_fusion(mode)
+            reg.fill_random(7)
+            qc.inverse_QFT(reg)
+            ms, passes = timed(reg, lambda: qc.inverse_QFT(reg))
+            d = roofs(ms, passes, n, flops if mode != getattr(qc, "FUSION_TOLERANCE", None) else 0, alg_bytes)
+            d["amplitude_updates_per_s"] = (nh + nph) * 2.0 ** n / (ms * 1e-3)
+            c3[label] = d
+        reg.set_fusion(0)
+    out["config3"] = c3
+
+    # config 5 on one GPU: n = 30 Shor N = 21, a = 2, L = 25, M = 5: 50 H + 25 modular multiplies + 300 phases, then measure
+    L, M, Cn, a = 25, 5, 21, 2
+    n = L + M
+    gates = 3 * L + L * (L - 1) // 2
+    c5 = {"workload": f"n=30 qcx_quantum_computation({Cn}, {a}) L={L} M={M}: {2 * L} H + {L} C_AMODC + {L * (L - 1) // 2} controlled phases, then measure_state",
+          "gates": gates}
+    rng = qc.Rng(12345)
+    with qc.Register(L, M) as reg:
+        def circuit():
+            qc.reset_register(reg); qc.quantum_computation(Cn, a, reg)
+        circuit()
+        ms, passes = timed(reg, circuit)                 # (reset included: a 16 GiB memset)
+        d = roofs(ms, passes, n, (L * (L - 1) // 2) * 6.0 * 2.0 ** (n - 2) + 2 * L * 4.0 * 2.0 ** n)
+        d["amplitude_updates_per_s"] = gates * 2.0 ** n / (ms * 1e-3)
+        c5["circuit_fused_default"] = d
+        c5["total_probability"] = reg.norm2()
+        t0 = time.perf_counter()
+        idx = qc.measure_state(reg, rng)
+        c5["measure_ms"] = (time.perf_counter() - t0) * 1e3
+        c5["measured_index"] = idx
+        c5["omega"] = qc.read_omega(idx, reg)
+        c5["nearest_multiple_of_one_sixth"] = min((abs(c5["omega"] - k / 6.0), k) for k in range(7))[1]
+    out["config5_one_gpu"] = c5
+    return out
+
+
+def c_host_child(args):
+    """(child process of rank 0, N > 1) the one-process C-ABI sharded register over the N GPUs: sweep + config-4 shape"""
+    import quantumcomputer_amd as qc
+    W = args.gpus
+    k = W.bit_length() - 1
+    n = args.n_local + k
+    out = {"host": "qcx_register_create_sharded: one process, peer stores over xGMI (k_pack_push), no RCCL", "shards": W}
+    try:
+        import ctypes as C
+        nd = C.c_int(0)
+        qc.lib().qcx_device_count(C.byref(nd))
+        out["visible_gpus"] = nd.value
+        out["devices"] = qc.spread_devices(W)
+        with qc.Register(n, 0, shards=W) as reg:            # devices=None: spread + pre-flight exchange check
+            out["selfchecks_passed"] = reg.selfchecks
+            out["exchange_checked_bit_for_bit"] = reg.selfchecks > 0
+            reg.set_fusion(-1)                               # one launch per gate per shard, like the headline
+            reg.fill_random(1)
+            sweep = lambda: [qc.hadamard_gate(q, reg) for q in range(n)]
+            for _ in range(args.warmup):
+                sweep()
+            reg.synchronize()
+            e0 = reg.sharded_stats()[0]
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                sweep()
+            reg.synchronize()
+            dt = time.perf_counter() - t0
+            out.update(n=n, ms_per_step=dt / args.steps * 1e3, value=args.steps * n * 2.0 ** n / dt, unit="amplitude-updates/s",
+                       exchanges_per_sweep=(reg.sharded_stats()[0] - e0) / args.steps,
+                       slices_log2=reg.overlap_stats()[0], total_probability_after=reg.norm2())
+            reg.set_fusion(1)
+            sweep(); reg.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                sweep()
+            reg.synchronize()
+            tf = time.perf_counter() - t0
+            out["fused_sweep"] = {"ms_per_step": tf / args.steps * 1e3, "value": args.steps * n * 2.0 ** n / tf}
+        nl4 = min(29, args.n_local)
+        with qc.Register(nl4 + k, 0, shards=W) as reg:
+            reg.set_fusion(-1)
+            res = {}
+
+            def timed(fn):
+                reg.synchronize(); t1 = time.perf_counter(); fn(); reg.synchronize()
+                return (time.perf_counter() - t1) * 1e3
+            reg.fill_random(1)
+            timed(lambda: qc.hadamard_gate(nl4 - 8, reg))
+            res["local_h_ms"] = timed(lambda: qc.hadamard_gate(nl4 - 8, reg))
+            for q in range(nl4 + k - 1, nl4 - 1, -1):
+                reg.fill_random(1)
+                res[f"global_h_q{q}_ms"] = timed(lambda q=q: qc.hadamard_gate(q, reg))
+            g = [v for kk, v in res.items() if kk.startswith("global")]
+            shard_bytes = 16.0 * 2.0 ** nl4
+            c4 = {"n": nl4 + k, "results_ms": res, "amplitude_updates_per_s_global_h": 2.0 ** (nl4 + k) / (sum(g) / len(g) * 1e-3)}
+            if min(g) > res["local_h_ms"]:
+                c4["exchange_GBps_per_gpu"] = shard_bytes * (W - 1) / W / ((min(g) - res["local_h_ms"]) * 1e-3) / 1e9
+            out["config4"] = c4
+    except Exception as e:      # reported, never fatal for the line
+        out["error"] = f"{type(e).__name__}: {e}"
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -689,6 +689,8 @@ struct FusePass {
     uint32_t xm_off, xm_cnt;    // LDS copy of the records' outside-tile masks: byte offset behind the lut, entries (0 = none)
     uint32_t has_cam, dbg;      // the pass holds modular multiplies (selects the kernel variant); dbg: diagnostics only (tools/probe_pass.py):
                                 // bit 0 skip the gates, bit 1 skip the stores, bit 2 skip the tile fill -- results are then wrong by design
+    uint32_t dg_cnt, dg_rec_off;// tolerance mode: merged diagonals of the pass (0 = none), record offset of their table area in ops
+    uint32_t dg_lds_off, dg_pad;// byte offset of their LDS area behind the lut
 };
 
 // One controlled modular multiply on an LDS-resident tile whose low M local bits are the M register.
@@ -1037,6 +1039,63 @@ __device__ __forceinline__ void fuse_round_item(Quad &q, const FuseOp *item, uin
         : [base] "s"(item), [p] "v"(p), [rsel] "s"(hdr), [hs] "s"(hs) : "vcc", "scc");
 }
 
+
+// a run of consecutive permutation-type modular multiplies (gcd(A, C) = 1, same C) folded into ONE
+// gather: inside a 2^M block all amplitudes share the L-register bits, so the run moves the amplitude
+// of value g from  f0 = (prod of the inverses whose control is set) * g  mod C.  The product is
+// walked through per-gate tables x -> x * inv_i mod C kept in LDS (camtab); pure data movement, the
+// same bits as applying the gates one by one.  Returns the number of gate records behind the header.
+template <int BLOCK, int TT>
+__device__ __forceinline__ unsigned fuse_camrun_step(amp_t *tile, unsigned short *lut, const unsigned char *camtab,
+                                                     const FuseOp *__restrict__ ops, unsigned i, uint64_t base)
+{
+    const unsigned cnt = ops[i].a & 0xffffu, cpad = ops[i].a >> 16;
+    const unsigned char *tabs = camtab + (unsigned)ops[i].mask;
+    const FuseOp *rec = ops + i + 1;
+    const unsigned M = rec[0].a & 0xffu, blkmask = (1u << M) - 1u;
+    const unsigned Cn = reinterpret_cast<const FuseCamExtra *>(&rec[0].c)->C;
+    // The factor depends on the index only through the control bits, i.e. through the 2^M-BLOCK an amplitude
+    // sits in (controls are L-register qubits, at or above M): it is walked once per block by the first
+    // 2^(T-M) threads and left in LDS (the scratch behind the tile), not once per amplitude by everybody.
+    unsigned char *xblk = reinterpret_cast<unsigned char *>(lut);
+    for (unsigned b = threadIdx.x; b < ((1u << TT) >> M); b += BLOCK) {
+        const unsigned e = b << M;
+        unsigned x = 1;
+        for (unsigned g = 0; g < cnt; g++) {
+            const uint64_t mext = rec[g].mask;
+            if ((base & mext) != mext) continue;                  // outside control is 0 for this tile
+            const int cl = (int)((rec[g].a >> 8) & 0xffu) - 1;
+            if (cl < 0 || ((e >> cl) & 1u)) x = tabs[g * cpad + x];
+        }
+        xblk[b] = (unsigned char)x;
+    }
+    __syncthreads();
+    const float rc = 1.0f / (float)Cn;
+    amp_t acc[4];
+    bool wr[4];
+#pragma unroll
+    for (unsigned k = 0; k < 4; k++) {
+        const unsigned e = k * BLOCK + threadIdx.x, f = e & blkmask;
+        const unsigned x = xblk[e >> M];
+        wr[k] = (x != 1u) && (f < Cn);
+        if (wr[k]) {
+            // (x * f) mod C for x, f < C <= 256: quotient estimate from the float reciprocal, off by at most one
+            const unsigned v = x * f;
+            unsigned q = (unsigned)((float)v * rc);
+            int rem = (int)v - (int)(q * Cn);
+            if (rem < 0) rem += (int)Cn; else if (rem >= (int)Cn) rem -= (int)Cn;
+            const amp_t sv = tile[(e - f) + (unsigned)rem];
+            acc[k].x = 0.0 + sv.x; acc[k].y = 0.0 + sv.y;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (unsigned k = 0; k < 4; k++)
+        if (wr[k]) tile[k * BLOCK + threadIdx.x] = acc[k];
+    __syncthreads();
+    return cnt;
+}
+
 template <int BLOCK, int TT, bool CAM = true>     // CAM = false: the pass holds no modular multiply (smaller kernel)
 __device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, unsigned short *lut, const unsigned char *camtab,
                                                   const uint64_t *xm, const FusePass &P, const FuseOp *__restrict__ ops,
@@ -1087,57 +1146,134 @@ __device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, unsigned short *l
             __syncthreads();
             i += 1 + cnt;
         } else if (CAM && type == FUSE_CAMRUN) {
-            // a run of consecutive permutation-type modular multiplies (gcd(A, C) = 1, same C) folded into ONE
-            // gather: inside a 2^M block all amplitudes share the L-register bits, so the run moves the amplitude
-            // of value g from  f0 = (prod of the inverses whose control is set) * g  mod C.  The product is
-            // walked through per-gate tables x -> x * inv_i mod C kept in LDS (camtab); pure data movement, the
-            // same bits as applying the gates one by one.
-            const unsigned cnt = ops[i].a & 0xffffu, cpad = ops[i].a >> 16;
-            const unsigned char *tabs = camtab + (unsigned)ops[i].mask;
-            const FuseOp *rec = ops + i + 1;
-            const unsigned M = rec[0].a & 0xffu, blkmask = (1u << M) - 1u;
-            const unsigned Cn = reinterpret_cast<const FuseCamExtra *>(&rec[0].c)->C;
-            // The factor depends on the index only through the control bits, i.e. through the 2^M-BLOCK an amplitude
-            // sits in (controls are L-register qubits, at or above M): it is walked once per block by the first
-            // 2^(T-M) threads and left in LDS (the scratch behind the tile), not once per amplitude by everybody.
-            unsigned char *xblk = reinterpret_cast<unsigned char *>(lut);
-            for (unsigned b = threadIdx.x; b < ((1u << TT) >> M); b += BLOCK) {
-                const unsigned e = b << M;
-                unsigned x = 1;
-                for (unsigned g = 0; g < cnt; g++) {
-                    const uint64_t mext = rec[g].mask;
-                    if ((base & mext) != mext) continue;                  // outside control is 0 for this tile
-                    const int cl = (int)((rec[g].a >> 8) & 0xffu) - 1;
-                    if (cl < 0 || ((e >> cl) & 1u)) x = tabs[g * cpad + x];
+            i += 1 + fuse_camrun_step<BLOCK, TT>(tile, lut, camtab, ops, i, base);
+        } else if (CAM) {    // FUSE_CAMODC between rounds
+            fuse_camodc_step<BLOCK, 4>(tile, lut, ops + i, base, 1u << TT);
+            i++;
+        } else {
+            __builtin_unreachable();
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// K6t  TOLERANCE MODE of the rounds form (qcx_set_fusion(reg, 2); opt-in, NOT bit-exact: amplitudes agree with the
+// reference to ~1e-15, north_star allows 1e-10).  The planner merges every run of consecutive controlled phases that
+// share a control qubit l into ONE diagonal (Q:682-689 applies l - M of them after each Hadamard):
+//     amp[i] *= prod over the targets k with bit k of i set of (c_k + i s_k),     for every i with bit l set.
+// The product splits over where the target bits live:
+//     E_out(tile)        targets outside the tile: a per-tile constant.  One thread per diagonal builds it at tile start
+//                        (while the LDS-DMA fill is in flight) from <= 5 tables of 256 entries indexed by the bytes of the
+//                        tile's base index (global memory, L2-resident), and leaves it in LDS;
+//     G0 G1 G2 (thread)  targets on tile-local bits, 4 local bits per table, 16 entries each, in LDS (768 B per diagonal);
+//                        the entry for a single set bit is that bit's own factor, so the factors of the round's two
+//                        register bits are read from the same tables.
+// A thread then multiplies the (at most four) amplitudes whose control bit is set by F, F w0, F w1, F w0 w1: one complex
+// multiply per amplitude instead of one rotation per gate per amplitude, FMA allowed.  Plain phases that could not be
+// merged, Hadamards and the modular multiplies run as in the exact form (without the canonical-zero bookkeeping: the
+// sign of a zero is below any tolerance).
+// Records: FUSE_DIAG  a = (tile-local control bit + 1, 0 = outside/none) | slot << 8 | groups with targets << 16,
+//                     mask = outside control bit, c = (bit pattern) tile-local target mask.
+// ---------------------------------------------------------------------------
+enum : uint32_t { FUSE_DIAG = 6 };
+struct DiagInfo { uint32_t field_off[5]; uint32_t present; uint32_t pad[2]; };      // 32 B; offsets in 16-B units from the table area
+
+__device__ __forceinline__ void cmul_tol(amp_t &v, const amp_t w)        // v *= w, 2 mul + 2 fma
+{
+    const double nx = __builtin_fma(w.x, v.x, -(w.y * v.y));
+    const double ny = __builtin_fma(w.x, v.y, w.y * v.x);
+    v.x = nx; v.y = ny;
+}
+__device__ __forceinline__ void h_butterfly_tol(amp_t &a, amp_t &b)
+{
+    const double s = QCX_SQRT1_2;
+    const double t0r = s * a.x, t0i = s * a.y, t1r = s * b.x, t1i = s * b.y;
+    a.x = t0r + t1r;  a.y = t0i + t1i;
+    b.x = t0r - t1r;  b.y = t0i - t1i;
+}
+
+template <int BLOCK, int TT, bool CAM>
+__device__ __forceinline__ void fuse_apply_rounds_tol(amp_t *tile, unsigned short *lut, const unsigned char *camtab,
+                                                      const amp_t *dg, const FusePass &P, const FuseOp *__restrict__ ops, uint64_t base)
+{
+    static_assert((1u << TT) == 4u * BLOCK, "rounds form needs 4 amplitudes per thread");
+    const amp_t *gtab = dg + P.dg_cnt;                          // behind the per-tile E_out slots
+    unsigned i = 0;
+    while (i < P.nops) {
+        const uint32_t type = ops[i].type & 0xffu;
+        if (type == FUSE_ROUND) {
+            const unsigned rb0 = ops[i].a & 0xffu, rb1 = (ops[i].a >> 8) & 0xffu;
+            const unsigned cnt = (unsigned)ops[i].mask;
+            const unsigned p = (unsigned)insert_zero(insert_zero(threadIdx.x, rb0), rb1);
+            const unsigned e1 = p | (1u << rb0), e2 = p | (1u << rb1), e3 = e1 | (1u << rb1);
+            amp_t v0 = tile[p], v1 = tile[e1], v2 = tile[e2], v3 = tile[e3];
+            unsigned o = i + 1;
+            const unsigned oend = i + cnt;
+            while (o <= oend) {
+                const uint32_t t = ops[o].type;
+                const uint32_t kind = t & 0xffu;
+                if (kind == FUSE_H) {
+                    if ((t >> 8) & 1u) { h_butterfly_tol(v0, v2); h_butterfly_tol(v1, v3); }
+                    else               { h_butterfly_tol(v0, v1); h_butterfly_tol(v2, v3); }
+                    o++;
+                } else if (kind == FUSE_PRUN) {
+                    const unsigned rc = t >> 16;
+                    for (unsigned g = 1; g <= rc; g++) {
+                        const uint64_t mext = ops[o + g].mask;
+                        if ((base & mext) != mext) continue;
+                        const uint32_t rsel = (ops[o + g].type >> 8) & 15u, mloc = ops[o + g].a;
+                        amp_t w; w.x = ops[o + g].c; w.y = ops[o + g].s;
+                        if ((p & mloc) == mloc) {
+                            if (rsel & 1u) cmul_tol(v0, w);
+                            if (rsel & 2u) cmul_tol(v1, w);
+                            if (rsel & 4u) cmul_tol(v2, w);
+                            if (rsel & 8u) cmul_tol(v3, w);
+                        }
+                    }
+                    o += 1 + rc;
+                } else {                                            // FUSE_DIAG
+                    const uint64_t mext = ops[o].mask;
+                    if ((base & mext) == mext) {
+                        const uint32_t a = ops[o].a;
+                        const int cl = (int)(a & 0xffu) - 1;
+                        const unsigned slot = (a >> 8) & 0xffu, groups = (a >> 16) & 7u;
+                        const uint64_t tloc = (uint64_t)__double_as_longlong(ops[o].c);
+                        const amp_t *G = gtab + slot * 48u;
+                        amp_t F = dg[slot];                                     // E_out of this tile
+                        if (groups & 1u) cmul_tol(F, G[p & 15u]);
+                        if (groups & 2u) cmul_tol(F, G[16u + ((p >> 4) & 15u)]);
+                        if (groups & 4u) cmul_tol(F, G[32u + (p >> 8)]);
+                        const bool t0 = (tloc >> rb0) & 1u, t1 = (tloc >> rb1) & 1u;
+                        amp_t w0, w1;                                           // uniform LDS reads (only where needed)
+                        if (t0) w0 = G[16u * (rb0 >> 2) + (1u << (rb0 & 3u))];
+                        if (t1) w1 = G[16u * (rb1 >> 2) + (1u << (rb1 & 3u))];
+                        if (cl == (int)rb1) {                                   // the usual case: the H just before was on rb1
+                            amp_t F3 = F;
+                            if (t0) cmul_tol(F3, w0);
+                            cmul_tol(v2, F); cmul_tol(v3, F3);
+                        } else if (cl == (int)rb0) {
+                            amp_t F3 = F;
+                            if (t1) cmul_tol(F3, w1);
+                            cmul_tol(v1, F); cmul_tol(v3, F3);
+                        } else if (cl < 0 || ((p >> cl) & 1u)) {
+                            amp_t F1 = F, F2 = F;
+                            if (t0) cmul_tol(F1, w0);
+                            if (t1) cmul_tol(F2, w1);
+                            amp_t F3 = F1;
+                            if (t1) cmul_tol(F3, w1);
+                            cmul_tol(v0, F); cmul_tol(v1, F1); cmul_tol(v2, F2); cmul_tol(v3, F3);
+                        }
+                    }
+                    o++;
                 }
-                xblk[b] = (unsigned char)x;
             }
-            __syncthreads();
-            const float rc = 1.0f / (float)Cn;
-            amp_t acc[4];
-            bool wr[4];
-#pragma unroll
-            for (unsigned k = 0; k < 4; k++) {
-                const unsigned e = k * BLOCK + threadIdx.x, f = e & blkmask;
-                const unsigned x = xblk[e >> M];
-                wr[k] = (x != 1u) && (f < Cn);
-                if (wr[k]) {
-                    // (x * f) mod C for x, f < C <= 256: quotient estimate from the float reciprocal, off by at most one
-                    const unsigned v = x * f;
-                    unsigned q = (unsigned)((float)v * rc);
-                    int rem = (int)v - (int)(q * Cn);
-                    if (rem < 0) rem += (int)Cn; else if (rem >= (int)Cn) rem -= (int)Cn;
-                    const amp_t sv = tile[(e - f) + (unsigned)rem];
-                    acc[k].x = 0.0 + sv.x; acc[k].y = 0.0 + sv.y;
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (unsigned k = 0; k < 4; k++)
-                if (wr[k]) tile[k * BLOCK + threadIdx.x] = acc[k];
+            tile[p] = v0; tile[e1] = v1; tile[e2] = v2; tile[e3] = v3;
             __syncthreads();
             i += 1 + cnt;
-        } else if (CAM) {    // FUSE_CAMODC between rounds
+        } else if (CAM && type == FUSE_CAMRUN) {
+            i += 1 + fuse_camrun_step<BLOCK, TT>(tile, lut, camtab, ops, i, base);
+        } else if (CAM) {
             fuse_camodc_step<BLOCK, 4>(tile, lut, ops + i, base, 1u << TT);
             i++;
         } else {
@@ -1227,7 +1363,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void
 // store phases of the resident workgroups overlap each other; measured, that beats the double-buffered pipeline
 // inside one workgroup (the round-1 pipelined form, removed) as soon as enough workgroups are resident, so this kernel carries nothing but
 // the rounds interpreter and is held to OCC waves per SIMD.
-template <int BLOCK, int TT, int OCC, bool CAM>
+template <int BLOCK, int TT, int OCC, bool CAM, bool TOL = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) void k_fused_rounds(
     amp_t *__restrict__ amp, unsigned n, FusePass P, const FuseOp *__restrict__ ops, uint64_t ntiles, const FuseOp *ops_asm)
 {
@@ -1241,6 +1377,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
         camtab[b] = reinterpret_cast<const unsigned char *>(ops + P.cam_ctl_local[2])[b];
     uint64_t *xm = reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(lut) + P.xm_off);
     for (unsigned b = threadIdx.x; b < P.xm_cnt + 66u; b += BLOCK) xm[b] = b < P.xm_cnt ? ops[b].mask : 0;    // + padding
+    // tolerance mode: [E_out slot per diagonal][G tables, 48 entries per diagonal] in LDS; the tables are staged once
+    amp_t *dg = reinterpret_cast<amp_t *>(reinterpret_cast<unsigned char *>(lut) + P.dg_lds_off);
+    const amp_t *dg_area = reinterpret_cast<const amp_t *>(ops + P.dg_rec_off);             // global: DiagInfo[], G tables, field tables
+    if constexpr (TOL)
+        for (unsigned b = threadIdx.x; b < P.dg_cnt * 48u; b += BLOCK) dg[P.dg_cnt + b] = dg_area[2u * P.dg_cnt + b];
     __syncthreads();
     const unsigned c = P.c, nh = P.nh;
     const unsigned lowmask = (1u << c) - 1u;
@@ -1264,8 +1405,23 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + off_k[k]),
                                                  (__attribute__((address_space(3))) void *)(tile + k * BLOCK + wbase), 16, 0, 2);
         }
+        if constexpr (TOL) {
+            // E_out of this tile for every diagonal of the pass: one thread each, while the tile fill is in flight
+            if (threadIdx.x < P.dg_cnt) {
+                const DiagInfo *info = reinterpret_cast<const DiagInfo *>(dg_area) + threadIdx.x;
+                const uint32_t present = info->present;
+                amp_t E; E.x = 1.0; E.y = 0.0;
+#pragma unroll
+                for (unsigned f = 0; f < 5; f++)
+                    if ((present >> f) & 1u) cmul_tol(E, dg_area[info->field_off[f] + (unsigned)((base >> (8u * f)) & 255u)]);
+                dg[threadIdx.x] = E;
+            }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if constexpr (TOL) {
+            if (!(P.dbg & 1u)) fuse_apply_rounds_tol<BLOCK, TT, CAM>(tile, lut, camtab, dg, P, ops, base);
+        } else
         if (!(P.dbg & 1u)) fuse_apply_rounds<BLOCK, TT, CAM>(tile, lut, camtab, xm, P, ops, ops_asm, base);
         amp_t v[4];
 #pragma unroll

@@ -57,6 +57,12 @@ def test_two_ranks_on_one_gpu_print_one_json_line():
     c4 = out["config4"]
     assert c4["n"] == 21 and "global_h_q20_ms" in c4["results_ms"] and c4["results_ms"]["local_h_ms"] > 0
     assert out["roofline"]["frac"] > 0 and out["roofline"]["traffic"] is None      # PMC traffic exists for n_local = 30 only
+    assert abs(out["total_probability_before"] - out["total_probability_after"]) < 1e-12     # conservation, shown on the line
+    ch = out["c_host"]                                      # the one-process C host over the same GPUs, from a child of rank 0
+    assert "error" not in ch, ch
+    assert ch["shards"] == 2 and ch["n"] == 21 and ch["value"] > 0 and ch["exchanges_per_sweep"] >= 1
+    assert ch["devices"] == [0, 0] or ch["exchange_checked_bit_for_bit"]         # several GPUs: the pre-flight check must have run
+    assert "global_h_q20_ms" in ch["config4"]["results_ms"]
 
 
 @pytest.mark.gpu

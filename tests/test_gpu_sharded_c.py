@@ -243,7 +243,7 @@ def test_sharded_register_from_plain_c(tmp_path):
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
 
 
-@pytest.mark.parametrize("shards,n", [(2, 12), (4, 20), (8, 30)])
+@pytest.mark.parametrize("shards,n", [(2, 12), (2, 16), (4, 20), (8, 30)])
 def test_exchange_selfcheck_passes_and_catches_a_wrong_trade(qc, monkeypatch, shards, n):
     """the pre-flight check of qcx_register_create_sharded (runs by itself when the shards sit on several GPUs; forced
     here so that a one-GPU box exercises it too): trade a small register there and back, compare every amplitude with
@@ -256,7 +256,7 @@ def test_exchange_selfcheck_passes_and_catches_a_wrong_trade(qc, monkeypatch, sh
         assert reg.selfchecks == 2
         devs = qc.spread_devices(shards)
         reg.set_relays(qc.idle_devices(devs, 2))                        # ... and once more through the relays
-        assert reg.selfchecks == 3
+        assert reg.selfchecks == (3 if reg.relay_stats()[0] == 2 else 2)    # (registers too small to stripe set up no relays)
     monkeypatch.setenv("QCX_SHARD_SELFCHECK_INJECT", "1")
     with pytest.raises(qc.QcxError, match="self-check FAILED"):
         qc.Register(n, 0, shards=shards)

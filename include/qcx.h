@@ -119,12 +119,18 @@ unsigned qcx_ref_int_pow(double base, double power);
 
 /* ---- gate fusion (no reference counterpart) ------------
  * Queued gates are executed as fused passes (one HBM round trip applies many gates to LDS-resident
- * tiles); results are bit-identical to the per-gate kernels.  Every call that observes the state
+ * tiles); in modes -1, 0 and 1 results are bit-identical to the per-gate kernels.  Every call that observes the state
  * flushes the queue; qcx_flush does so explicitly.
  *   enable =  0 (default): a gate call launches its own kernel; the whole-circuit entry points
  *                (qcx_inverse_QFT, qcx_quantum_computation) hand their complete gate list to the pass scheduler
  *   enable =  1: every gate call is queued
- *   enable = -1: strictly one kernel launch per gate, inside the whole-circuit entry points too */
+ *   enable = -1: strictly one kernel launch per gate, inside the whole-circuit entry points too
+ *   enable =  2: TOLERANCE MODE, opt-in, NOT bit-exact: like 1, and every run of consecutive controlled phases that
+ *                share a qubit (Q:682-689: all phases after H(l) share l) is merged into one diagonal -- one complex
+ *                multiply per amplitude by the product of the factors of its set target bits, FMA allowed.  Amplitudes
+ *                differ from the bit-exact modes by rounding only: |delta| <= 1e-14 * |amplitude| per merged diagonal
+ *                (tests bound the whole n <= 16 circuits at 1e-12; north_star asks 1e-10); zero signs are not
+ *                canonicalised.  Unsharded registers only (a sharded register treats 2 as 1). */
 int  qcx_set_fusion(qcx_register *reg, int enable);
 int  qcx_flush(qcx_register *reg);
 int  qcx_fusion_stats(qcx_register *reg, unsigned long *passes_launched, unsigned long *gates_fused);
@@ -219,10 +225,15 @@ typedef struct {
     size_t   rec_off, rec_cnt;      /* this pass's records (tables included) inside `records` */
     unsigned nops;                  /* records the kernel walks (the rest, if any, are tables) */
     unsigned table_bytes, table_rec_off;    /* folded modular-multiply tables: size, and offset in records from rec_off */
+    unsigned diag_cnt, diag_rec_off;        /* tolerance mode: merged diagonals of the pass, record offset of their table area */
 } qcx_plan_action;
 int  qcx_fusion_plan(unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates,
                      qcx_plan_action *actions, unsigned max_actions, unsigned *n_actions,
                      qcx_fuse_record *records, size_t max_records, size_t *n_records);
+/* the same for a fusion mode: 1 = the bit-exact plan (what qcx_fusion_plan returns), 2 = the tolerance mode's plan */
+int  qcx_fusion_plan_mode(int mode, unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates,
+                          qcx_plan_action *actions, unsigned max_actions, unsigned *n_actions,
+                          qcx_fuse_record *records, size_t max_records, size_t *n_records);
 /* sequential cumulative scan of |amp|^2 over this shard continuing from cum_in
  * (global index of local 0 = first_global; indices >= last_excluded are not
  * examined, Q:283).  Synchronous. */

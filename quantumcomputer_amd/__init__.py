@@ -9,6 +9,8 @@ from .register import (Register, Rng, load_state_file, c_amodc_gate, c_phase_shi
                        inverse_QFT, measure_state, quantum_computation, read_omega,
                        reset_register, swap_states)
 
-__all__ = ["Register", "Rng", "reset_register", "hadamard_gate", "c_phase_shift_gate", "c_amodc_gate",
+FUSION_TOLERANCE = 2      # qcx_set_fusion(reg, 2): the opt-in tolerance mode (include/qcx.h)
+
+__all__ = ["FUSION_TOLERANCE", "Register", "Rng", "reset_register", "hadamard_gate", "c_phase_shift_gate", "c_amodc_gate",
            "swap_states", "inverse_QFT", "quantum_computation", "measure_state", "read_omega",
            "display_state", "check_normalisation", "lib", "tune", "polar", "QcxError", "LIB_PATH", "spread_devices", "idle_devices"]

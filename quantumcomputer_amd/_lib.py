@@ -88,6 +88,7 @@ SIGNATURES = {
     "qcx_state_save": (_i, [_p, C.c_char_p]),
     "qcx_state_load": (_i, [_p, C.c_char_p]),
     "qcx_fusion_plan": (_i, [_u, _u, _u, _p, _p, _u, C.POINTER(_u), _p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "qcx_fusion_plan_mode": (_i, [_i, _u, _u, _u, _p, _p, _u, C.POINTER(_u), _p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "qcx_shard_measure_scan": (_i, [_p, _u, _u64, _u64, _d, _d, C.POINTER(_i), C.POINTER(_u64), C.POINTER(_d), _p]),
     "qcx_shard_collapse": (_i, [_p, _u, _i64, _p]),
 }
@@ -119,12 +120,13 @@ class PlanAction(C.Structure):
     _fields_ = [("fused", C.c_int), ("first_gate", C.c_uint), ("ngates", C.c_uint), ("T", C.c_uint), ("c", C.c_uint),
                 ("nh", C.c_uint), ("hbit", C.c_ubyte * 16), ("nopipe", C.c_uint), ("rounds_form", C.c_uint),
                 ("rec_off", C.c_size_t), ("rec_cnt", C.c_size_t), ("nops", C.c_uint), ("table_bytes", C.c_uint),
-                ("table_rec_off", C.c_uint)]
+                ("table_rec_off", C.c_uint), ("diag_cnt", C.c_uint), ("diag_rec_off", C.c_uint)]
 
 
-def fusion_plan(n_local, M, descs):
+def fusion_plan(n_local, M, descs, mode=1):
     """The pass planner alone (host code, no GPU needed).  descs: (type, q, mask, c, s, C, A) tuples as for
-    qcx_shard_run_fused.  Returns (actions, records): a list of PlanAction and a ctypes array of FuseRecord."""
+    qcx_shard_run_fused.  Returns (actions, records): a list of PlanAction and a ctypes array of FuseRecord.
+    mode 1: the bit-exact plan; 2: the tolerance mode's plan (merged diagonals)."""
     arr = (GateDesc * max(len(descs), 1))()
     for i, d in enumerate(descs):
         arr[i].type, arr[i].q, arr[i].mask, arr[i].c, arr[i].s, arr[i].C, arr[i].A = d
@@ -133,12 +135,12 @@ def fusion_plan(n_local, M, descs):
     while True:
         acts = (PlanAction * cap_a)()
         recs = (FuseRecord * cap_r)()
-        st = lib().qcx_fusion_plan(n_local, M, len(descs), C.cast(arr, C.c_void_p), C.cast(acts, C.c_void_p), cap_a, C.byref(na),
+        st = lib().qcx_fusion_plan_mode(mode, n_local, M, len(descs), C.cast(arr, C.c_void_p), C.cast(acts, C.c_void_p), cap_a, C.byref(na),
                                    C.cast(recs, C.c_void_p), cap_r, C.byref(nr))
         if st == 1 and (na.value > cap_a or nr.value > cap_r):        # QCX_INSUFFICIENT_MEMORY: grow and retry
             cap_a, cap_r = max(cap_a, na.value), max(cap_r, nr.value)
             continue
-        check(st, "qcx_fusion_plan")
+        check(st, "qcx_fusion_plan_mode")
         return [acts[k] for k in range(na.value)], recs, nr.value
 
 

@@ -99,6 +99,7 @@ struct Tune {
     long fuse_T      = 11;     // fused passes: tile = 2^T amplitudes in LDS (8..12)
     long fuse_c      = 4;      // fused passes: contiguous low bits of a tile (runs of 16 * 2^c bytes)
     long fuse_grid_cap = 24576; // workgroups of the one-tile-per-workgroup form (each walks several tiles: the table fill at kernel start is amortised)
+    long fuse_tol_occ = 6;     // tolerance-mode passes (merged diagonals): waves per SIMD the kernel is built for (6 or 8)
     long fuse_rounds_occ = 8;  // rounds-form passes: k_fused_rounds built for this many waves per SIMD (6, 7, 8; 0 = the general kernel)
     long fuse_T_phase = 10;    // tile bits of phase-dominated passes (one tile per workgroup, not pipelined); 0 = same as the rest
     long fuse_c_phase = 4;
@@ -122,7 +123,7 @@ static Tune tune_now() { std::lock_guard<std::mutex> lock(g_tune_mutex); return 
 extern "C" int qcx_tune_set(const char *key, long value)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); g_tune.name = value; return QCX_NO_ERROR; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ)
 #undef K
     return QCX_BAD_ARGUMENTS;
 }
@@ -130,7 +131,7 @@ extern "C" int qcx_tune_set(const char *key, long value)
 extern "C" long qcx_tune_get(const char *key)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); return g_tune.name; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ)
 #undef K
     return -1;
 }
@@ -992,9 +993,20 @@ extern "C" int qcx_shard_run_fused(void *amp, unsigned n_local, unsigned M, unsi
 // The planner alone, on the host (no GPU needed): which passes / stand-alone gates a gate list becomes and the
 // records the pass kernels would interpret.  actions[k] describes action k; records receives the raw 32-byte
 // records of all passes back to back (action.rec_off / rec_cnt index into it, in records).
+extern "C" int qcx_fusion_plan_mode(int mode, unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates,
+                                    qcx_plan_action *actions, unsigned max_actions, unsigned *n_actions,
+                                    qcx_fuse_record *records, size_t max_records, size_t *n_records);
+
 extern "C" int qcx_fusion_plan(unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates,
                                qcx_plan_action *actions, unsigned max_actions, unsigned *n_actions,
                                qcx_fuse_record *records, size_t max_records, size_t *n_records)
+{
+    return qcx_fusion_plan_mode(1, n_local, M, count, gates, actions, max_actions, n_actions, records, max_records, n_records);
+}
+
+extern "C" int qcx_fusion_plan_mode(int mode, unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates,
+                                    qcx_plan_action *actions, unsigned max_actions, unsigned *n_actions,
+                                    qcx_fuse_record *records, size_t max_records, size_t *n_records)
 {
     if (n_local == 0 || n_local > 40 || M > n_local || (count && !gates) || !n_actions || !n_records) return QCX_BAD_ARGUMENTS;
     if (M > 12) return QCX_UNSUPPORTED;
@@ -1006,7 +1018,7 @@ extern "C" int qcx_fusion_plan(unsigned n_local, unsigned M, unsigned count, con
     QCX_TRY(descs_to_gates(n_local, M, count, gates, q));
     std::vector<FuseAction> acts;
     std::vector<FuseOp> ops;
-    fuse_plan(&tmp, tune_now(), q, acts, ops);
+    fuse_plan(&tmp, tune_now(), q, acts, ops, mode == 2);
     *n_actions = (unsigned)acts.size();
     *n_records = ops.size();
     if (acts.size() > max_actions || ops.size() > max_records || (!actions && !acts.empty()) || (!records && !ops.empty()))
@@ -1023,6 +1035,7 @@ extern "C" int qcx_fusion_plan(unsigned n_local, unsigned M, unsigned count, con
         o.rounds_form = (unsigned)a.P.cam_ctl_local[0];
         o.rec_off = a.op_off; o.rec_cnt = a.op_cnt; o.nops = a.P.nops;
         o.table_bytes = (unsigned)a.P.cam_ctl_local[1]; o.table_rec_off = (unsigned)a.P.cam_ctl_local[2];
+        o.diag_cnt = a.P.dg_cnt; o.diag_rec_off = a.P.dg_rec_off;
     }
     if (!ops.empty()) memcpy(records, ops.data(), ops.size() * sizeof(FuseOp));
     return QCX_NO_ERROR;
@@ -1035,7 +1048,7 @@ extern "C" int qcx_set_fusion(qcx_register *r, int enable)
     if (!r) return QCX_BAD_ARGUMENTS;
     if (r->sh) { QCX_TRY(sh_flush(r->sh)); r->sh->fusion = enable >= 0 ? 1 : -1; return QCX_NO_ERROR; }   // (gates are always queued; -1 = one launch per gate)
     FLUSH(r);
-    r->fusion = enable > 0 ? 1 : (enable < 0 ? -1 : 0);
+    r->fusion = enable >= 2 ? 2 : (enable > 0 ? 1 : (enable < 0 ? -1 : 0));
     return QCX_NO_ERROR;
 }
 

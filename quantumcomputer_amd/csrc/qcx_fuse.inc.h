@@ -17,6 +17,53 @@ struct QGate {
     unsigned C, A;            // CAMODC
 };
 
+// TOLERANCE MODE (qcx_set_fusion(reg, 2)): a run of >= 2 consecutive controlled phases that share a qubit (their
+// "control": the gates are symmetric in their two qubits) becomes ONE diagonal -- amp[i] *= prod over the other qubits k of
+// the run with bit k of i set of (c_k + i s_k), for every i with the shared bit set (Q:682-689 issues
+// exactly such runs: all controlled phases after H(l) share l).  The factors of a qubit that occurs twice are multiplied
+// on the host (long double).  Not bit-exact: see K6t in qcx_kernels.h.
+struct DiagSpec {
+    unsigned ctl;                 // the shared qubit
+    uint64_t tmask;               // the other qubits of the run
+    double   wc[40], ws[40];      // their factors (cos, sin), (1, 0) where not a target
+    size_t   first, count;        // the run in the ORIGINAL gate list
+};
+
+static void merge_diagonals(const std::vector<QGate> &in, std::vector<QGate> &out, std::vector<DiagSpec> &specs,
+                            std::vector<size_t> &ofirst, std::vector<size_t> &ocnt)
+{
+    auto two_bit_phase = [&](size_t i) { return in[i].type == FUSE_PHASE && __builtin_popcountll(in[i].mask) == 2; };
+    size_t i = 0;
+    while (i < in.size()) {
+        size_t best_len = 1; unsigned best_ctl = 0;
+        if (two_bit_phase(i)) {
+            for (unsigned b = 0; b < 64; b++) {
+                if (!((in[i].mask >> b) & 1)) continue;
+                size_t j = i;
+                while (j < in.size() && two_bit_phase(j) && ((in[j].mask >> b) & 1)) j++;
+                if (j - i > best_len) { best_len = j - i; best_ctl = b; }
+            }
+        }
+        if (best_len < 2) { out.push_back(in[i]); ofirst.push_back(i); ocnt.push_back(1); i++; continue; }
+        DiagSpec d; memset(&d, 0, sizeof d);
+        d.ctl = best_ctl; d.first = i; d.count = best_len;
+        long double wc[40], ws[40];
+        for (unsigned k = 0; k < 40; k++) { wc[k] = 1.0L; ws[k] = 0.0L; }
+        for (size_t j = i; j < i + best_len; j++) {
+            const unsigned k = (unsigned)__builtin_ctzll(in[j].mask & ~((uint64_t)1 << best_ctl));
+            d.tmask |= (uint64_t)1 << k;
+            const long double c = in[j].c, s2 = in[j].s, x = wc[k], y = ws[k];
+            wc[k] = x * c - y * s2; ws[k] = x * s2 + y * c;
+        }
+        for (unsigned k = 0; k < 40; k++) { d.wc[k] = (double)wc[k]; d.ws[k] = (double)ws[k]; }
+        QGate g; memset(&g, 0, sizeof g);
+        g.type = FUSE_DIAG; g.q = best_ctl; g.mask = d.tmask; g.C = (unsigned)specs.size();
+        specs.push_back(d);
+        out.push_back(g); ofirst.push_back(i); ocnt.push_back(best_len);
+        i += best_len;
+    }
+}
+
 struct GateQueue {
     std::vector<QGate> gates;
     FuseOp  *d_ops = nullptr;       // device copy of the ops of the passes in flight
@@ -73,8 +120,13 @@ static int launch_standalone(qcx_register *r, const QGate &g)
 }
 
 // tile-local form of the gates [first, last) for a tile with hot bits `hbits` (one record per gate)
+// `specs` / `orig` / `expand`: tolerance mode.  A merged diagonal becomes one FUSE_DIAG record (its slot = position in
+// `pass_diags`, whose tables diag_tables() builds), or -- expand -- the plain phases it was merged from (passes that do not
+// run in the rounds form have no diagonal interpreter).
 static void build_pass_ops(const qcx_register *r, const std::vector<QGate> &gates, size_t first, size_t last,
-                           unsigned c, const std::vector<unsigned> &hbits, std::vector<FuseOp> &out)
+                           unsigned c, const std::vector<unsigned> &hbits, std::vector<FuseOp> &out,
+                           const std::vector<DiagSpec> *specs = nullptr, const std::vector<QGate> *orig = nullptr,
+                           bool expand = false, std::vector<unsigned> *pass_diags = nullptr)
 {
     const unsigned n = r->n;
     auto local_of = [&](unsigned b, bool *inside) -> unsigned {
@@ -89,6 +141,27 @@ static void build_pass_ops(const qcx_register *r, const std::vector<QGate> &gate
         memset(&o, 0, sizeof o);
         o.type = g.type;
         bool in;
+        if (g.type == FUSE_DIAG) {
+            const DiagSpec &d = (*specs)[g.C];
+            if (expand) {
+                build_pass_ops(r, *orig, d.first, d.first + d.count, c, hbits, out);
+                continue;
+            }
+            const unsigned lc = local_of(d.ctl, &in);
+            uint64_t tloc = 0; unsigned groups = 0;
+            for (unsigned b = 0; b < n; b++) {
+                if (!((d.tmask >> b) & 1)) continue;
+                bool tin;
+                const unsigned lb = local_of(b, &tin);
+                if (tin) { tloc |= (uint64_t)1 << lb; groups |= 1u << (lb >> 2); }
+            }
+            o.a = (in ? lc + 1 : 0u) | ((unsigned)pass_diags->size() << 8) | (groups << 16);
+            o.mask = in ? 0 : (uint64_t)1 << d.ctl;
+            memcpy(&o.c, &tloc, sizeof tloc);
+            pass_diags->push_back(g.C);
+            out.push_back(o);
+            continue;
+        }
         if (g.type == FUSE_H) {
             o.a = local_of(g.q, &in);
         } else if (g.type == FUSE_PHASE) {
@@ -115,6 +188,64 @@ static void build_pass_ops(const qcx_register *r, const std::vector<QGate> &gate
     }
 }
 
+// tolerance mode: the table area of a pass's merged diagonals, in 16-byte units (one complex double each):
+//   [DiagInfo x nd (2 units each)] [G tables: nd x 48] [field tables: 256 entries per (diagonal, byte of the base index)
+//   that holds targets outside the tile]
+static void diag_tables(unsigned n, unsigned c, const std::vector<unsigned> &hbits, const std::vector<DiagSpec> &specs,
+                        const std::vector<unsigned> &pass_diags, std::vector<double> &area)
+{
+    const size_t nd = pass_diags.size();
+    area.assign(2 * (2 * nd + 48 * nd), 0.0);
+    std::vector<int> local_of_bit(64, -1);
+    for (unsigned b = 0; b < c; b++) local_of_bit[b] = (int)b;
+    for (size_t j = 0; j < hbits.size(); j++) local_of_bit[hbits[j]] = (int)(c + j);
+    for (size_t s = 0; s < nd; s++) {
+        const DiagSpec &d = specs[pass_diags[s]];
+        // G tables: group g covers tile-local bits 4g .. 4g+3; entry j = product of the factors of the targets among them
+        for (unsigned g = 0; g < 3; g++)
+            for (unsigned j = 0; j < 16; j++) {
+                long double x = 1.0L, y = 0.0L;
+                for (unsigned t = 0; t < 4; t++) {
+                    if (!((j >> t) & 1u)) continue;
+                    const unsigned lb = 4 * g + t;
+                    unsigned gb = 64;
+                    for (unsigned b = 0; b < n; b++) if (local_of_bit[b] == (int)lb) gb = b;
+                    if (gb >= 64 || !((d.tmask >> gb) & 1)) continue;
+                    const long double cc = d.wc[gb], ss = d.ws[gb], nx = x * cc - y * ss, ny = x * ss + y * cc;
+                    x = nx; y = ny;
+                }
+                double *e = &area[2 * (2 * nd + 48 * s + 16 * g + j)];
+                e[0] = (double)x; e[1] = (double)y;
+            }
+        // field tables: byte f of the tile's base index (global bits 8f .. 8f+7), targets outside the tile only
+        DiagInfo info; memset(&info, 0, sizeof info);
+        for (unsigned f = 0; f < 5; f++) {
+            std::vector<unsigned> bits(8, 64);
+            bool any = false;
+            for (unsigned t = 0; t < 8; t++) {
+                const unsigned gb = 8 * f + t;
+                if (gb < n && ((d.tmask >> gb) & 1) && local_of_bit[gb] < 0) { bits[t] = gb; any = true; }
+            }
+            if (!any) continue;
+            info.present |= 1u << f;
+            info.field_off[f] = (uint32_t)(area.size() / 2);
+            const size_t at = area.size();
+            area.resize(at + 2 * 256);
+            for (unsigned j = 0; j < 256; j++) {
+                long double x = 1.0L, y = 0.0L;
+                for (unsigned t = 0; t < 8; t++)
+                    if (((j >> t) & 1u) && bits[t] < 64) {
+                        const long double cc = d.wc[bits[t]], ss = d.ws[bits[t]], nx = x * cc - y * ss, ny = x * ss + y * cc;
+                        x = nx; y = ny;
+                    }
+                area[at + 2 * j] = (double)x; area[at + 2 * j + 1] = (double)y;
+            }
+        }
+        memcpy(&area[2 * (2 * s)], &info, sizeof info);
+    }
+    if (area.size() % 4) area.resize(area.size() + 2, 0.0);       // whole 32-byte records
+}
+
 // ROUNDS form: group a pass's records into rounds of at most two distinct H bits (the round's register bits);
 // inside a round consecutive phases that rotate the same registers form runs (FUSE_PRUN)
 static void to_rounds(const Tune &tn, const std::vector<FuseOp> &legacy, unsigned T, std::vector<FuseOp> &out, std::vector<unsigned char> &blob)
@@ -139,6 +270,7 @@ static void to_rounds(const Tune &tn, const std::vector<FuseOp> &legacy, unsigne
                 o.a = (o.a == rb[0]) ? 0u : 1u; o.type = FUSE_H | ((32u | o.a) << 8);
                 run_hdr = (size_t)-1; out.push_back(o); continue;
             }
+            if (o.type == FUSE_DIAG) { run_hdr = (size_t)-1; out.push_back(o); continue; }     // tolerance mode: an item of its own
             const uint32_t mr = o.a & regmask;
             uint32_t rsel = 0;
             for (unsigned q = 0; q < 4; q++) {
@@ -203,11 +335,18 @@ static void to_rounds(const Tune &tn, const std::vector<FuseOp> &legacy, unsigne
 
 // the rounds-only kernel, built for 6, 7 or 8 waves per SIMD; false when the geometry has no rounds form
 template <int B, int TT>
-static bool launch_rounds_kernel(int occ, unsigned grid, size_t lds, hipStream_t st, amp_t *amp, unsigned n, const FusePass &P,
+static bool launch_rounds_kernel(int occ, int tol_occ, unsigned grid, size_t lds, hipStream_t st, amp_t *amp, unsigned n, const FusePass &P,
                                  const FuseOp *d_ops, uint64_t ntiles)
 {
     if constexpr ((1u << TT) == 4u * B) {
         const bool cam = P.has_cam != 0;
+        if (P.dg_cnt) {       // tolerance mode: the pass holds merged diagonals (K6t)
+#define QCX_TOL_LAUNCH(O, C) hipLaunchKernelGGL((k_fused_rounds<B, TT, O, C, true>), dim3(grid), dim3(B), lds, st, amp, n, P, d_ops, ntiles, d_ops)
+            if (tol_occ >= 8) { if (cam) QCX_TOL_LAUNCH(8, true); else QCX_TOL_LAUNCH(8, false); }
+            else { if (cam) QCX_TOL_LAUNCH(6, true); else QCX_TOL_LAUNCH(6, false); }
+#undef QCX_TOL_LAUNCH
+            return true;
+        }
 #define QCX_ROUNDS_LAUNCH(O, C) hipLaunchKernelGGL((k_fused_rounds<B, TT, O, C>), dim3(grid), dim3(B), lds, st, amp, n, P, d_ops, ntiles, d_ops)
         if (occ >= 8) { if (cam) QCX_ROUNDS_LAUNCH(8, true); else QCX_ROUNDS_LAUNCH(8, false); }
         else if (occ == 7) { if (cam) QCX_ROUNDS_LAUNCH(7, true); else QCX_ROUNDS_LAUNCH(7, false); }
@@ -215,7 +354,7 @@ static bool launch_rounds_kernel(int occ, unsigned grid, size_t lds, hipStream_t
 #undef QCX_ROUNDS_LAUNCH
         return true;
     } else {
-        (void)occ; (void)grid; (void)lds; (void)st; (void)amp; (void)n; (void)P; (void)d_ops; (void)ntiles;
+        (void)occ; (void)tol_occ; (void)grid; (void)lds; (void)st; (void)amp; (void)n; (void)P; (void)d_ops; (void)ntiles;
         return false;
     }
 }
@@ -235,10 +374,15 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
         P.xm_off = (uint32_t)((lut_bytes + 7) & ~(size_t)7);
         lut_bytes = P.xm_off + 8 * ((size_t)P.xm_cnt + 66);          // padded: lanes look up to 64 entries past a run
     }
+    P.dg_lds_off = 0;
+    if (P.dg_cnt) {                                                                // + tolerance mode: E_out slots and G tables of the merged diagonals
+        P.dg_lds_off = (uint32_t)((lut_bytes + 15) & ~(size_t)15);
+        lut_bytes = P.dg_lds_off + 16 * (size_t)P.dg_cnt * 49;
+    }
     const size_t lds = ((size_t)16 << P.T) + lut_bytes;
     // 4 amplitudes per thread (all loads of a tile in flight at once, few registers): block = 2^T / 4
 #define QCX_FUSE_LAUNCH(B, TTv) do { \
-        if (P.cam_ctl_local[0] && tn.fuse_ldsdma && tn.fuse_rounds_occ >= 6 && launch_rounds_kernel<B, TTv>((int)tn.fuse_rounds_occ, grid, lds, r->stream, r->amp, n, P, d_ops, ntiles)) { \
+        if (P.cam_ctl_local[0] && tn.fuse_ldsdma && tn.fuse_rounds_occ >= 6 && launch_rounds_kernel<B, TTv>((int)tn.fuse_rounds_occ, (int)tn.fuse_tol_occ, grid, lds, r->stream, r->amp, n, P, d_ops, ntiles)) { \
         } else if (tn.fuse_ldsdma) hipLaunchKernelGGL((k_fused<B, TTv, true>), dim3(grid), dim3(B), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); \
         else hipLaunchKernelGGL((k_fused<B, TTv, false>), dim3(grid), dim3(B), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); } while (0)
     switch (P.T) {
@@ -256,8 +400,20 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
 // The planner: cut a gate list into actions (fused passes and stand-alone gates) and emit every pass's records.
 // Pure host code (no HIP call): qcx_fusion_plan exposes it so that the CPU-only tests can check the records against
 // the oracle with an emulator of the pass kernels (tests/fuse_emulator.py).
-static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<QGate> &gates, std::vector<FuseAction> &acts, std::vector<FuseOp> &all_ops)
+// tol: tolerance mode (qcx_set_fusion(reg, 2)).  Actions always refer to the ORIGINAL gate list (first_gate / ngates /
+// gate), whatever was merged.
+static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<QGate> &gates_in, std::vector<FuseAction> &acts, std::vector<FuseOp> &all_ops,
+                      bool tol = false)
 {
+    std::vector<QGate> merged;
+    std::vector<DiagSpec> specs;
+    std::vector<size_t> ofirst, ocnt;                  // per (merged) gate: its run in the original list
+    if (tol) merge_diagonals(gates_in, merged, specs, ofirst, ocnt);
+    const std::vector<QGate> &gates = tol ? merged : gates_in;
+    if (!tol) { ofirst.resize(gates.size()); ocnt.assign(gates.size(), 1); for (size_t k = 0; k < gates.size(); k++) ofirst[k] = k; }
+    auto standalone = [&](size_t k) {                  // gate k (merged numbering) as stand-alone kernel launches
+        for (size_t j = 0; j < ocnt[k]; j++) { FuseAction a; memset(&a, 0, sizeof a); a.gate = ofirst[k] + j; acts.push_back(a); }
+    };
     const unsigned n = r->n;
     unsigned T = (unsigned)tn.fuse_T, c_def = (unsigned)tn.fuse_c;
     if (T > 12) T = 12;
@@ -271,7 +427,7 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
     while (i < gates.size()) {
         FuseAction act;
         memset(&act, 0, sizeof act);
-        if (gates[i].type == 99) { act.gate = i++; acts.push_back(act); continue; }   // table-form modular multiply
+        if (gates[i].type == 99) { standalone(i++); continue; }   // table-form modular multiply
         // ---- grow one pass: a gate joins while the bits it needs inside the tile still fit ----------------
         std::vector<unsigned> hbits;
         const size_t first = i;
@@ -287,7 +443,7 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
                 for (unsigned b : need) if (std::find(merged.begin(), merged.end(), b) == merged.end()) merged.push_back(b);
                 if (merged.size() > bud) break;
                 hbits.swap(merged);
-                if (g.type == FUSE_H) n_h++; else if (g.type == FUSE_PHASE) n_ph++; else n_other++;
+                if (g.type == FUSE_H) n_h++; else if (g.type == FUSE_PHASE || g.type == FUSE_DIAG) n_ph++; else n_other++;
                 i++;
             }
         };
@@ -329,32 +485,49 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
             grow(c, budget);
             act.nopipe = 1;
         }
-        if (i == first) { act.gate = i++; acts.push_back(act); continue; }             // does not fit a tile at all
-        if (i - first == 1) { act.gate = first; acts.push_back(act); continue; }       // alone: its tuned kernel
+        if (i == first) { standalone(i++); continue; }             // does not fit a tile at all
+        if (i - first == 1) { standalone(first); continue; }       // alone: its tuned kernel
         // pad the tile with the lowest free bits (longer contiguous runs) up to T bits
         for (unsigned b = c; hbits.size() < budget && b < n; b++)
             if (std::find(hbits.begin(), hbits.end(), b) == hbits.end()) hbits.push_back(b);
         std::sort(hbits.begin(), hbits.end());
 
         act.fused = 1;
-        act.ngates = i - first; act.first_gate = first;
+        act.first_gate = ofirst[first]; act.ngates = ofirst[i - 1] + ocnt[i - 1] - ofirst[first];
         act.P.has_cam = n_other ? 1u : 0u;
         act.P.c = c; act.P.nh = (uint32_t)hbits.size(); act.P.T = c + act.P.nh;
         act.P.cam_ctl_local[3] = (int32_t)cam_lut_bytes((unsigned)r->M);           // table area sits behind the lut
         for (unsigned j = 0; j < act.P.nh; j++) act.P.hbit[j] = (uint8_t)hbits[j];
         legacy.clear();
-        build_pass_ops(r, gates, first, i, c, hbits, legacy);
-        act.op_off = all_ops.size();
         bool rounds = tn.fuse_rounds && act.P.T >= 10 && act.P.T <= 12;
+        // (tolerance mode: merged diagonals exist in the rounds form only, at most 16 per pass -- their tables live in LDS;
+        // otherwise the pass gets the plain phases they were merged from)
+        std::vector<unsigned> pass_diags;
+        size_t n_diag = 0;
+        for (size_t k = first; k < i; k++) n_diag += gates[k].type == FUSE_DIAG;
+        bool keep_diags = tol && rounds && n_diag > 0 && n_diag <= 16;
+        build_pass_ops(r, gates, first, i, c, hbits, legacy, &specs, &gates_in, !keep_diags, &pass_diags);
+        act.op_off = all_ops.size();
         if (rounds) {
             // ROUNDS form: phases run as "phase runs", which need the records' outside-tile masks in LDS next to the
             // tiles (8 B per record); when that would cost a resident workgroup the pass uses the plain gate list
             std::vector<unsigned char> blob;
             to_rounds(tn, legacy, act.P.T, all_ops, blob);
             const size_t nrec = all_ops.size() - act.op_off;
-            const size_t lds = 2 * ((size_t)16 << act.P.T) + (size_t)act.P.cam_ctl_local[3] + blob.size() + 64 + 8 * (nrec + 66);
-            const size_t limit = (size_t)160 * 1024 / (act.P.T == 12 ? 1 : act.P.T == 11 ? 2 : 4);
-            if (lds > limit) { all_ops.resize(act.op_off); rounds = false; }
+            size_t lds = 2 * ((size_t)16 << act.P.T) + (size_t)act.P.cam_ctl_local[3] + blob.size() + 64 + 8 * (nrec + 66);
+            size_t limit = (size_t)160 * 1024 / (act.P.T == 12 ? 1 : act.P.T == 11 ? 2 : 4);
+            if (keep_diags) {            // tolerance mode: what the workgroup really needs; two of them must fit a CU
+                lds = ((size_t)16 << act.P.T) + (size_t)act.P.cam_ctl_local[3] + blob.size() + 64 + 8 * (nrec + 66) + 16 * 49 * pass_diags.size();
+                limit = (size_t)80 * 1024;
+            }
+            if (getenv("QCX_FUSE_DUMP")) fprintf(stderr, "[qcx fuse] lds %zu limit %zu keep %d nd %zu nrec %zu\n", lds, limit, (int)keep_diags, pass_diags.size(), nrec);
+            if (lds > limit) {
+                all_ops.resize(act.op_off); rounds = false;
+                if (keep_diags) {        // the plain gate list has no diagonal interpreter: back to the phases
+                    legacy.clear(); pass_diags.clear(); keep_diags = false;
+                    build_pass_ops(r, gates, first, i, c, hbits, legacy, &specs, &gates_in, true, &pass_diags);
+                }
+            }
             else {
                 act.P.xm_cnt = (uint32_t)nrec;
                 act.P.cam_ctl_local[0] = 1;
@@ -366,11 +539,20 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
                     all_ops.resize(at + blob.size() / sizeof(FuseOp));
                     memcpy(&all_ops[at], blob.data(), blob.size());
                 }
+                if (keep_diags) {                // the diagonals' table area rides behind everything else of the pass
+                    std::vector<double> area;
+                    diag_tables(n, c, hbits, specs, pass_diags, area);
+                    act.P.dg_cnt = (uint32_t)pass_diags.size();
+                    act.P.dg_rec_off = (uint32_t)(all_ops.size() - act.op_off);
+                    const size_t at = all_ops.size();
+                    all_ops.resize(at + area.size() * sizeof(double) / sizeof(FuseOp));
+                    memcpy(&all_ops[at], area.data(), area.size() * sizeof(double));
+                }
+                act.P.nops = (uint32_t)nrec;
             }
         }
-        if (!rounds) all_ops.insert(all_ops.end(), legacy.begin(), legacy.end());
+        if (!rounds) { all_ops.insert(all_ops.end(), legacy.begin(), legacy.end()); act.P.nops = (uint32_t)legacy.size(); }
         act.op_cnt = all_ops.size() - act.op_off;
-        act.P.nops = (uint32_t)(act.P.cam_ctl_local[1] ? (size_t)act.P.cam_ctl_local[2] : act.op_cnt);
         static const bool dump = getenv("QCX_FUSE_DUMP") != nullptr;      // planner diagnostics (tools/probe_fuse3.py)
         if (dump) {
             unsigned nround = 0, nh = 0, nrun = 0, nsingle = 0, ncam = 0, run_gates[16] = {0}, ext = 0, loc = 0;
@@ -406,7 +588,7 @@ static int fuse_flush(qcx_register *r)
     std::vector<FuseAction> acts;
     std::vector<FuseOp> all_ops;
     const Tune tn = tune_now();
-    fuse_plan(r, tn, gates, acts, all_ops);
+    fuse_plan(r, tn, gates, acts, all_ops, r->fusion == 2);
 
     if (!all_ops.empty()) {
         if (gq->ev_valid) HIP_TRY(hipEventSynchronize(gq->ev));       // the previous flush may still read the buffers

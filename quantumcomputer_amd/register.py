@@ -192,8 +192,12 @@ class Register:
     def set_fusion(self, enable=True):
         """Fused LDS-tile passes (bit-identical results).  True/1: every gate call is queued; False/0 (default): only
         the whole-circuit calls (inverse_QFT, quantum_computation) run as fused passes; -1: strictly one kernel launch
-        per gate, inside the whole-circuit calls too."""
-        mode = -1 if (enable is not True and enable is not False and int(enable) < 0) else int(bool(enable))
+        per gate, inside the whole-circuit calls too; 2 (FUSION_TOLERANCE): opt-in tolerance mode -- runs of controlled
+        phases sharing a qubit are merged into one diagonal, NOT bit-exact (rounding-level differences, include/qcx.h)."""
+        if enable is True or enable is False:
+            mode = int(enable)
+        else:
+            mode = -1 if int(enable) < 0 else min(int(enable), 2)
         check(lib().qcx_set_fusion(self._h, mode), "qcx_set_fusion")
 
     def flush(self):

@@ -12,7 +12,7 @@ import struct
 
 import numpy as np
 
-FUSE_H, FUSE_PHASE, FUSE_CAMODC, FUSE_ROUND, FUSE_PRUN, FUSE_CAMRUN = 0, 1, 2, 3, 4, 5
+FUSE_H, FUSE_PHASE, FUSE_CAMODC, FUSE_ROUND, FUSE_PRUN, FUSE_CAMRUN, FUSE_DIAG = 0, 1, 2, 3, 4, 5, 6
 SQRT1_2 = 0.70710678118654752440
 
 
@@ -132,6 +132,39 @@ def _camrun(P, re, im, recs, i, blob):
     return cnt
 
 
+def _diag(P, re, im, rec, area, nd):
+    """FUSE_DIAG (tolerance mode, K6t): amplitudes with the control bit set are multiplied by
+    E_out(tile) * G0[local bits 0-3] * G1[4-7] * G2[8-11]; the tables come from the pass's table area (complex128 units)"""
+    a = rec.a
+    cl, slot, groups = (a & 0xFF) - 1, (a >> 8) & 0xFF, (a >> 16) & 7
+    assert slot < nd
+    sel = P.outside_all_set(rec.mask)
+    if cl >= 0:
+        sel = sel & P.bit(cl)
+    tloc = struct.unpack("<Q", struct.pack("<d", rec.c))[0]
+    # tile-local element index of every amplitude
+    e = np.zeros(P.idx.shape, dtype=np.int64)
+    for j in range(P.T):
+        e |= P.bit(j).astype(np.int64) << j
+    assert tloc < (1 << P.T) and all(((tloc >> (4 * g)) & 15) == 0 for g in range(3) if not (groups >> g) & 1)
+    G = area[2 * nd + 48 * slot: 2 * nd + 48 * (slot + 1)]
+    F = np.ones(P.idx.shape, dtype=np.complex128)
+    info = struct.unpack("<8I", area[2 * slot: 2 * slot + 2].tobytes())
+    field_off, present = info[:5], info[5]
+    base = P.base.astype(np.int64)
+    for f in range(5):
+        if (present >> f) & 1:
+            F = F * area[field_off[f] + ((base >> (8 * f)) & 255)]
+    for g in range(3):
+        if (groups >> g) & 1:
+            F = F * G[16 * g + ((e >> (4 * g)) & 15)]
+        else:
+            assert np.all(G[16 * g: 16 * g + 16] == 1.0)
+    z = (re + 1j * im)
+    z[sel] = z[sel] * F[sel]
+    re[:], im[:] = z.real, z.imag
+
+
 def apply_pass(state, n, act, recs):
     """one fused pass; state = interleaved (re, im) float64 array of 2 * 2^n, modified in place"""
     re, im = state[0::2].copy(), state[1::2].copy()
@@ -143,8 +176,13 @@ def apply_pass(state, n, act, recs):
         raw = b"".join(bytes(memoryview(recs[r0 + act.table_rec_off + k]).cast("B")) for k in range(act.rec_cnt - act.table_rec_off))
         blob = raw[:act.table_bytes]
     nops = act.nops
+    nd = getattr(act, "diag_cnt", 0)
+    area = None
+    if nd:
+        raw = b"".join(bytes(memoryview(recs[r0 + act.diag_rec_off + k]).cast("B")) for k in range(act.rec_cnt - act.diag_rec_off))
+        area = np.frombuffer(raw, dtype=np.complex128)
     i = 0
-    stats = dict(rounds=0, runs=0, run_gates=0, h=0)
+    stats = dict(rounds=0, runs=0, run_gates=0, h=0, diags=0)
     if not act.rounds_form:
         while i < nops:
             r = R[i]
@@ -180,7 +218,7 @@ def apply_pass(state, n, act, recs):
                     elif kind == FUSE_PRUN:
                         rsel, canon = code & 15, bool(code & 16)
                         assert 1 <= rc <= 64 and rsel and not (code & 32)
-                        assert canon == (not has_h), "a run canonicalises its own zeros exactly when its round has no H"
+                        assert nd or canon == (not has_h), "a run canonicalises its own zeros exactly when its round has no H"
                         touched = np.zeros(P.idx.shape, dtype=bool)
                         for g in range(rc):
                             gr = R[o + 1 + g]
@@ -193,6 +231,9 @@ def apply_pass(state, n, act, recs):
                             re[touched] += 0.0; im[touched] += 0.0
                         stats["runs"] += 1; stats["run_gates"] += rc
                         o += 1 + rc
+                    elif kind == FUSE_DIAG and nd:
+                        _diag(P, re, im, R[o], area, nd); stats["diags"] += 1
+                        o += 1
                     else:
                         raise AssertionError(f"item kind {kind} inside a round")
                 assert o == oend + 1 and saw_h == bool(has_h)
@@ -213,7 +254,7 @@ def apply_pass(state, n, act, recs):
 def run_plan(state, n, M, descs, actions, recs, ob):
     """apply a whole plan: fused passes through the emulator, stand-alone gates through the oracle"""
     covered = 0
-    totals = dict(passes=0, standalone=0, rounds=0, runs=0, run_gates=0, h=0)
+    totals = dict(passes=0, standalone=0, rounds=0, runs=0, run_gates=0, h=0, diags=0)
     for act in actions:
         assert act.first_gate == covered, "actions cover the gate list in order without gaps"
         covered += act.ngates

@@ -166,3 +166,104 @@ def test_long_phase_runs_are_cut_at_64_gates(qc, ob, tune_guard, count):
     oracle_run(ob, want, n, 0, 1, steps)
     emu.run_plan(state, n, 0, descs, actions, recs, ob)
     assert np.array_equal(bits(state), bits(want))
+
+
+# ---- tolerance mode (qcx_set_fusion(reg, 2)): merged diagonals, NOT bit-exact -----------------------------------------
+TOL = 1e-12       # max |delta amplitude| against the oracle on these n <= 14 circuits (north_star allows 1e-10)
+
+
+def shor_descs(qc, Cn, L, M, a):
+    """the gate list of quantum_computation (Q:712-737) with exact modular powers"""
+    n = L + M
+    descs = [(0, l, 0, 0.0, 0.0, 0, 0) for l in range(M, n)]
+    x = a % Cn
+    for l in range(M, n):
+        descs.append((2, l, 0, 0.0, 0.0, Cn, x)); x = (x * x) % Cn
+    return descs + iqft_descs(qc, n, M)
+
+
+def max_delta(a, b):
+    d = np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)
+    return float(np.max(np.hypot(d[0::2], d[1::2])))
+
+
+@pytest.mark.parametrize("n,M", [(12, 0), (13, 0), (14, 4), (11, 5)])
+@pytest.mark.parametrize("T,c", [(10, 4), (11, 4), (12, 3), (12, 4)])
+def test_tolerance_mode_iqft_merges_every_run_into_one_diagonal(qc, ob, tune_guard, n, M, T, c):
+    if T > n:
+        pytest.skip("tile larger than the register")
+    qc.tune(fuse_T=T, fuse_c=c, fuse_T_phase=0)
+    descs = iqft_descs(qc, n, M)
+    L = n - M
+    acts, recs, _ = qc.fusion_plan(n, M, descs, mode=2)
+    state = ob.fill_random(n, 11)
+    want = state.copy()
+    ob.iqft(want, n, M)
+    tot = emu.run_plan(state, n, M, descs, acts, recs, ob)
+    assert max_delta(state, want) <= TOL
+    assert not np.array_equal(bits(state), bits(want)) or L < 3          # it really is the other arithmetic
+    # every H but the last is followed by a run of >= 2 phases (the run after H(M+1) has one gate and stays a phase)
+    assert max(L - 3, 0) <= tot["diags"] <= max(L - 2, 0) and L - 1 <= tot["h"] <= L      # (a lone last H may run stand-alone)
+    exact_acts, _, _ = qc.fusion_plan(n, M, descs, mode=1)
+    assert sum(a.fused for a in acts) <= sum(a.fused for a in exact_acts)
+
+
+@pytest.mark.parametrize("Cn,L,M,a", [(15, 8, 4, 7), (21, 9, 5, 2), (33, 8, 6, 5)])
+def test_tolerance_mode_shor_circuit(qc, ob, tune_guard, Cn, L, M, a):
+    n = L + M
+    descs = shor_descs(qc, Cn, L, M, a)
+    acts, recs, _ = qc.fusion_plan(n, M, descs, mode=2)
+    state = np.zeros(2 << n); ob.reset(state, n)
+    want = state.copy()
+    ob.quantum_computation(want, n, M, Cn, a)
+    tot = emu.run_plan(state, n, M, descs, acts, recs, ob)
+    assert max_delta(state, want) <= TOL and tot["diags"] >= L - 3
+    # the measurement distribution is untouched at this level: same cumulative probabilities to 1e-12
+    p0 = np.cumsum(state[0::2] ** 2 + state[1::2] ** 2); p1 = np.cumsum(want[0::2] ** 2 + want[1::2] ** 2)
+    assert np.max(np.abs(p0 - p1)) < 1e-12
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_tolerance_mode_random_programs(qc, ob, tune_guard, seed):
+    """random programs with plenty of phase runs sharing a qubit (and phases that share none), every gate kind, several
+    geometries; repeated targets inside a run multiply their factors"""
+    rs = np.random.RandomState(100 + seed)
+    n, M, Cn = int(rs.randint(10, 15)), int(rs.choice([0, 3, 4])), 0
+    if M:
+        Cn = int(rs.randint(3, 1 << M))
+    T, c = [(10, 4), (11, 4), (12, 3), (11, 2)][seed % 4]
+    if T > n:
+        T = n
+    qc.tune(fuse_T=T, fuse_c=min(c, T))
+    descs, steps = [], []
+    for _ in range(int(rs.randint(30, 80))):
+        k = rs.randint(0, 10)
+        if k < 3:
+            q = int(rs.randint(0, n)); descs.append((0, q, 0, 0.0, 0.0, 0, 0)); steps.append(("h", q))
+        elif k < 8 or M == 0:
+            ctl = int(rs.randint(0, n))
+            for _ in range(int(rs.randint(1, 9))):                         # a run sharing ctl (targets may repeat)
+                t = int(rs.randint(0, n))
+                if t == ctl:
+                    continue
+                th = float(rs.uniform(-3, 3))
+                steps.append(("p", ctl, t, th)); descs.append((1, 0, (1 << ctl) | (1 << t), 0.0, 0.0, 0, 0))
+        else:
+            atox, ctl = int(rs.randint(1, 4 * Cn)), int(rs.randint(M, n))
+            descs.append((2, ctl, 0, 0.0, 0.0, Cn, atox % Cn)); steps.append(("c", atox, ctl))
+    descs = fill_polar(qc, descs, steps)
+    acts, recs, _ = qc.fusion_plan(n, M, descs, mode=2)
+    state = ob.fill_random(n, seed)
+    want = state.copy()
+    oracle_run(ob, want, n, M, Cn, steps)
+    emu.run_plan(state, n, M, descs, acts, recs, ob)
+    assert max_delta(state, want) <= TOL, (n, M, T, c)
+
+
+def test_mode_1_plan_is_unchanged_by_the_tolerance_code(qc, ob, tune_guard):
+    """the bit-exact planner's output carries no diagonal: same records through either entry point"""
+    descs = iqft_descs(qc, 13, 0)
+    a1, r1, n1 = qc.fusion_plan(13, 0, descs)
+    a2, r2, n2 = qc.fusion_plan(13, 0, descs, mode=1)
+    assert n1 == n2 and all(x.diag_cnt == 0 for x in a1)
+    assert bytes(memoryview(r1).cast("B"))[:32 * n1] == bytes(memoryview(r2).cast("B"))[:32 * n2]

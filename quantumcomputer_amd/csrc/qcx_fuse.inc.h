@@ -17,7 +17,7 @@ struct QGate {
     unsigned C, A;            // CAMODC
 };
 
-// TOLERANCE MODE (qcx_set_fusion(reg, 2)): a run of >= 2 consecutive controlled phases that share a qubit (their
+// TOLERANCE MODE (qcx_set_fusion(reg, 2)): a run of consecutive controlled phases that share a qubit (their
 // "control": the gates are symmetric in their two qubits) becomes ONE diagonal -- amp[i] *= prod over the other qubits k of
 // the run with bit k of i set of (c_k + i s_k), for every i with the shared bit set (Q:682-689 issues
 // exactly such runs: all controlled phases after H(l) share l).  The factors of a qubit that occurs twice are multiplied
@@ -34,17 +34,22 @@ static void merge_diagonals(const std::vector<QGate> &in, std::vector<QGate> &ou
 {
     auto two_bit_phase = [&](size_t i) { return in[i].type == FUSE_PHASE && __builtin_popcountll(in[i].mask) == 2; };
     size_t i = 0;
+    unsigned last_h = 64;                  // target of the Hadamard just before (a single phase takes it as its control)
     while (i < in.size()) {
-        size_t best_len = 1; unsigned best_ctl = 0;
+        size_t best_len = 0; unsigned best_ctl = 0;
         if (two_bit_phase(i)) {
             for (unsigned b = 0; b < 64; b++) {
                 if (!((in[i].mask >> b) & 1)) continue;
                 size_t j = i;
                 while (j < in.size() && two_bit_phase(j) && ((in[j].mask >> b) & 1)) j++;
-                if (j - i > best_len) { best_len = j - i; best_ctl = b; }
+                if (j - i > best_len || (j - i == best_len && b == last_h)) { best_len = j - i; best_ctl = b; }
             }
         }
-        if (best_len < 2) { out.push_back(in[i]); ofirst.push_back(i); ocnt.push_back(1); i++; continue; }
+        if (best_len < 1) {
+            if (in[i].type == FUSE_H) last_h = in[i].q; else last_h = 64;
+            out.push_back(in[i]); ofirst.push_back(i); ocnt.push_back(1); i++; continue;
+        }
+        last_h = 64;
         DiagSpec d; memset(&d, 0, sizeof d);
         d.ctl = best_ctl; d.first = i; d.count = best_len;
         long double wc[40], ws[40];
@@ -159,7 +164,12 @@ static void build_pass_ops(const qcx_register *r, const std::vector<QGate> &gate
             o.mask = in ? 0 : (uint64_t)1 << d.ctl;
             memcpy(&o.c, &tloc, sizeof tloc);
             pass_diags->push_back(g.C);
+            // the phases it was merged from follow as ALTERNATES (their number rides in the s field): to_rounds keeps
+            // either the diagonal (fast round) or the phases
+            const uint64_t nalt = d.count;
+            memcpy(&o.s, &nalt, sizeof nalt);
             out.push_back(o);
+            build_pass_ops(r, *orig, d.first, d.first + d.count, c, hbits, out);
             continue;
         }
         if (g.type == FUSE_H) {
@@ -248,29 +258,69 @@ static void diag_tables(unsigned n, unsigned c, const std::vector<unsigned> &hbi
 
 // ROUNDS form: group a pass's records into rounds of at most two distinct H bits (the round's register bits);
 // inside a round consecutive phases that rotate the same registers form runs (FUSE_PRUN)
-static void to_rounds(const Tune &tn, const std::vector<FuseOp> &legacy, unsigned T, std::vector<FuseOp> &out, std::vector<unsigned char> &blob)
+static void to_rounds(const Tune &tn, const std::vector<FuseOp> &legacy, unsigned T, std::vector<FuseOp> &out, std::vector<unsigned char> &blob,
+                      std::vector<unsigned> *kept_slots = nullptr, unsigned *generic_rounds = nullptr)
 {
-    std::vector<FuseOp> cur;
+    // tolerance mode (kept_slots != nullptr): a merged diagonal arrives as a FUSE_DIAG record followed by the phases it
+    // stands for; a round of the shape H(x) [D(x)] [H(y) [D(y)]] keeps its diagonals (FUSE_QROUND, slots renumbered in the
+    // order kept), every other round gets the phases back and is emitted exactly as in the bit-exact modes
+    struct Item { FuseOp o; std::vector<FuseOp> alts; };
+    std::vector<Item> cur;
     std::vector<unsigned> rb;
     auto close_round = [&]() {
         if (cur.empty()) { rb.clear(); return; }
         for (unsigned b = T; rb.size() < 2 && b-- > 0;)
             if (std::find(rb.begin(), rb.end(), b) == rb.end()) rb.push_back(b);
         std::sort(rb.begin(), rb.end());
+        if (kept_slots && tn.fuse_qround) {
+            uint32_t step[2] = {0xffffffffu, 0xffffffffu};
+            unsigned old_slot[2] = {0, 0};
+            unsigned ns = 0, nd = 0; bool ok = true;
+            for (size_t k = 0; k < cur.size() && ok; k++) {
+                const FuseOp &o = cur[k].o;
+                if (o.type == FUSE_H && ns < 2 && (o.a == rb[0] || o.a == rb[1])) step[ns++] = (o.a == rb[1]) ? 1u : 0u;
+                else if (o.type == FUSE_DIAG && ns >= 1 && !(step[ns - 1] & 2u) && o.mask == 0) {
+                    const unsigned hb = (step[ns - 1] & 1u) ? rb[1] : rb[0], ob = (step[ns - 1] & 1u) ? rb[0] : rb[1];
+                    uint64_t tloc; memcpy(&tloc, &o.c, sizeof tloc);
+                    if ((o.a & 0xffu) != hb + 1) { ok = false; break; }
+                    old_slot[ns - 1] = (o.a >> 8) & 0xffu;
+                    step[ns - 1] |= 2u | (((o.a >> 16) & 7u) << 16) | ((uint32_t)((tloc >> ob) & 1u) << 19);
+                    nd++;
+                } else ok = false;
+            }
+            if (ok && ns >= 1 && nd >= 1 && kept_slots->size() + nd <= 16) {
+                for (unsigned q = 0; q < ns; q++)
+                    if (step[q] & 2u) { step[q] |= (uint32_t)kept_slots->size() << 8; kept_slots->push_back(old_slot[q]); }
+                FuseOp hdr; memset(&hdr, 0, sizeof hdr);
+                hdr.type = FUSE_QROUND; hdr.a = rb[0] | (rb[1] << 8) | (ns << 16); hdr.mask = 1;
+                out.push_back(hdr);
+                FuseOp st; memset(&st, 0, sizeof st);
+                st.type = step[0]; st.a = step[1];
+                out.push_back(st);
+                cur.clear(); rb.clear();
+                return;
+            }
+        }
+        // the general form: diagonals (if any) give way to their phases
+        if (generic_rounds) ++*generic_rounds;
+        std::vector<FuseOp> flat;
+        for (const Item &it : cur) {
+            if (it.o.type == FUSE_DIAG) flat.insert(flat.end(), it.alts.begin(), it.alts.end());
+            else flat.push_back(it.o);
+        }
         FuseOp hdr; memset(&hdr, 0, sizeof hdr);
         bool has_h = false;
-        for (const FuseOp &o : cur) has_h |= (o.type == FUSE_H);
+        for (const FuseOp &o : flat) has_h |= (o.type == FUSE_H);
         hdr.type = FUSE_ROUND; hdr.a = rb[0] | (rb[1] << 8) | ((has_h ? 1u : 0u) << 16);
         out.push_back(hdr);
         const size_t hdr_at = out.size() - 1;
         const uint32_t regmask = (1u << rb[0]) | (1u << rb[1]);
         size_t run_hdr = (size_t)-1; uint32_t run_rsel = 0;
-        for (FuseOp o : cur) {
+        for (FuseOp o : flat) {
             if (o.type == FUSE_H) {          // item headers carry everything in their first dword (one scalar load per item)
                 o.a = (o.a == rb[0]) ? 0u : 1u; o.type = FUSE_H | ((32u | o.a) << 8);
                 run_hdr = (size_t)-1; out.push_back(o); continue;
             }
-            if (o.type == FUSE_DIAG) { run_hdr = (size_t)-1; out.push_back(o); continue; }     // tolerance mode: an item of its own
             const uint32_t mr = o.a & regmask;
             uint32_t rsel = 0;
             for (unsigned q = 0; q < 4; q++) {
@@ -327,8 +377,13 @@ static void to_rounds(const Tune &tn, const std::vector<FuseOp> &legacy, unsigne
                 if (rb.size() == 2) close_round();
                 rb.push_back(o.a);
             }
-            cur.push_back(o);
-        } else cur.push_back(o);
+            cur.push_back(Item{o, {}});
+        } else if (o.type == FUSE_DIAG) {
+            uint64_t nalt; memcpy(&nalt, &o.s, sizeof nalt);
+            Item it{o, std::vector<FuseOp>(legacy.begin() + li + 1, legacy.begin() + li + 1 + nalt)};
+            cur.push_back(it);
+            li += nalt;
+        } else cur.push_back(Item{o, {}});
     }
     close_round();
 }
@@ -340,10 +395,12 @@ static bool launch_rounds_kernel(int occ, int tol_occ, unsigned grid, size_t lds
 {
     if constexpr ((1u << TT) == 4u * B) {
         const bool cam = P.has_cam != 0;
-        if (P.dg_cnt) {       // tolerance mode: the pass holds merged diagonals (K6t)
-#define QCX_TOL_LAUNCH(O, C) hipLaunchKernelGGL((k_fused_rounds<B, TT, O, C, true>), dim3(grid), dim3(B), lds, st, amp, n, P, d_ops, ntiles, d_ops)
-            if (tol_occ >= 8) { if (cam) QCX_TOL_LAUNCH(8, true); else QCX_TOL_LAUNCH(8, false); }
-            else { if (cam) QCX_TOL_LAUNCH(6, true); else QCX_TOL_LAUNCH(6, false); }
+        if (P.dg_cnt) {       // tolerance mode: the pass holds merged diagonals (K6t); 2 = every round is a fast round (slim kernel)
+#define QCX_TOL_LAUNCH(O, C, S) hipLaunchKernelGGL((k_fused_rounds<B, TT, O, C, S>), dim3(grid), dim3(B), lds, st, amp, n, P, d_ops, ntiles, d_ops)
+            if (P.dg_slim) {
+                if (tol_occ >= 8) { if (cam) QCX_TOL_LAUNCH(8, true, 2); else QCX_TOL_LAUNCH(8, false, 2); }
+                else { if (cam) QCX_TOL_LAUNCH(6, true, 2); else QCX_TOL_LAUNCH(6, false, 2); }
+            } else { if (cam) QCX_TOL_LAUNCH(6, true, 1); else QCX_TOL_LAUNCH(6, false, 1); }
 #undef QCX_TOL_LAUNCH
             return true;
         }
@@ -369,8 +426,9 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
     const size_t lut_only = cam_lut_bytes((unsigned)r->M);                         // scratch of the modular-multiply steps
     size_t lut_bytes = lut_only + (size_t)P.cam_ctl_local[1];                      // + tables of folded multiply runs
     P.xm_off = 0;
-    P.dbg = (uint32_t)tn.fuse_dbg;
-    if (P.xm_cnt) {                                                                // + the records' outside-tile masks (phase runs)
+    P.dbg = (uint32_t)tn.fuse_dbg | (((uint32_t)tn.fuse_swz & 7u) << 8);
+    if (P.dg_cnt && !P.has_cam) { lut_bytes = 16; P.cam_ctl_local[3] = 16; }       // tolerance-mode pass without multiplies: no scratch
+    if (P.xm_cnt && !P.dg_slim) {                                                  // + the records' outside-tile masks (phase runs)
         P.xm_off = (uint32_t)((lut_bytes + 7) & ~(size_t)7);
         lut_bytes = P.xm_off + 8 * ((size_t)P.xm_cnt + 66);          // padded: lanes look up to 64 entries past a run
     }
@@ -473,6 +531,18 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
                 if (passes(Ta, ca) * 123u < passes(T, c_def) * 100u) { Tcur = Ta; ccur = ca; }
             }
         }
+        // Tolerance mode: passes with merged diagonals overlap their arithmetic better on the smaller tile (2^10 amplitudes,
+        // 256-thread workgroups: n = 28 inverse QFT 7.4 against 8.0 ms) -- taken when it does not cost a pass, estimated from
+        // the distinct Hadamard targets above the tile's low bits in the rest of the queue.
+        if (tol && tn.fuse_tol_T >= 10 && (unsigned)tn.fuse_tol_T < Tcur && (unsigned)tn.fuse_tol_T <= n && tn.fuse_rounds) {
+            bool pure = true; uint64_t hot = 0;
+            for (size_t k = first; k < gates.size(); k++) {
+                if (gates[k].type == FUSE_H) { if (gates[k].q >= ccur) hot |= (uint64_t)1 << gates[k].q; }
+                else if (gates[k].type != FUSE_DIAG && gates[k].type != FUSE_PHASE) { pure = false; break; }
+            }
+            const unsigned hb = (unsigned)__builtin_popcountll(hot), Ts = (unsigned)tn.fuse_tol_T;
+            if (pure && hb && (hb + (Ts - ccur) - 1) / (Ts - ccur) == (hb + (Tcur - ccur) - 1) / (Tcur - ccur)) Tcur = Ts;
+        }
         unsigned c = ccur, budget = Tcur - ccur;
         grow(c, budget);
         // A pass dominated by controlled phases is bound by FP64 issue and latency, not by HBM: it runs better on
@@ -505,19 +575,28 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         std::vector<unsigned> pass_diags;
         size_t n_diag = 0;
         for (size_t k = first; k < i; k++) n_diag += gates[k].type == FUSE_DIAG;
-        bool keep_diags = tol && rounds && n_diag > 0 && n_diag <= 16;
+        bool keep_diags = tol && rounds && n_diag > 0 && n_diag <= 255;
         build_pass_ops(r, gates, first, i, c, hbits, legacy, &specs, &gates_in, !keep_diags, &pass_diags);
         act.op_off = all_ops.size();
         if (rounds) {
             // ROUNDS form: phases run as "phase runs", which need the records' outside-tile masks in LDS next to the
             // tiles (8 B per record); when that would cost a resident workgroup the pass uses the plain gate list
             std::vector<unsigned char> blob;
-            to_rounds(tn, legacy, act.P.T, all_ops, blob);
+            std::vector<unsigned> kept;                  // old slot numbers of the diagonals that stayed merged, in new-slot order
+            unsigned generic_rounds = 0;
+            to_rounds(tn, legacy, act.P.T, all_ops, blob, keep_diags ? &kept : nullptr, &generic_rounds);
+            act.P.dg_slim = (keep_diags && !kept.empty() && generic_rounds == 0) ? 1u : 0u;     // every round is a fast round
+            if (keep_diags) {
+                std::vector<unsigned> kd;
+                for (unsigned os : kept) kd.push_back(pass_diags[os]);
+                pass_diags.swap(kd);
+                keep_diags = !pass_diags.empty();
+            }
             const size_t nrec = all_ops.size() - act.op_off;
             size_t lds = 2 * ((size_t)16 << act.P.T) + (size_t)act.P.cam_ctl_local[3] + blob.size() + 64 + 8 * (nrec + 66);
             size_t limit = (size_t)160 * 1024 / (act.P.T == 12 ? 1 : act.P.T == 11 ? 2 : 4);
             if (keep_diags) {            // tolerance mode: what the workgroup really needs; two of them must fit a CU
-                lds = ((size_t)16 << act.P.T) + (size_t)act.P.cam_ctl_local[3] + blob.size() + 64 + 8 * (nrec + 66) + 16 * 49 * pass_diags.size();
+                lds = ((size_t)16 << act.P.T) + (n_other ? (size_t)act.P.cam_ctl_local[3] : 16) + blob.size() + 64 + 8 * (nrec + 66) + 16 * 49 * pass_diags.size();
                 limit = (size_t)80 * 1024;
             }
             if (getenv("QCX_FUSE_DUMP")) fprintf(stderr, "[qcx fuse] lds %zu limit %zu keep %d nd %zu nrec %zu\n", lds, limit, (int)keep_diags, pass_diags.size(), nrec);

@@ -690,7 +690,7 @@ struct FusePass {
     uint32_t has_cam, dbg;      // the pass holds modular multiplies (selects the kernel variant); dbg: diagnostics only (tools/probe_pass.py):
                                 // bit 0 skip the gates, bit 1 skip the stores, bit 2 skip the tile fill -- results are then wrong by design
     uint32_t dg_cnt, dg_rec_off;// tolerance mode: merged diagonals of the pass (0 = none), record offset of their table area in ops
-    uint32_t dg_lds_off, dg_pad;// byte offset of their LDS area behind the lut
+    uint32_t dg_lds_off, dg_slim;// byte offset of their LDS area behind the lut; 1: every round of the pass is a fast round
 };
 
 // One controlled modular multiply on an LDS-resident tile whose low M local bits are the M register.
@@ -1096,16 +1096,115 @@ __device__ __forceinline__ unsigned fuse_camrun_step(amp_t *tile, unsigned short
     return cnt;
 }
 
-template <int BLOCK, int TT, bool CAM = true>     // CAM = false: the pass holds no modular multiply (smaller kernel)
+// ---------------------------------------------------------------------------
+// K6t  TOLERANCE MODE of the rounds form (qcx_set_fusion(reg, 2); opt-in, NOT bit-exact: amplitudes agree with the
+// reference to ~1e-15, north_star allows 1e-10).  The planner merges every run of consecutive controlled phases that
+// share a control qubit l into ONE diagonal (SURVEY s8(f)-2: Q:682-689 applies l - M of them after each Hadamard):
+//     amp[i] *= prod over the targets k with bit k of i set of (c_k + i s_k),     for every i with bit l set.
+// The product splits over where the target bits live:
+//     E_out(tile)        targets outside the tile: a per-tile constant.  One thread per diagonal builds it at tile start
+//                        (while the LDS-DMA fill is in flight) from <= 5 tables of 256 entries indexed by the bytes of the
+//                        tile's base index (global memory, L2-resident), and leaves it in LDS;
+//     G0 G1 G2 (thread)  targets on tile-local bits, 4 local bits per table, 16 entries each, in LDS (768 B per diagonal);
+//                        the entry for a single set bit is that bit's own factor, so the factors of the round's two
+//                        register bits are read from the same tables.
+// A thread then multiplies the two amplitudes whose control bit is set by F and F w(other register bit): one complex
+// multiply per amplitude instead of one rotation per gate per amplitude, FMA allowed.
+// Only rounds of the shape the schedule of Q:682-689 produces carry merged diagonals (FUSE_QROUND below); everywhere
+// else the planner puts the original phases back, and those -- like every Hadamard outside a fast round and the modular
+// multiplies -- run through the exact interpreter, same bits as in modes 0 / 1.
+// ---------------------------------------------------------------------------
+// The schedule of Q:682-689 gives rounds of the shape  H(x) D(x) H(y) D(y)  (x, y = the round's register bits, D(b) = a
+// merged diagonal whose control is b).  The host recognises them (FUSE_QROUND: header + ONE record with two step words)
+// and the kernel runs them as straight-line code: every table read of the round is issued up front, nothing is fetched
+// between the butterflies.  Step word: bit 0 = the step's bit is rb1, bit 1 = a diagonal follows the H, bits 8-15 its
+// slot, bits 16-18 its groups, bit 19 = the round's OTHER register bit is one of its targets; 0xffffffff = no step.
+enum : uint32_t { FUSE_DIAG = 6, FUSE_QROUND = 7 };
+struct DiagInfo { uint32_t field_off[5]; uint32_t present; uint32_t pad[2]; };      // 32 B; offsets in 16-B units from the table area
+
+__device__ __forceinline__ void cmul_tol(amp_t &v, const amp_t w)        // v *= w, 2 mul + 2 fma
+{
+    const double nx = __builtin_fma(w.x, v.x, -(w.y * v.y));
+    const double ny = __builtin_fma(w.x, v.y, w.y * v.x);
+    v.x = nx; v.y = ny;
+}
+__device__ __forceinline__ void h_butterfly_tol(amp_t &a, amp_t &b)
+{
+    const double s = QCX_SQRT1_2;
+    const double t0r = s * a.x, t0i = s * a.y, t1r = s * b.x, t1i = s * b.y;
+    a.x = t0r + t1r;  a.y = t0i + t1i;
+    b.x = t0r - t1r;  b.y = t0i - t1i;
+}
+
+// factors of one step of a fast round: F for the register whose other register bit is clear, F3 for the one where it is set
+__device__ __forceinline__ void qround_factors(uint32_t s, unsigned p, unsigned rb0, unsigned rb1, const amp_t *dg, const amp_t *gtab,
+                                               amp_t &F, amp_t &F3)
+{
+    const unsigned slot = (s >> 8) & 0xffu;
+    const amp_t *G = gtab + slot * 48u;
+    F = dg[slot];
+    if (s & (1u << 16)) cmul_tol(F, G[p & 15u]);
+    if (s & (1u << 17)) cmul_tol(F, G[16u + ((p >> 4) & 15u)]);
+    if (s & (1u << 18)) cmul_tol(F, G[32u + (p >> 8)]);
+    F3 = F;
+    if (s & (1u << 19)) {
+        const unsigned ob = (s & 1u) ? rb0 : rb1;
+        cmul_tol(F3, G[16u * (ob >> 2) + (1u << (ob & 3u))]);
+    }
+}
+
+// one step of a fast round on fixed registers: H between (lo0, hi0) and (lo1, hi1), then (dgl) the diagonal on the two
+// amplitudes that have the step's bit set
+__device__ __forceinline__ void qround_step(bool dgl, amp_t &lo0, amp_t &hi0, amp_t &lo1, amp_t &hi1, const amp_t F, const amp_t F3)
+{
+    h_butterfly_tol(lo0, hi0); h_butterfly_tol(lo1, hi1);
+    if (dgl) { cmul_tol(hi0, F); cmul_tol(hi1, F3); }
+}
+
+// a whole fast round with the bit of each step fixed at compile time (HA / HB: the step works on rb1), from the LDS reads
+// to the LDS writes: written once per combination so that which register a step touches is never a run-time choice (a
+// run-time choice makes the compiler keep the four amplitudes in scratch memory and index them)
+template <bool HA, bool HB>
+__device__ __forceinline__ void qround_run(amp_t *tile, unsigned p, unsigned e1, unsigned e2, unsigned e3, unsigned rb0, unsigned rb1,
+                                           uint32_t sA, uint32_t sB, const amp_t *dg, const amp_t *gtab)
+{
+    amp_t F, F3;
+    F.x = F3.x = 1.0; F.y = F3.y = 0.0;
+    const bool dA = (sA & 2u) != 0, two = sB != 0xffffffffu, dB = two && (sB & 2u);
+    amp_t v0 = tile[p], v1 = tile[e1], v2 = tile[e2], v3 = tile[e3];
+    if (dA) qround_factors(sA, p, rb0, rb1, dg, gtab, F, F3);
+    if (HA) qround_step(dA, v0, v2, v1, v3, F, F3); else qround_step(dA, v0, v1, v2, v3, F, F3);
+    __builtin_amdgcn_sched_barrier(0);          // (keeps the second step's table reads out of the first step's registers)
+    if (two) {
+        if (dB) qround_factors(sB, p, rb0, rb1, dg, gtab, F, F3);
+        if (HB) qround_step(dB, v0, v2, v1, v3, F, F3); else qround_step(dB, v0, v1, v2, v3, F, F3);
+    }
+    tile[p] = v0; tile[e1] = v1; tile[e2] = v2; tile[e3] = v3;
+}
+
+template <int BLOCK, int TT, bool CAM = true, int TOL = 0>     // CAM = false: the pass holds no modular multiply (smaller kernel); TOL: 1 tolerance mode, 2 fast rounds only
 __device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, unsigned short *lut, const unsigned char *camtab,
                                                   const uint64_t *xm, const FusePass &P, const FuseOp *__restrict__ ops,
-                                                  const FuseOp *ops_asm, uint64_t base)
+                                                  const FuseOp *ops_asm, uint64_t base, const amp_t *dg = nullptr)
 {
     static_assert((1u << TT) == 4u * BLOCK, "rounds form needs 4 amplitudes per thread");
     unsigned i = 0;
     while (i < P.nops) {
         const uint32_t type = ops[i].type & 0xffu;
-        if (type == FUSE_ROUND) {
+        if (TOL && type == FUSE_QROUND) {
+            // tolerance mode, fast round  H(x) [D(x)] [H(y) [D(y)]]: straight-line, every table read issued up front
+            const amp_t *gtab = dg + P.dg_cnt;                      // behind the per-tile E_out slots
+            const unsigned rb0 = ops[i].a & 0xffu, rb1 = (ops[i].a >> 8) & 0xffu;
+            const uint32_t sA = ops[i + 1].type, sB = ops[i + 1].a;
+            const unsigned p = (unsigned)insert_zero(insert_zero(threadIdx.x, rb0), rb1);
+            const unsigned e1 = p | (1u << rb0), e2 = p | (1u << rb1), e3 = e1 | (1u << rb1);
+            if (sA & 1u) { if (sB & 1u) qround_run<true, true>(tile, p, e1, e2, e3, rb0, rb1, sA, sB, dg, gtab);
+                           else         qround_run<true, false>(tile, p, e1, e2, e3, rb0, rb1, sA, sB, dg, gtab); }
+            else         { if (sB & 1u) qround_run<false, true>(tile, p, e1, e2, e3, rb0, rb1, sA, sB, dg, gtab);
+                           else         qround_run<false, false>(tile, p, e1, e2, e3, rb0, rb1, sA, sB, dg, gtab); }
+            __syncthreads();
+            i += 2;
+        } else if (TOL != 2 && type == FUSE_ROUND) {
             const unsigned rb0 = ops[i].a & 0xffu, rb1 = (ops[i].a >> 8) & 0xffu;
             const unsigned cnt = (unsigned)ops[i].mask;
             const unsigned p = (unsigned)insert_zero(insert_zero(threadIdx.x, rb0), rb1);
@@ -1156,131 +1255,6 @@ __device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, unsigned short *l
     }
 }
 
-
-// ---------------------------------------------------------------------------
-// K6t  TOLERANCE MODE of the rounds form (qcx_set_fusion(reg, 2); opt-in, NOT bit-exact: amplitudes agree with the
-// reference to ~1e-15, north_star allows 1e-10).  The planner merges every run of consecutive controlled phases that
-// share a control qubit l into ONE diagonal (SURVEY s8(f)-2: Q:682-689 applies l - M of them after each Hadamard):
-//     amp[i] *= prod over the targets k with bit k of i set of (c_k + i s_k),     for every i with bit l set.
-// The product splits over where the target bits live:
-//     E_out(tile)        targets outside the tile: a per-tile constant.  One thread per diagonal builds it at tile start
-//                        (while the LDS-DMA fill is in flight) from <= 5 tables of 256 entries indexed by the bytes of the
-//                        tile's base index (global memory, L2-resident), and leaves it in LDS;
-//     G0 G1 G2 (thread)  targets on tile-local bits, 4 local bits per table, 16 entries each, in LDS (768 B per diagonal);
-//                        the entry for a single set bit is that bit's own factor, so the factors of the round's two
-//                        register bits are read from the same tables.
-// A thread then multiplies the (at most four) amplitudes whose control bit is set by F, F w0, F w1, F w0 w1: one complex
-// multiply per amplitude instead of one rotation per gate per amplitude, FMA allowed.  Plain phases that could not be
-// merged, Hadamards and the modular multiplies run as in the exact form (without the canonical-zero bookkeeping: the
-// sign of a zero is below any tolerance).
-// Records: FUSE_DIAG  a = (tile-local control bit + 1, 0 = outside/none) | slot << 8 | groups with targets << 16,
-//                     mask = outside control bit, c = (bit pattern) tile-local target mask.
-// ---------------------------------------------------------------------------
-enum : uint32_t { FUSE_DIAG = 6 };
-struct DiagInfo { uint32_t field_off[5]; uint32_t present; uint32_t pad[2]; };      // 32 B; offsets in 16-B units from the table area
-
-__device__ __forceinline__ void cmul_tol(amp_t &v, const amp_t w)        // v *= w, 2 mul + 2 fma
-{
-    const double nx = __builtin_fma(w.x, v.x, -(w.y * v.y));
-    const double ny = __builtin_fma(w.x, v.y, w.y * v.x);
-    v.x = nx; v.y = ny;
-}
-__device__ __forceinline__ void h_butterfly_tol(amp_t &a, amp_t &b)
-{
-    const double s = QCX_SQRT1_2;
-    const double t0r = s * a.x, t0i = s * a.y, t1r = s * b.x, t1i = s * b.y;
-    a.x = t0r + t1r;  a.y = t0i + t1i;
-    b.x = t0r - t1r;  b.y = t0i - t1i;
-}
-
-template <int BLOCK, int TT, bool CAM>
-__device__ __forceinline__ void fuse_apply_rounds_tol(amp_t *tile, unsigned short *lut, const unsigned char *camtab,
-                                                      const amp_t *dg, const FusePass &P, const FuseOp *__restrict__ ops, uint64_t base)
-{
-    static_assert((1u << TT) == 4u * BLOCK, "rounds form needs 4 amplitudes per thread");
-    const amp_t *gtab = dg + P.dg_cnt;                          // behind the per-tile E_out slots
-    unsigned i = 0;
-    while (i < P.nops) {
-        const uint32_t type = ops[i].type & 0xffu;
-        if (type == FUSE_ROUND) {
-            const unsigned rb0 = ops[i].a & 0xffu, rb1 = (ops[i].a >> 8) & 0xffu;
-            const unsigned cnt = (unsigned)ops[i].mask;
-            const unsigned p = (unsigned)insert_zero(insert_zero(threadIdx.x, rb0), rb1);
-            const unsigned e1 = p | (1u << rb0), e2 = p | (1u << rb1), e3 = e1 | (1u << rb1);
-            amp_t v0 = tile[p], v1 = tile[e1], v2 = tile[e2], v3 = tile[e3];
-            unsigned o = i + 1;
-            const unsigned oend = i + cnt;
-            while (o <= oend) {
-                const uint32_t t = ops[o].type;
-                const uint32_t kind = t & 0xffu;
-                if (kind == FUSE_H) {
-                    if ((t >> 8) & 1u) { h_butterfly_tol(v0, v2); h_butterfly_tol(v1, v3); }
-                    else               { h_butterfly_tol(v0, v1); h_butterfly_tol(v2, v3); }
-                    o++;
-                } else if (kind == FUSE_PRUN) {
-                    const unsigned rc = t >> 16;
-                    for (unsigned g = 1; g <= rc; g++) {
-                        const uint64_t mext = ops[o + g].mask;
-                        if ((base & mext) != mext) continue;
-                        const uint32_t rsel = (ops[o + g].type >> 8) & 15u, mloc = ops[o + g].a;
-                        amp_t w; w.x = ops[o + g].c; w.y = ops[o + g].s;
-                        if ((p & mloc) == mloc) {
-                            if (rsel & 1u) cmul_tol(v0, w);
-                            if (rsel & 2u) cmul_tol(v1, w);
-                            if (rsel & 4u) cmul_tol(v2, w);
-                            if (rsel & 8u) cmul_tol(v3, w);
-                        }
-                    }
-                    o += 1 + rc;
-                } else {                                            // FUSE_DIAG
-                    const uint64_t mext = ops[o].mask;
-                    if ((base & mext) == mext) {
-                        const uint32_t a = ops[o].a;
-                        const int cl = (int)(a & 0xffu) - 1;
-                        const unsigned slot = (a >> 8) & 0xffu, groups = (a >> 16) & 7u;
-                        const uint64_t tloc = (uint64_t)__double_as_longlong(ops[o].c);
-                        const amp_t *G = gtab + slot * 48u;
-                        amp_t F = dg[slot];                                     // E_out of this tile
-                        if (groups & 1u) cmul_tol(F, G[p & 15u]);
-                        if (groups & 2u) cmul_tol(F, G[16u + ((p >> 4) & 15u)]);
-                        if (groups & 4u) cmul_tol(F, G[32u + (p >> 8)]);
-                        const bool t0 = (tloc >> rb0) & 1u, t1 = (tloc >> rb1) & 1u;
-                        amp_t w0, w1;                                           // uniform LDS reads (only where needed)
-                        if (t0) w0 = G[16u * (rb0 >> 2) + (1u << (rb0 & 3u))];
-                        if (t1) w1 = G[16u * (rb1 >> 2) + (1u << (rb1 & 3u))];
-                        if (cl == (int)rb1) {                                   // the usual case: the H just before was on rb1
-                            amp_t F3 = F;
-                            if (t0) cmul_tol(F3, w0);
-                            cmul_tol(v2, F); cmul_tol(v3, F3);
-                        } else if (cl == (int)rb0) {
-                            amp_t F3 = F;
-                            if (t1) cmul_tol(F3, w1);
-                            cmul_tol(v1, F); cmul_tol(v3, F3);
-                        } else if (cl < 0 || ((p >> cl) & 1u)) {
-                            amp_t F1 = F, F2 = F;
-                            if (t0) cmul_tol(F1, w0);
-                            if (t1) cmul_tol(F2, w1);
-                            amp_t F3 = F1;
-                            if (t1) cmul_tol(F3, w1);
-                            cmul_tol(v0, F); cmul_tol(v1, F1); cmul_tol(v2, F2); cmul_tol(v3, F3);
-                        }
-                    }
-                    o++;
-                }
-            }
-            tile[p] = v0; tile[e1] = v1; tile[e2] = v2; tile[e3] = v3;
-            __syncthreads();
-            i += 1 + cnt;
-        } else if (CAM && type == FUSE_CAMRUN) {
-            i += 1 + fuse_camrun_step<BLOCK, TT>(tile, lut, camtab, ops, i, base);
-        } else if (CAM) {
-            fuse_camodc_step<BLOCK, 4>(tile, lut, ops + i, base, 1u << TT);
-            i++;
-        } else {
-            __builtin_unreachable();
-        }
-    }
-}
 
 template <int BLOCK, int TT, bool LDSDMA>   // TT = tile bits when known at compile time (loops unroll, loads batch); 0 = generic
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void k_fused(amp_t *__restrict__ amp, unsigned n, FusePass P,
@@ -1363,7 +1337,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void
 // store phases of the resident workgroups overlap each other; measured, that beats the double-buffered pipeline
 // inside one workgroup (the round-1 pipelined form, removed) as soon as enough workgroups are resident, so this kernel carries nothing but
 // the rounds interpreter and is held to OCC waves per SIMD.
-template <int BLOCK, int TT, int OCC, bool CAM, bool TOL = false>
+template <int BLOCK, int TT, int OCC, bool CAM, int TOL = 0>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) void k_fused_rounds(
     amp_t *__restrict__ amp, unsigned n, FusePass P, const FuseOp *__restrict__ ops, uint64_t ntiles, const FuseOp *ops_asm)
 {
@@ -1376,7 +1350,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
     for (unsigned b = threadIdx.x; b < (unsigned)P.cam_ctl_local[1]; b += BLOCK)
         camtab[b] = reinterpret_cast<const unsigned char *>(ops + P.cam_ctl_local[2])[b];
     uint64_t *xm = reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(lut) + P.xm_off);
-    for (unsigned b = threadIdx.x; b < P.xm_cnt + 66u; b += BLOCK) xm[b] = b < P.xm_cnt ? ops[b].mask : 0;    // + padding
+    if constexpr (TOL != 2)
+        for (unsigned b = threadIdx.x; b < P.xm_cnt + 66u; b += BLOCK) xm[b] = b < P.xm_cnt ? ops[b].mask : 0;    // + padding
     // tolerance mode: [E_out slot per diagonal][G tables, 48 entries per diagonal] in LDS; the tables are staged once
     amp_t *dg = reinterpret_cast<amp_t *>(reinterpret_cast<unsigned char *>(lut) + P.dg_lds_off);
     const amp_t *dg_area = reinterpret_cast<const amp_t *>(ops + P.dg_rec_off);             // global: DiagInfo[], G tables, field tables
@@ -1395,7 +1370,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
 #pragma unroll
     for (unsigned k = 0; k < 4; k++) off_k[k] = scatter(k * BLOCK);
     const unsigned wbase = (threadIdx.x >> 6) * 64;
-    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // swz = s > 0: workgroups that share an XCD (blockIdx mod 8 under round-robin placement) take 2^s NEIGHBOURING tiles
+    // instead of every eighth one -- their runs are then adjacent in memory (speed only; any order is correct)
+    const unsigned swz = (P.dbg >> 8) & 7u;
+    for (uint64_t t0 = blockIdx.x; t0 < ntiles; t0 += gridDim.x) {
+        uint64_t t = t0;
+        if (swz && !((ntiles | gridDim.x) & ((8u << swz) - 1u))) {
+            const uint64_t xcd = t0 & 7u, slot = t0 >> 3, in = slot & ((1u << swz) - 1u), grp = slot >> swz;
+            t = (((grp << 3) | xcd) << swz) | in;
+        }
         uint64_t base = t << c;
         for (unsigned j = 0; j < nh; j++) base = insert_zero(base, P.hbit[j]);
         amp_t *g = amp + (base | off_t);
@@ -1419,10 +1402,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if constexpr (TOL) {
-            if (!(P.dbg & 1u)) fuse_apply_rounds_tol<BLOCK, TT, CAM>(tile, lut, camtab, dg, P, ops, base);
-        } else
-        if (!(P.dbg & 1u)) fuse_apply_rounds<BLOCK, TT, CAM>(tile, lut, camtab, xm, P, ops, ops_asm, base);
+        if (!(P.dbg & 1u)) fuse_apply_rounds<BLOCK, TT, CAM, TOL>(tile, lut, camtab, xm, P, ops, ops_asm, base, dg);
         amp_t v[4];
 #pragma unroll
         for (unsigned k = 0; k < 4; k++) v[k] = tile[k * BLOCK + threadIdx.x];

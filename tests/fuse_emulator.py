@@ -12,7 +12,7 @@ import struct
 
 import numpy as np
 
-FUSE_H, FUSE_PHASE, FUSE_CAMODC, FUSE_ROUND, FUSE_PRUN, FUSE_CAMRUN, FUSE_DIAG = 0, 1, 2, 3, 4, 5, 6
+FUSE_H, FUSE_PHASE, FUSE_CAMODC, FUSE_ROUND, FUSE_PRUN, FUSE_CAMRUN, FUSE_DIAG, FUSE_QROUND = 0, 1, 2, 3, 4, 5, 6, 7
 SQRT1_2 = 0.70710678118654752440
 
 
@@ -240,6 +240,32 @@ def apply_pass(state, n, act, recs):
                 if has_h:
                     re += 0.0; im += 0.0
                 i += 1 + cnt
+            elif t == FUSE_QROUND and nd:
+                # tolerance mode fast round: H(x) [D(x)] [H(y) [D(y)]] on the two register bits, two step words in the next record
+                rb0, rb1, ns = r.a & 0xFF, (r.a >> 8) & 0xFF, (r.a >> 16) & 0xFF
+                assert rb0 < rb1 < P.T and int(r.mask) == 1 and 1 <= ns <= 2
+                steps = [R[i + 1].type, R[i + 1].a]
+                assert (steps[1] == 0xFFFFFFFF) == (ns == 1)
+                stats["rounds"] += 1
+                for sw in steps[:ns]:
+                    hb, ob = (rb1, rb0) if sw & 1 else (rb0, rb1)
+                    _h(re, im, P.gbit(hb), False); stats["h"] += 1
+                    if sw & 2:
+                        slot, groups, t_other = (sw >> 8) & 0xFF, (sw >> 16) & 7, (sw >> 19) & 1
+                        # the same diagonal through the generic record: control = the H's bit, local target mask from the tables
+                        G = area[2 * nd + 48 * slot: 2 * nd + 48 * (slot + 1)]
+                        tloc = 0
+                        for lb in range(12):
+                            if G[16 * (lb >> 2) + (1 << (lb & 3))] != 1.0:
+                                tloc |= 1 << lb
+                        assert ((tloc >> ob) & 1) <= t_other, "a target on the other register bit must be flagged"
+                        if not t_other:
+                            assert G[16 * (ob >> 2) + (1 << (ob & 3))] == 1.0
+                        class Rec: pass
+                        rec = Rec(); rec.a = (hb + 1) | (slot << 8) | (groups << 16); rec.mask = 0
+                        rec.c = struct.unpack("<d", struct.pack("<Q", tloc))[0]
+                        _diag(P, re, im, rec, area, nd); stats["diags"] += 1
+                i += 2
             elif t == FUSE_CAMRUN:
                 i += 1 + _camrun(P, re, im, R, i, blob)
             elif t == FUSE_CAMODC:

@@ -101,6 +101,7 @@ struct Tune {
     long fuse_grid_cap = 24576; // workgroups of the one-tile-per-workgroup form (each walks several tiles: the table fill at kernel start is amortised)
     long fuse_qround = 1;      // tolerance mode: rounds of the shape H D H D run as straight-line code (FUSE_QROUND)
     long fuse_swz = 0;         // rounds kernel: workgroups of one XCD take 2^this neighbouring tiles (0: tile = blockIdx)
+    long fuse_front = 1;       // a pending reset / collapse is written together with the closed-form front of the queue (K0b)
     long fuse_tol_T = 10;      // tolerance mode: tile bits of diagonal passes when that costs no extra pass (0: same as the rest)
     long fuse_tol_occ = 6;     // tolerance-mode passes (merged diagonals): waves per SIMD the kernel is built for (6 or 8)
     long fuse_rounds_occ = 8;  // rounds-form passes: k_fused_rounds built for this many waves per SIMD (6, 7, 8; 0 = the general kernel)
@@ -126,7 +127,7 @@ static Tune tune_now() { std::lock_guard<std::mutex> lock(g_tune_mutex); return 
 extern "C" int qcx_tune_set(const char *key, long value)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); g_tune.name = value; return QCX_NO_ERROR; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front)
 #undef K
     return QCX_BAD_ARGUMENTS;
 }
@@ -134,7 +135,7 @@ extern "C" int qcx_tune_set(const char *key, long value)
 extern "C" long qcx_tune_get(const char *key)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); return g_tune.name; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front)
 #undef K
     return -1;
 }
@@ -667,6 +668,9 @@ struct qcx_register {
     int        fusion;          // 1: every gate call is queued (fused passes, qcx_fuse.inc.h); 0: only the whole-circuit entry points; -1: nothing
     int        composite;       // > 0 while a whole-circuit entry point is queueing its gates
     struct GateQueue *queue;
+    int        basis_pending;   // the state IS the basis state basis_index (reset / collapse) but has not been written yet:
+    uint64_t   basis_index;     // the next flush writes it, together with a closed-form gate prefix if the queue has one
+    unsigned long fronts;       // basis-state fronts executed as one write pass (K0b)
     struct ShardSet *sh;     // non-null: the register is sharded over several GPUs by this process (qcx_sharded.inc.h)
 };
 
@@ -1067,7 +1071,7 @@ extern "C" int qcx_fusion_stats(qcx_register *r, unsigned long *passes, unsigned
 {
     if (!r) return QCX_BAD_ARGUMENTS;
     if (r->sh) { if (passes) *passes = 0; if (gates) *gates = 0; return QCX_NO_ERROR; }     // (per-device queues: see qcx_sharded_stats)
-    if (passes) *passes = r->queue ? r->queue->passes_launched : 0;
+    if (passes) *passes = (r->queue ? r->queue->passes_launched : 0) + r->fronts;
     if (gates) *gates = r->queue ? r->queue->gates_fused : 0;
     return QCX_NO_ERROR;
 }
@@ -1096,6 +1100,11 @@ extern "C" int qcx_reset_register(qcx_register *r)
     if (!r) return QCX_BAD_ARGUMENTS;
     if (r->sh) return sh_reset(r->sh);
     if (r->queue) r->queue->gates.clear();         // pending gates act on a state that is being overwritten
+    if (r->fusion >= 0 && r->n >= 1) {             // lazily: the write happens at the next flush, fused with the circuit front (K0b)
+        r->basis_pending = 1; r->basis_index = 1;
+        return QCX_NO_ERROR;
+    }
+    r->basis_pending = 0;
     return qcx_shard_reset(r->amp, r->n, 1, r->stream);
 }
 
@@ -1105,6 +1114,7 @@ extern "C" int qcx_hadamard_gate(unsigned q, qcx_register *r)
     if (q >= r->n) return QCX_BAD_QUBIT;
     if (r->sh) { SGate g; memset(&g, 0, sizeof g); g.type = FUSE_H; g.q = q; return sh_push(r->sh, g); }
     if (r->fusion > 0 || r->composite) { QGate g; memset(&g, 0, sizeof g); g.type = FUSE_H; g.q = q; return fuse_push(r, g); }
+    FLUSH(r);                                         // (a lazily pending reset / collapse is written first)
     return qcx_shard_hadamard(r->amp, r->n, q, r->stream);
 }
 
@@ -1132,6 +1142,7 @@ extern "C" int qcx_c_phase_shift_gate(unsigned c, unsigned t, double theta, qcx_
         g.type = FUSE_PHASE; g.mask = ((uint64_t)1 << c) | ((uint64_t)1 << t); g.c = er; g.s = ei;
         return fuse_push(r, g);
     }
+    FLUSH(r);
     return qcx_shard_phase(r->amp, r->n, ((uint64_t)1 << c) | ((uint64_t)1 << t), er, ei, r->stream);
 }
 
@@ -1146,6 +1157,7 @@ extern "C" int qcx_c_amodc_gate(unsigned C, unsigned long long atox, unsigned c,
         g.type = ((unsigned)r->M <= 12 && camodc_closed_form(r->n, (unsigned)r->M, C, g.A, c)) ? (uint32_t)FUSE_CAMODC : 99u;
         return fuse_push(r, g);
     }
+    FLUSH(r);
     return reg_camodc(r, C, (unsigned)(atox % C), c);
 }
 
@@ -1228,7 +1240,8 @@ extern "C" int qcx_measure_state_r(qcx_register *r, double rnd, unsigned long *s
     int found = 0; uint64_t idx = 0; double cum = 0.0;
     QCX_TRY(qcx_shard_measure_scan(r->amp, r->n, 0, r->dim - 1, 0.0, rnd, &found, &idx, &cum, r->stream));
     if (!found) idx = r->dim - 1;                                           // Q:283 fall-through
-    QCX_TRY(qcx_shard_collapse(r->amp, r->n, (int64_t)idx, r->stream));     // Q:302-303
+    if (r->fusion >= 0) { r->basis_pending = 1; r->basis_index = idx; }     // Q:302-303, written at the next flush (or never: a reset may follow)
+    else QCX_TRY(qcx_shard_collapse(r->amp, r->n, (int64_t)idx, r->stream));
     *state_num = (unsigned long)idx;
     return QCX_NO_ERROR;
 }
@@ -1390,6 +1403,7 @@ extern "C" int qcx_state_fill_random(qcx_register *r, uint64_t seed)
     if (!r) return QCX_BAD_ARGUMENTS;
     if (r->sh) return sh_fill_random(r->sh, seed);
     if (r->queue) r->queue->gates.clear();
+    r->basis_pending = 0;                           // everything is overwritten
     // U(-0.5, 0.5) components have variance 1/12: this scale makes the expected norm 1
     return qcx_shard_fill_random(r->amp, r->n, 0, seed, sqrt(6.0 / (double)r->dim), r->stream);
 }

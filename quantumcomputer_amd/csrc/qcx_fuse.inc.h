@@ -658,9 +658,55 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
 
 // plan -> upload every pass's records in one copy -> launch in order.  No host synchronisation except waiting for
 // the PREVIOUS flush's kernels before its record buffers are reused.
+// The register is the basis state r->basis_index but nothing has been written yet (lazy reset / collapse).  Write it now --
+// together with the longest prefix of the queue that has a closed form on a basis state: Hadamards on distinct qubits, then
+// controlled modular multiplies (K0b, k_basis_front; the front of Q:712-737 is exactly that).  *used = gates consumed.
+static int basis_front(qcx_register *r, const std::vector<QGate> &gates, size_t *used)
+{
+    *used = 0;
+    const unsigned n = r->n, M = (unsigned)r->M;
+    r->basis_pending = 0;
+    const Tune tn = tune_now();
+    size_t k = 0;
+    uint64_t hmask = 0;
+    unsigned nh = 0;
+    const uint64_t lowmask = ((uint64_t)1 << M) - 1;
+    BasisFront B; memset(&B, 0, sizeof B);
+    if (tn.fuse_front && n >= M + 6 && M <= 12) {
+        while (k < gates.size() && gates[k].type == FUSE_H && !((hmask >> gates[k].q) & 1)) { hmask |= (uint64_t)1 << gates[k].q; nh++; k++; }
+        if (!(hmask & lowmask))
+            while (k < gates.size() && gates[k].type == FUSE_CAMODC && gates[k].q != 0xffffffffu && B.ncam < 64) {
+                B.C[B.ncam] = gates[k].C; B.A[B.ncam] = gates[k].A % gates[k].C; B.ctl[B.ncam] = (uint8_t)gates[k].q; B.ncam++; k++;
+            }
+    }
+    if (k == 0) {                                                       // nothing to fuse: the plain write
+        if (r->basis_index == 1) return qcx_shard_reset(r->amp, n, 1, r->stream);
+        return qcx_shard_collapse(r->amp, n, (int64_t)r->basis_index, r->stream);
+    }
+    const uint64_t nmask = (n >= 64) ? ~(uint64_t)0 : (((uint64_t)1 << n) - 1);
+    B.basis = r->basis_index; B.hmask = hmask; B.M = M;
+    B.fixed_mask = ~hmask & ~lowmask & nmask;
+    B.sign_mask = r->basis_index & hmask;
+    double v = 1.0;
+    for (unsigned q = 0; q < nh; q++) v = QCX_SQRT1_2 * v;              // fl(s * v), one rounding per Hadamard like the kernels
+    B.v = v;
+    const uint64_t nwaves = ((uint64_t)1 << n) >> (6 + M);
+    hipLaunchKernelGGL(k_basis_front, dim3(grid_for(nwaves, 4, 65536, 256)), dim3(256), 0, r->stream, r->amp, n, B);
+    HIP_TRY(hipGetLastError());
+    r->fronts++;
+    *used = k;
+    return QCX_NO_ERROR;
+}
+
 static int fuse_flush(qcx_register *r)
 {
     GateQueue *gq = r->queue;
+    if (r->basis_pending) {
+        static const std::vector<QGate> none;
+        size_t used = 0;
+        QCX_TRY(basis_front(r, gq ? gq->gates : none, &used));
+        if (used) { gq->gates.erase(gq->gates.begin(), gq->gates.begin() + used); gq->gates_fused += used; }
+    }
     if (!gq || gq->gates.empty()) return QCX_NO_ERROR;
     std::vector<QGate> gates;
     gates.swap(gq->gates);                       // the queue is empty from here on (re-entrancy safe)

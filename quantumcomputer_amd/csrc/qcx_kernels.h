@@ -1424,6 +1424,69 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
 // vector-memory operations; DESIGN.md s4 has the numbers of that experiment.)
 
 // ---------------------------------------------------------------------------
+// K0b  the circuit front on a BASIS state, in one write pass.  After reset_register (Q:318-324) -- or a measurement's
+// collapse (Q:302-303) -- the register holds one amplitude (1, 0) at index b.  A prefix of the queued gates of the shape
+//     H on distinct qubits (the set Hm)  then  controlled modular multiplies          (Q:720-731 is exactly that)
+// has a closed form with the reference's own roundings:
+//   * each H multiplies the populated amplitudes by s = M_SQRT1_2 ONCE MORE (the pair partner is an exact zero, so the
+//     reference's (s*a +/- s*0) + 0 is fl(s*a) with sign -1 on the "1" side when the basis bit was 1): after k of them
+//     every populated amplitude is +/- v_k, v_k = fl(s * v_(k-1)), v_0 = 1, sign = parity of (i & b & Hm);
+//   * a modular multiply moves the one populated residue f of every 2^M block to (A f) mod C when its control bit is 1
+//     and f < C (all other sources of that destination are exact zeros: 0 + ... + v = v), so after the ladder block x
+//     holds its amplitude at f(x), the chain over the gates in issue order.
+// The kernel writes EVERY amplitude of the shard once (the zeros too: it replaces the 16 * 2^n-byte memset of the reset),
+// 16 * 2^n bytes instead of one read + write per Hadamard pass.  A wave owns 64 blocks: lane l walks the chain of block l,
+// then the wave writes the 64 * 2^M amplitudes with coalesced 1-KiB stores, fetching each store's residues by shuffle.
+// ---------------------------------------------------------------------------
+struct BasisFront {
+    uint64_t basis, hmask, fixed_mask;      // populated blocks: (i & fixed_mask) == (basis & fixed_mask)
+    uint64_t sign_mask;                     // sign = parity of popcount(i & sign_mask)
+    double   v;                             // magnitude after the Hadamards
+    unsigned M, ncam;                       // M = 0 and ncam = 0: no block structure (every amplitude is its own block)
+    uint32_t C[64], A[64];
+    uint8_t  ctl[64];
+};
+
+__global__ __launch_bounds__(256) void k_basis_front(amp_t *__restrict__ amp, unsigned n, BasisFront B)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned M = B.M;
+    const uint64_t ntiles = ((uint64_t)1 << n) >> (6 + M);          // host guarantees n >= M + 6
+    const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
+    const unsigned lowmask = (1u << M) - 1u;
+    for (uint64_t t = wave; t < ntiles; t += nwaves) {
+        const uint64_t tile0 = t << (6 + M);
+        // lane l: block l of the tile
+        const uint64_t bi = tile0 + ((uint64_t)lane << M);
+        unsigned f = (unsigned)(B.basis & lowmask);
+        bool pop = (bi & B.fixed_mask) == (B.basis & B.fixed_mask);
+        for (unsigned g = 0; g < B.ncam; g++)
+            if (((bi >> B.ctl[g]) & 1u) && f < B.C[g]) f = (B.A[g] * f) % B.C[g];
+        const int fcode = pop ? (int)f : -1;
+        const unsigned sgn_blk = (unsigned)__builtin_popcountll(bi & B.sign_mask) & 1u;
+        for (unsigned j = 0; j < (1u << M); j++) {
+            const unsigned e = j * 64u + lane;                      // element of the tile this lane stores
+            const unsigned src = e >> M;                            // its block
+            const int fc = __shfl(fcode, (int)src, 64);
+            const unsigned sb = (unsigned)__shfl((int)sgn_blk, (int)src, 64);
+            const unsigned low = e & lowmask;
+            amp_t v; v.x = 0.0; v.y = 0.0;
+            if (fc >= 0) {
+                // with a block structure (ncam > 0, or M bits outside the Hadamard set) the low bits must equal the residue;
+                // low bits inside the Hadamard set are free (then ncam == 0 and fixed_mask covers the rest)
+                const unsigned free_low = (unsigned)(B.hmask & lowmask);
+                const bool hit = ((low ^ (unsigned)fc) & ~free_low) == 0;
+                if (hit) {
+                    const unsigned sg = (sb ^ ((unsigned)__builtin_popcount(low & (unsigned)(B.sign_mask & lowmask)) & 1u));
+                    v.x = sg ? -B.v : B.v;
+                }
+            }
+            __builtin_nontemporal_store(v, amp + tile0 + e);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // X1  local index-bit permutation (pack pass of the sharded qubit remap): dst[j] = src[j with the bit
 // pairs (a_m, b_m) exchanged].  Out of place, coalesced stores, gathered loads (runs of 2^min(a, b)).
 // ---------------------------------------------------------------------------

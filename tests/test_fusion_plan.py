@@ -14,7 +14,7 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 
 
-TUNE_KEYS = ("fuse_T", "fuse_c", "fuse_rounds", "fuse_camruns", "fuse_T_phase", "fuse_c_phase", "fuse_phase_ratio")
+TUNE_KEYS = ("fuse_T", "fuse_c", "fuse_rounds", "fuse_camruns", "fuse_T_phase", "fuse_c_phase", "fuse_phase_ratio", "fuse_tol_T")
 
 
 @pytest.fixture()
@@ -192,7 +192,7 @@ def max_delta(a, b):
 def test_tolerance_mode_iqft_merges_every_run_into_one_diagonal(qc, ob, tune_guard, n, M, T, c):
     if T > n:
         pytest.skip("tile larger than the register")
-    qc.tune(fuse_T=T, fuse_c=c, fuse_T_phase=0)
+    qc.tune(fuse_T=T, fuse_c=c, fuse_T_phase=0, fuse_tol_T=0)         # the geometry under test, not the planner's own choice
     descs = iqft_descs(qc, n, M)
     L = n - M
     acts, recs, _ = qc.fusion_plan(n, M, descs, mode=2)
@@ -259,6 +259,20 @@ def test_tolerance_mode_random_programs(qc, ob, tune_guard, seed):
     oracle_run(ob, want, n, M, Cn, steps)
     emu.run_plan(state, n, M, descs, acts, recs, ob)
     assert max_delta(state, want) <= TOL, (n, M, T, c)
+
+
+def test_tolerance_mode_plan_of_the_n28_iqft(qc, tune_guard):
+    """config 3 in tolerance mode: 28 H + 378 phases -> 4 passes of fast rounds only (slim kernel), 27 diagonals, on 2^10
+    tiles (the smaller tile costs no pass here)"""
+    n = 28
+    descs = iqft_descs(qc, n, 0)
+    actions, recs, nrec = qc.fusion_plan(n, 0, descs, mode=2)
+    assert [a.fused for a in actions] == [1, 1, 1, 1] and sum(a.ngates for a in actions) == 406
+    assert [(a.T, a.c) for a in actions] == [(10, 4)] * 4
+    assert sum(a.diag_cnt for a in actions) == 27
+    for a in actions:
+        kinds = {recs[a.rec_off + k].type & 0xFF for k in range(0, a.nops, 2)}
+        assert kinds == {emu.FUSE_QROUND}, kinds
 
 
 def test_mode_1_plan_is_unchanged_by_the_tolerance_code(qc, ob, tune_guard):

@@ -1,0 +1,136 @@
+"""GPU: the circuit front on a basis state as ONE write pass (K0b, k_basis_front).  reset_register / the collapse of a
+measurement are lazy: the next flush writes the basis state together with the longest queue prefix of the shape
+"Hadamards on distinct qubits, then controlled modular multiplies" -- the front of quantum_computation (Q:720-731) -- in
+closed form, with the reference's own roundings.  Everything here is bit for bit against the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+@pytest.fixture()
+def tune_guard(qc):
+    old = {k: qc.lib().qcx_tune_get(k.encode()) for k in ("fuse_front",)}
+    yield
+    qc.tune(**old)
+
+
+@pytest.mark.parametrize("C,L,M,a", [(15, 8, 4, 7), (21, 9, 5, 2), (21, 14, 5, 2), (35, 7, 6, 2), (15, 12, 4, 11), (33, 10, 6, 7), (21, 6, 5, 2)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_shor_circuit_front_is_one_write_pass(qc, ob, C, L, M, a, mode):
+    n = L + M
+    with qc.Register(L, M) as reg:
+        reg.set_fusion(mode)
+        for shot in range(2):
+            p0 = reg.fusion_stats()
+            qc.reset_register(reg)
+            qc.quantum_computation(C, a, reg)
+            got = reg.read()
+            want = np.zeros(2 << n); ob.reset(want, n); ob.quantum_computation(want, n, M, C, a, threads=8)
+            assert np.array_equal(bits(got), bits(want)), (shot,)
+            # 2L gates went into the front when the register is large enough for it (n >= M + 6)
+            if n >= M + 6:
+                assert 3 * L + L * (L - 1) // 2 - 2 <= reg.fusion_stats()[1] - p0[1] <= 3 * L + L * (L - 1) // 2     # (a lone last gate may run stand-alone)
+            idx = qc.measure_state(reg, 0.3 + 0.2 * shot)
+            assert idx == ob.measure(want, n, 0.3 + 0.2 * shot)
+            assert np.array_equal(bits(reg.read()), bits(want))          # the lazy collapse, materialised by the read
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_fronts_from_random_basis_states(qc, ob, tune_guard, seed):
+    """basis state = a measured index (bits set inside the Hadamard set give minus signs), Hadamards on a random subset
+    (also inside the M register: then no multiply joins), multiplies with coprime and non-coprime factors, controls in
+    and outside the Hadamard set, C up to 2^M; then more gates of every kind"""
+    rs = np.random.RandomState(500 + seed)
+    n, M = int(rs.randint(8, 17)), int(rs.choice([0, 2, 4, 5]))
+    if n < M + 6:
+        n = M + 6
+    want = ob.fill_random(n, seed)
+    with qc.Register(n - M, M) as reg:
+        reg.set_fusion(int(rs.choice([0, 1])))
+        reg.fill_random(seed)
+        r = float(rs.uniform(0, 1))
+        assert qc.measure_state(reg, r) == ob.measure(want, n, r)         # collapse: lazy on the product side
+        lo = M if rs.rand() < 0.7 else 0
+        hs = [int(q) for q in rs.permutation(np.arange(lo, n))[: int(rs.randint(0, n - lo + 1))]]
+        for q in hs:
+            qc.hadamard_gate(q, reg); ob.hadamard(want, n, q)
+        if M:
+            for _ in range(int(rs.randint(0, 8))):
+                Cn = int(rs.randint(2, (1 << M) + 1)); A = int(rs.randint(1, 3 * Cn)); ctl = int(rs.randint(M, n))
+                qc.c_amodc_gate(Cn, A, ctl, reg); ob.camodc(want, n, M, Cn, A, ctl)
+        for _ in range(int(rs.randint(0, 12))):
+            k = rs.randint(0, 3)
+            if k == 0:
+                q = int(rs.randint(0, n)); qc.hadamard_gate(q, reg); ob.hadamard(want, n, q)
+            elif k == 1 or M == 0:
+                c, t = (int(x) for x in rs.choice(n, 2, replace=False)); th = float(rs.uniform(-3, 3))
+                qc.c_phase_shift_gate(c, t, th, reg); ob.cphase(want, n, c, t, th)
+            else:
+                Cn = int(rs.randint(2, (1 << M) + 1)); A = int(rs.randint(1, 3 * Cn)); ctl = int(rs.randint(M, n))
+                qc.c_amodc_gate(Cn, A, ctl, reg); ob.camodc(want, n, M, Cn, A, ctl)
+        assert np.array_equal(bits(reg.read()), bits(want)), (n, M, hs)
+
+
+def test_front_off_and_strict_mode_give_the_same_bits(qc, ob, tune_guard):
+    L, M, C, a = 11, 5, 21, 2
+    n = L + M
+    want = np.zeros(2 << n); ob.reset(want, n); ob.quantum_computation(want, n, M, C, a, threads=8)
+    for front, mode in ((0, 0), (1, 0), (1, -1), (1, 2)):
+        qc.tune(fuse_front=front)
+        with qc.Register(L, M) as reg:
+            reg.set_fusion(mode)
+            qc.reset_register(reg)
+            qc.quantum_computation(C, a, reg)
+            got = reg.read()
+        if mode == 2:
+            d = got - want
+            assert float(np.max(np.hypot(d[0::2], d[1::2]))) <= 1e-12
+        else:
+            assert np.array_equal(bits(got), bits(want)), (front, mode)
+
+
+def test_lazy_reset_is_visible_to_every_observer(qc, ob, tmp_path):
+    n = 12
+    with qc.Register(n, 0) as reg:
+        reg.fill_random(3)
+        qc.reset_register(reg)                                  # nothing written yet
+        assert reg.norm2() == 1.0 and reg.total_probability() == 1.0
+        s = reg.read(); assert s[2] == 1.0 and np.count_nonzero(s) == 1
+        qc.reset_register(reg)
+        reg.write(np.array([0.5, 0.25]), first=7)               # partial write on top of the (materialised) reset state
+        s = reg.read(); assert s[2] == 1.0 and s[14] == 0.5 and s[15] == 0.25 and np.count_nonzero(s) == 3
+        reg.fill_random(5); qc.reset_register(reg); reg.fill_random(6)      # a fill after a lazy reset wins
+        assert np.array_equal(bits(reg.read()), bits(ob.fill_random(n, 6)))
+        qc.reset_register(reg); p = str(tmp_path / "s.qcx"); reg.save(p)
+        reg.fill_random(1); reg.load(p)
+        s = reg.read(); assert s[2] == 1.0 and np.count_nonzero(s) == 1
+        qc.reset_register(reg)
+        assert qc.measure_state(reg, 0.99) == 1                 # measuring the basis state gives it back
+        assert reg.device_pointer() != 0
+        s = reg.read(); assert s[2] == 1.0 and np.count_nonzero(s) == 1
+
+
+def test_config5_front_n30_is_one_pass(qc, ob):
+    """n = 30: reset + 25 H + 25 multiplies through the front, windows against the oracle's per-index chain"""
+    L, M, Cn, a = 25, 5, 21, 2
+    n = L + M
+    W = 13
+    rs = np.random.RandomState(6)
+    with qc.Register(L, M) as reg:
+        reg.set_fusion(1)
+        qc.reset_register(reg)
+        for l in range(M, n):
+            qc.hadamard_gate(l, reg)
+        atox = a % Cn
+        for l in range(M, n):
+            qc.c_amodc_gate(Cn, atox, l, reg); atox = atox * atox % Cn
+        p0 = reg.fusion_stats()[0]
+        assert abs(reg.norm2() - 1.0) < 1e-12
+        assert reg.fusion_stats()[0] - p0 == 1                  # the whole front: one write pass
+        for s in sorted({0, (1 << n) - (1 << W)} | {int(v) << W for v in rs.randint(0, 1 << (n - W), 6)}):
+            assert np.array_equal(bits(reg.read(s, 1 << W)), bits(ob.shor_front_window(n, M, Cn, a, s, 1 << W))), s

@@ -28,7 +28,7 @@ def max_delta(a, b):
 
 @pytest.fixture()
 def tune_guard(qc):
-    keys = ("fuse_T", "fuse_c", "fuse_grid_cap", "fuse_T_phase", "fuse_c_phase", "fuse_phase_ratio", "fuse_tol_occ", "fuse_hsweep_T")
+    keys = ("fuse_T", "fuse_c", "fuse_grid_cap", "fuse_T_phase", "fuse_c_phase", "fuse_phase_ratio", "fuse_tol_occ", "fuse_hsweep_T", "fuse_tol_T")
     old = {k: qc.lib().qcx_tune_get(k.encode()) for k in keys}
     yield
     qc.tune(**old)
@@ -40,7 +40,7 @@ def test_inverse_qft_within_tolerance(qc, ob, tune_guard, n, M, geom):
     if geom:
         if geom[0] > n:
             pytest.skip("tile larger than the register")
-        qc.tune(fuse_T=geom[0], fuse_c=geom[1], fuse_T_phase=0)
+        qc.tune(fuse_T=geom[0], fuse_c=geom[1], fuse_T_phase=0, fuse_tol_T=0)
     with qc.Register(n - M, M) as reg:
         reg.set_fusion(qc.FUSION_TOLERANCE)
         reg.fill_random(21)
@@ -78,7 +78,7 @@ def test_random_programs_within_tolerance(qc, ob, tune_guard, seed):
     n, M = int(rs.randint(10, 19)), int(rs.choice([0, 3, 4, 5]))
     Cn = int(rs.randint(3, 1 << M)) if M else 1
     T, c = [(10, 4), (11, 4), (12, 3), (11, 2), (12, 4), (10, 6), (11, 4), (12, 0)][seed]
-    qc.tune(fuse_T=min(T, n), fuse_c=min(c, T, n), fuse_grid_cap=[0, 5][seed % 2] or 24576)
+    qc.tune(fuse_T=min(T, n), fuse_c=min(c, T, n), fuse_grid_cap=[0, 5][seed % 2] or 24576, fuse_tol_T=[0, 10][seed % 2])
     want = ob.fill_random(n, seed)
     with qc.Register(n - M, M) as reg:
         reg.set_fusion(2)

@@ -295,7 +295,7 @@ def main():
                      "note": "qcx_set_fusion(1): same 30 hadamard_gate calls, executed as fused passes over LDS tiles; "
                              "32 B per amplitude are counted once per pass.  An all-Hadamard queue is planned on 2^12-amplitude "
                              "tiles with 128-B runs: 3 passes per 30-qubit sweep instead of 4, each slower (about 4.2 vs 5.1 TB/s), "
-                             "the sweep faster"}
+                             "the sweep faster.  With the gates skipped the three passes take 21.3 ms (profiles/r03_tune_sweep.txt)"}
             reg.set_fusion(False)
         reg.close()
         exchanges = 0
@@ -466,9 +466,9 @@ def single_gpu_configs(qc, reps=3):
     controlled phase performs 6 FP64 operations on a quarter of the amplitudes, a Hadamard 4 per amplitude."""
     out = {}
 
-    def timed(reg, fn):
+    def timed(reg, fn, nrep=None):
         best, passes = 1e30, 0
-        for _ in range(reps):
+        for _ in range(nrep or reps):
             reg.synchronize()
             p0 = reg.fusion_stats()[0]
             reg.timer_start(); fn(); ms = reg.timer_stop()
@@ -515,6 +515,8 @@ def single_gpu_configs(qc, reps=3):
             qc.inverse_QFT(reg)
             ms, passes = timed(reg, lambda: qc.inverse_QFT(reg))
             d = roofs(ms, passes, n, flops if mode != getattr(qc, "FUSION_TOLERANCE", None) else 0, alg_bytes)
+            if mode == getattr(qc, "FUSION_TOLERANCE", None):
+                d["note"] = "opt-in qcx_set_fusion(reg, 2): runs of phases sharing a qubit merged into one diagonal; NOT bit-exact (|delta amplitude| <= 1e-12 in the tests)"
             d["amplitude_updates_per_s"] = (nh + nph) * 2.0 ** n / (ms * 1e-3)
             c3[label] = d
         reg.set_fusion(0)
@@ -530,11 +532,21 @@ def single_gpu_configs(qc, reps=3):
     with qc.Register(L, M) as reg:
         def circuit():
             qc.reset_register(reg); qc.quantum_computation(Cn, a, reg)
+        modes5 = [("circuit_fused_default", 0), ("circuit_per_gate", -1)]
+        if hasattr(qc, "FUSION_TOLERANCE"):
+            modes5.insert(1, ("circuit_tolerance_mode", qc.FUSION_TOLERANCE))
+        for label, mode in modes5:
+            reg.set_fusion(mode)
+            circuit()
+            ms, passes = timed(reg, circuit, 1 if mode < 0 else None)     # (reset included)
+            exact = mode != getattr(qc, "FUSION_TOLERANCE", None)
+            d = roofs(ms, passes, n, ((L * (L - 1) // 2) * 6.0 * 2.0 ** (n - 2) + 2 * L * 4.0 * 2.0 ** n) if exact and mode < 0 else 0)
+            d["amplitude_updates_per_s"] = gates * 2.0 ** n / (ms * 1e-3)
+            c5[label] = d
+        c5["note"] = ("passes include the circuit front (reset + Hadamard layer + modular-multiply ladder on the basis state) as ONE "
+                      "write pass of 16 B per amplitude; the others move 32 B per amplitude")
+        reg.set_fusion(0)
         circuit()
-        ms, passes = timed(reg, circuit)                 # (reset included: a 16 GiB memset)
-        d = roofs(ms, passes, n, (L * (L - 1) // 2) * 6.0 * 2.0 ** (n - 2) + 2 * L * 4.0 * 2.0 ** n)
-        d["amplitude_updates_per_s"] = gates * 2.0 ** n / (ms * 1e-3)
-        c5["circuit_fused_default"] = d
         c5["total_probability"] = reg.norm2()
         t0 = time.perf_counter()
         idx = qc.measure_state(reg, rng)

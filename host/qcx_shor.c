@@ -7,7 +7,8 @@
  * -Q turns on the reference's 32-bit INT_POW behaviour for differential runs, -j prints a one-line
  * JSON performance summary.  The circuit (qcx_quantum_computation) runs as fused passes by default; -G forces one kernel
  * launch per gate (qcx_set_fusion(reg, -1)), -F queues every gate call (qcx_set_fusion(reg, 1)); the results are the same
- * bits in all three modes.  -o file writes the register's state after the LAST period-finding attempt (post-measurement,
+ * bits in all three modes; -T selects the opt-in tolerance mode (qcx_set_fusion(reg, 2): runs of controlled phases merged into
+ * one diagonal, rounding-level differences in the amplitudes).  -o file writes the register's state after the LAST period-finding attempt (post-measurement,
  * i.e. collapsed) and -O file the state right after the last circuit, before measuring (qcx_state_save).  Exit code = the reference's ErrorCode (Q:164-170, Q:1340-1347).
  *
  * The quantum part (reset, circuit, measurement) runs on the GPU through include/qcx.h; everything
@@ -31,7 +32,7 @@ typedef struct {
     unsigned C, forced_a;
     int L, M;
     unsigned long seed;
-    bool seed_given, ref_quirks, json, fusion, per_gate;
+    bool seed_given, ref_quirks, json, fusion, per_gate, tolerance;
     const char *dump_final, *dump_circuit;
     int gpus;                   /* -g N: shard the register over N GPUs (2, 4, 8, 16) from this one process */
     const char *gpu_list;       /* -d "0,0,1,1": HIP device of each shard (default: spread over the visible GPUs) */
@@ -43,7 +44,7 @@ typedef struct {
 } Stats;
 
 static const char *USAGE =
-    "Usage: qcx_shor -C num -L L_reg_size -M M_reg_size [-a trial_int | -f trial_int] [-v] [-V] [-s seed] [-Q] [-j] [-F | -G] [-g gpus [-d dev,dev,...]] [-o state_file] [-O state_file]\n";
+    "Usage: qcx_shor -C num -L L_reg_size -M M_reg_size [-a trial_int | -f trial_int] [-v] [-V] [-s seed] [-Q] [-j] [-F | -G | -T] [-g gpus [-d dev,dev,...]] [-o state_file] [-O state_file]\n";
 
 static double now_seconds(void)
 {
@@ -57,7 +58,7 @@ static int parse_args(int argc, char **argv, Options *o)
     bool haveC = false, haveL = false, haveM = false;
     int ch;
     memset(o, 0, sizeof *o);
-    while ((ch = getopt(argc, argv, "C:L:M:a:f:s:o:O:g:d:vVQjFG")) != -1) {
+    while ((ch = getopt(argc, argv, "C:L:M:a:f:s:o:O:g:d:vVQjFGT")) != -1) {
         switch (ch) {
         case 'C': o->C = (unsigned)atoi(optarg); haveC = true; break;
         case 'L': o->L = atoi(optarg); haveL = true; break;
@@ -70,6 +71,7 @@ static int parse_args(int argc, char **argv, Options *o)
         case 'j': o->json = true; break;
         case 'F': o->fusion = true; break;
         case 'G': o->per_gate = true; break;
+        case 'T': o->tolerance = true; break;
         case 'g': o->gpus = atoi(optarg); break;
         case 'd': o->gpu_list = optarg; break;
         case 'o': o->dump_final = optarg; break;
@@ -209,6 +211,7 @@ int main(int argc, char **argv)
 
     if (o.fusion) qcx_set_fusion(reg, 1);        /* -F: every gate call is queued and run as fused passes (same bits) */
     if (o.per_gate) qcx_set_fusion(reg, -1);     /* -G: one kernel launch per gate, also inside the circuit call */
+    if (o.tolerance) qcx_set_fusion(reg, 2);     /* -T: opt-in tolerance mode (merged diagonals; amplitudes to ~1e-15, not bit-exact) */
     const double t0 = now_seconds();
     s = shors_algorithm(factors, &o, reg, rng, &st);
     qcx_synchronize(reg);

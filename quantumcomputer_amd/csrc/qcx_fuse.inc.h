@@ -259,8 +259,10 @@ static void diag_tables(unsigned n, unsigned c, const std::vector<unsigned> &hbi
 // ROUNDS form: group a pass's records into rounds of at most two distinct H bits (the round's register bits);
 // inside a round consecutive phases that rotate the same registers form runs (FUSE_PRUN)
 static void to_rounds(const Tune &tn, const std::vector<FuseOp> &legacy, unsigned T, std::vector<FuseOp> &out, std::vector<unsigned char> &blob,
-                      std::vector<unsigned> *kept_slots = nullptr, unsigned *generic_rounds = nullptr)
+                      std::vector<unsigned> *kept_slots = nullptr, unsigned *generic_rounds = nullptr, unsigned maxrb = 2)
 {
+    // maxrb = 3: radix-8 fast rounds (k_fused_q3): up to three steps H(x) [D(x)] per round; a round of any other shape
+    // counts as generic (the caller then plans the pass again in the radix-4 form)
     // tolerance mode (kept_slots != nullptr): a merged diagonal arrives as a FUSE_DIAG record followed by the phases it
     // stands for; a round of the shape H(x) [D(x)] [H(y) [D(y)]] keeps its diagonals (FUSE_QROUND, slots renumbered in the
     // order kept), every other round gets the phases back and is emitted exactly as in the bit-exact modes
@@ -269,9 +271,46 @@ static void to_rounds(const Tune &tn, const std::vector<FuseOp> &legacy, unsigne
     std::vector<unsigned> rb;
     auto close_round = [&]() {
         if (cur.empty()) { rb.clear(); return; }
-        for (unsigned b = T; rb.size() < 2 && b-- > 0;)
+        for (unsigned b = T; rb.size() < maxrb && b-- > 0;)
             if (std::find(rb.begin(), rb.end(), b) == rb.end()) rb.push_back(b);
         std::sort(rb.begin(), rb.end());
+        if (maxrb == 3) {
+            uint32_t step[3] = {0, 0, 0};
+            unsigned old_slot[3] = {0, 0, 0}, which[3] = {0, 0, 0};
+            unsigned ns = 0, nd = 0; bool ok = true;
+            auto index_of = [&](unsigned lb) { return lb == rb[0] ? 0u : lb == rb[1] ? 1u : 2u; };
+            for (size_t k = 0; k < cur.size() && ok; k++) {
+                const FuseOp &o = cur[k].o;
+                if (o.type == FUSE_H && ns < 3 && (o.a == rb[0] || o.a == rb[1] || o.a == rb[2])) { which[ns] = index_of(o.a); step[ns] = which[ns]; ns++; }
+                else if (o.type == FUSE_DIAG && ns >= 1 && !(step[ns - 1] & 4u) && o.mask == 0) {
+                    const unsigned R = which[ns - 1], o1 = (R == 0) ? 1u : 0u, o2 = (R == 2) ? 1u : 2u;
+                    uint64_t tloc; memcpy(&tloc, &o.c, sizeof tloc);
+                    if ((o.a & 0xffu) != rb[R] + 1) { ok = false; break; }
+                    old_slot[ns - 1] = (o.a >> 8) & 0xffu;
+                    step[ns - 1] |= 4u | (((o.a >> 16) & 7u) << 16) | ((uint32_t)((tloc >> rb[o1]) & 1u) << 19) | ((uint32_t)((tloc >> rb[o2]) & 1u) << 20);
+                    nd++;
+                } else ok = false;
+            }
+            for (unsigned q = 0; q < ns && ok; q++) for (unsigned q2 = q + 1; q2 < ns; q2++) if (which[q] == which[q2]) ok = false;
+            if (ok && ns >= 1 && (nd == 0 || (kept_slots && kept_slots->size() + nd <= 16))) {
+                bool used[3] = {false, false, false};
+                for (unsigned q = 0; q < ns; q++) used[which[q]] = true;
+                for (unsigned q = ns; q < 3; q++) for (unsigned w = 0; w < 3; w++) if (!used[w]) { step[q] = w; used[w] = true; break; }   // absent steps: the remaining bits
+                for (unsigned q = 0; q < ns; q++)
+                    if (step[q] & 4u) { step[q] |= (uint32_t)kept_slots->size() << 8; kept_slots->push_back(old_slot[q]); }
+                FuseOp hdr; memset(&hdr, 0, sizeof hdr);
+                hdr.type = FUSE_QROUND3; hdr.a = rb[0] | (rb[1] << 8) | (rb[2] << 16) | (ns << 24); hdr.mask = 1;
+                out.push_back(hdr);
+                FuseOp st; memset(&st, 0, sizeof st);
+                st.type = step[0]; st.a = step[1]; st.mask = step[2];
+                out.push_back(st);
+                cur.clear(); rb.clear();
+                return;
+            }
+            if (generic_rounds) ++*generic_rounds;       // not a radix-8 fast round: the caller re-plans
+            cur.clear(); rb.clear();
+            return;
+        }
         if (kept_slots && tn.fuse_qround) {
             uint32_t step[2] = {0xffffffffu, 0xffffffffu};
             unsigned old_slot[2] = {0, 0};
@@ -374,7 +413,7 @@ static void to_rounds(const Tune &tn, const std::vector<FuseOp> &legacy, unsigne
         }
         else if (o.type == FUSE_H) {
             if (std::find(rb.begin(), rb.end(), o.a) == rb.end()) {
-                if (rb.size() == 2) close_round();
+                if (rb.size() == maxrb) close_round();
                 rb.push_back(o.a);
             }
             cur.push_back(Item{o, {}});
@@ -427,7 +466,7 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
     size_t lut_bytes = lut_only + (size_t)P.cam_ctl_local[1];                      // + tables of folded multiply runs
     P.xm_off = 0;
     P.dbg = (uint32_t)tn.fuse_dbg | (((uint32_t)tn.fuse_swz & 7u) << 8);
-    if (P.dg_cnt && !P.has_cam) { lut_bytes = 16; P.cam_ctl_local[3] = 16; }       // tolerance-mode pass without multiplies: no scratch
+    if ((P.dg_cnt || P.dg_slim == 2) && !P.has_cam) { lut_bytes = 16; P.cam_ctl_local[3] = 16; }       // tolerance-mode pass without multiplies: no scratch
     if (P.xm_cnt && !P.dg_slim) {                                                  // + the records' outside-tile masks (phase runs)
         P.xm_off = (uint32_t)((lut_bytes + 7) & ~(size_t)7);
         lut_bytes = P.xm_off + 8 * ((size_t)P.xm_cnt + 66);          // padded: lanes look up to 64 entries past a run
@@ -443,6 +482,16 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
         if (P.cam_ctl_local[0] && tn.fuse_ldsdma && tn.fuse_rounds_occ >= 6 && launch_rounds_kernel<B, TTv>((int)tn.fuse_rounds_occ, (int)tn.fuse_tol_occ, grid, lds, r->stream, r->amp, n, P, d_ops, ntiles)) { \
         } else if (tn.fuse_ldsdma) hipLaunchKernelGGL((k_fused<B, TTv, true>), dim3(grid), dim3(B), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); \
         else hipLaunchKernelGGL((k_fused<B, TTv, false>), dim3(grid), dim3(B), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); } while (0)
+    if (P.dg_slim == 2) {                 // tolerance mode, radix-8 fast rounds only
+        if (P.T != 12) { set_error("radix-8 pass on a tile of 2^%u amplitudes", P.T); return QCX_UNKNOWN_ERROR; }
+        // (a few workgroups per CU that walk the tiles: 2048 workgroups 6.3 ms, 24576 7.0 ms, one per tile 8.3 ms at n = 28)
+        // (the Hadamard-only exact form likes more of them: n = 30 sweep 23.5 ms with 8192, 23.9 with 3072)
+        const unsigned grid3 = grid_for(ntiles, 1, P.dg_cnt ? tn.fuse_q3_cap : tn.fuse_q3_cap_exact);
+        if (P.dg_cnt) hipLaunchKernelGGL((k_fused_q3<512, 12, 4, false>), dim3(grid3), dim3(512), lds, r->stream, r->amp, n, P, d_ops, ntiles);
+        else hipLaunchKernelGGL((k_fused_q3<512, 12, 4, true>), dim3(grid3), dim3(512), lds, r->stream, r->amp, n, P, d_ops, ntiles);
+        HIP_TRY(hipGetLastError());
+        return QCX_NO_ERROR;
+    }
     switch (P.T) {
     case 12: QCX_FUSE_LAUNCH(1024, 12); break;
     case 11: QCX_FUSE_LAUNCH(512, 11); break;
@@ -482,9 +531,12 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
     std::vector<FuseOp> legacy;
     std::vector<unsigned> need;
     size_t i = 0;
+    bool q3_refused = false;               // the radix-8 plan of the pass starting at i did not work out: plan it the usual way
     while (i < gates.size()) {
         FuseAction act;
         memset(&act, 0, sizeof act);
+        const bool q3_allowed = !q3_refused;
+        q3_refused = false;
         if (gates[i].type == 99) { standalone(i++); continue; }   // table-form modular multiply
         // ---- grow one pass: a gate joins while the bits it needs inside the tile still fit ----------------
         std::vector<unsigned> hbits;
@@ -510,6 +562,7 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         // sweep in 3 passes instead of 4 -- at 1.23x the time per pass (128-B runs, 64 KiB tiles: measured 8.2 vs 6.7 ms at
         // n = 30), so that geometry is taken when it saves enough passes.  Passes with phases or multiplies keep theirs.
         unsigned Tcur = T, ccur = c_def;
+        bool want_q3 = false;
         {
             const unsigned Ta = (unsigned)tn.fuse_hsweep_T, ca = (unsigned)tn.fuse_hsweep_c;
             bool tail_h = Ta >= 10 && Ta <= 12 && Ta <= n && ca <= Ta && tn.fuse_rounds;
@@ -528,7 +581,10 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
                     }
                     return np;
                 };
-                if (passes(Ta, ca) * 123u < passes(T, c_def) * 100u) { Tcur = Ta; ccur = ca; }
+                if (passes(Ta, ca) * 123u < passes(T, c_def) * 100u) {
+                    Tcur = Ta; ccur = ca;
+                    if (Ta == 12 && q3_allowed && tn.fuse_q3) want_q3 = true;      // radix-8 rounds, exact butterflies (k_fused_q3<.., EXACT>)
+                }
             }
         }
         // Tolerance mode: passes with merged diagonals overlap their arithmetic better on the smaller tile (2^10 amplitudes,
@@ -541,7 +597,10 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
                 else if (gates[k].type != FUSE_DIAG && gates[k].type != FUSE_PHASE) { pure = false; break; }
             }
             const unsigned hb = (unsigned)__builtin_popcountll(hot), Ts = (unsigned)tn.fuse_tol_T;
-            if (pure && hb && (hb + (Ts - ccur) - 1) / (Ts - ccur) == (hb + (Tcur - ccur) - 1) / (Tcur - ccur)) Tcur = Ts;
+            auto passes_at = [&](unsigned TT) { return (hb + (TT - ccur) - 1) / (TT - ccur); };
+            // radix-8 rounds on 2^12 tiles (k_fused_q3) when they save a pass against both radix-4 geometries
+            if (pure && hb && q3_allowed && tn.fuse_q3 && n >= 12 && ccur <= 4 && passes_at(12) < std::min(passes_at(Ts), passes_at(Tcur))) { Tcur = 12; want_q3 = true; }
+            else if (pure && hb && passes_at(Ts) == passes_at(Tcur)) Tcur = Ts;
         }
         unsigned c = ccur, budget = Tcur - ccur;
         grow(c, budget);
@@ -549,7 +608,7 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         // smaller tiles (256-thread workgroups: smaller barrier domains, more of them resident), at the price of
         // fewer hot bits per pass; and never on the pipelined kernel.
         const unsigned Tp = (unsigned)tn.fuse_T_phase;
-        if (Tp >= 9 && Tp <= 12 && Tp <= n && tn.fuse_rounds && n_other == 0 &&
+        if (!want_q3 && Tp >= 9 && Tp <= 12 && Tp <= n && tn.fuse_rounds && n_other == 0 &&
             n_ph >= (size_t)tn.fuse_phase_ratio * std::max<size_t>(n_h, 1)) {
             c = std::min((unsigned)tn.fuse_c_phase, Tp); budget = Tp - c;
             grow(c, budget);
@@ -570,6 +629,7 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         for (unsigned j = 0; j < act.P.nh; j++) act.P.hbit[j] = (uint8_t)hbits[j];
         legacy.clear();
         bool rounds = tn.fuse_rounds && act.P.T >= 10 && act.P.T <= 12;
+        if (want_q3 && !(rounds && act.P.T == 12 && n_other == 0)) { q3_refused = true; i = first; continue; }
         // (tolerance mode: merged diagonals exist in the rounds form only, at most 16 per pass -- their tables live in LDS;
         // otherwise the pass gets the plain phases they were merged from)
         std::vector<unsigned> pass_diags;
@@ -584,8 +644,13 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
             std::vector<unsigned char> blob;
             std::vector<unsigned> kept;                  // old slot numbers of the diagonals that stayed merged, in new-slot order
             unsigned generic_rounds = 0;
-            to_rounds(tn, legacy, act.P.T, all_ops, blob, keep_diags ? &kept : nullptr, &generic_rounds);
-            act.P.dg_slim = (keep_diags && !kept.empty() && generic_rounds == 0) ? 1u : 0u;     // every round is a fast round
+            to_rounds(tn, legacy, act.P.T, all_ops, blob, keep_diags ? &kept : nullptr, &generic_rounds, want_q3 ? 3u : 2u);
+            if (want_q3 && (generic_rounds || (n_diag > 0 && (!keep_diags || kept.empty())) || (n_diag == 0 && n_ph + n_other > 0))) {       // not all radix-8 fast rounds: plan this pass again, radix 4
+                all_ops.resize(act.op_off); q3_refused = true; i = first; continue;
+            }
+            act.P.dg_slim = want_q3 ? 2u : (keep_diags && !kept.empty() && generic_rounds == 0) ? 1u : 0u;     // every round is a fast round (2: radix 8)
+            act.P.tol_scale = 1.0;
+            if (want_q3) for (size_t k = 0; k < n_h; k++) act.P.tol_scale *= QCX_SQRT1_2;
             if (keep_diags) {
                 std::vector<unsigned> kd;
                 for (unsigned os : kept) kd.push_back(pass_diags[os]);

@@ -714,7 +714,8 @@ struct FusePass {
     uint32_t has_cam, dbg;      // the pass holds modular multiplies (selects the kernel variant); dbg: diagnostics only (tools/probe_pass.py):
                                 // bit 0 skip the gates, bit 1 skip the stores, bit 2 skip the tile fill -- results are then wrong by design
     uint32_t dg_cnt, dg_rec_off;// tolerance mode: merged diagonals of the pass (0 = none), record offset of their table area in ops
-    uint32_t dg_lds_off, dg_slim;// byte offset of their LDS area behind the lut; 1: every round of the pass is a fast round
+    uint32_t dg_lds_off, dg_slim;// byte offset of their LDS area behind the lut; 1: every round of the pass is a fast round; 2: radix-8 fast rounds
+    double   tol_scale;         // radix-8 passes: M_SQRT1_2 ^ (Hadamards of the pass), applied once when a tile is stored
 };
 
 // One controlled modular multiply on an LDS-resident tile whose low M local bits are the M register.
@@ -1433,6 +1434,168 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
         if (!(P.dbg & 2u)) {
 #pragma unroll
             for (unsigned k = 0; k < 4; k++) __builtin_nontemporal_store(v[k], g + off_k[k]);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K6t-8  tolerance mode, RADIX-8 fast rounds on 2^12-amplitude tiles: a thread keeps the 8 amplitudes that differ in THREE
+// register bits, a round is up to three steps  H(x) [D(x)]  -- three Hadamards and their merged diagonals per LDS round trip
+// and per barrier instead of two, with 512-thread workgroups (8 waves) on a tile that holds 8 hot bits: the n = 28 inverse
+// QFT in 3 passes instead of 4.  Passes whose rounds are ALL of that shape and that hold no modular multiply take this
+// kernel; everything else takes k_fused_rounds.
+// Records: FUSE_QROUND3  a = rb0 | rb1 << 8 | rb2 << 16 | steps << 24, mask = 1 (one record follows), then one record with
+// the step words in type, a and the low half of mask.  Step word: bits 0-1 = which register bit (0..2), bit 2 = a diagonal
+// follows the H, bits 8-15 its slot, bits 16-18 its groups, bit 19 / 20 = the lower / higher of the OTHER two register
+// bits is one of its targets.
+// ---------------------------------------------------------------------------
+enum : uint32_t { FUSE_QROUND3 = 8 };
+
+// Hadamard butterfly WITHOUT its 1/sqrt(2): the radix-8 passes multiply every amplitude by (1/sqrt 2)^(Hadamards of the pass)
+// once, when the tile is stored (every amplitude of a tile takes part in every Hadamard of the pass)
+__device__ __forceinline__ void h_butterfly_unscaled(amp_t &a, amp_t &b)
+{
+    const double ar = a.x, ai = a.y;
+    a.x = ar + b.x;  a.y = ai + b.y;
+    b.x = ar - b.x;  b.y = ai - b.y;
+}
+
+// the exact Hadamard butterfly without its trailing "+ 0.0" (the pass canonicalises once, when the tile is stored)
+__device__ __forceinline__ void h_butterfly_noz(amp_t &a, amp_t &b)
+{
+    const double s = QCX_SQRT1_2;
+    const double t0r = s * a.x, t0i = s * a.y, t1r = s * b.x, t1i = s * b.y;
+    a.x = t0r + t1r;  a.y = t0i + t1i;
+    b.x = t0r - t1r;  b.y = t0i - t1i;
+}
+
+template <int R, bool EXACT>        // step on register bit R of an 8-amplitude register file (index bit j of v[] = register bit j)
+__device__ __forceinline__ void q3_step(uint32_t s, unsigned p, unsigned rbo1, unsigned rbo2, amp_t (&v)[8], const amp_t *dg, const amp_t *gtab)
+{
+    constexpr int O1 = (R == 0) ? 1 : 0, O2 = (R == 2) ? 1 : 2;          // the other two register bits, ascending
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            if constexpr (EXACT) h_butterfly_noz(v[(a << O1) | (b << O2)], v[(1 << R) | (a << O1) | (b << O2)]);
+            else h_butterfly_unscaled(v[(a << O1) | (b << O2)], v[(1 << R) | (a << O1) | (b << O2)]);
+        }
+    if constexpr (EXACT) return;
+    if (s & 4u) {
+        const unsigned slot = (s >> 8) & 0xffu;
+        const amp_t *G = gtab + slot * 48u;
+        amp_t F = dg[slot];
+        if (s & (1u << 16)) cmul_tol(F, G[p & 15u]);
+        if (s & (1u << 17)) cmul_tol(F, G[16u + ((p >> 4) & 15u)]);
+        if (s & (1u << 18)) cmul_tol(F, G[32u + (p >> 8)]);
+        amp_t F1 = F, F2 = F;
+        if (s & (1u << 19)) cmul_tol(F1, G[16u * (rbo1 >> 2) + (1u << (rbo1 & 3u))]);
+        if (s & (1u << 20)) { const amp_t w2 = G[16u * (rbo2 >> 2) + (1u << (rbo2 & 3u))]; cmul_tol(F2, w2); amp_t F3 = F1; cmul_tol(F3, w2);
+                              cmul_tol(v[(1 << R) | (1 << O1) | (1 << O2)], F3); }
+        else cmul_tol(v[(1 << R) | (1 << O1) | (1 << O2)], F1);
+        cmul_tol(v[1 << R], F);
+        cmul_tol(v[(1 << R) | (1 << O1)], F1);
+        cmul_tol(v[(1 << R) | (1 << O2)], F2);
+    }
+}
+
+template <int RA, int RB, int RC, bool EXACT>
+__device__ __forceinline__ void q3_run(amp_t *tile, unsigned p, const unsigned (&rb)[3], unsigned nsteps, uint32_t sA, uint32_t sB, uint32_t sC,
+                                       const amp_t *dg, const amp_t *gtab)
+{
+    amp_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = tile[p | ((j & 1u) << rb[0]) | (((j >> 1) & 1u) << rb[1]) | ((unsigned)(j >> 2) << rb[2])];
+    q3_step<RA, EXACT>(sA, p, rb[RA == 0 ? 1 : 0], rb[RA == 2 ? 1 : 2], v, dg, gtab);
+    __builtin_amdgcn_sched_barrier(0);
+    if (nsteps > 1) q3_step<RB, EXACT>(sB, p, rb[RB == 0 ? 1 : 0], rb[RB == 2 ? 1 : 2], v, dg, gtab);
+    __builtin_amdgcn_sched_barrier(0);
+    if (nsteps > 2) q3_step<RC, EXACT>(sC, p, rb[RC == 0 ? 1 : 0], rb[RC == 2 ? 1 : 2], v, dg, gtab);
+#pragma unroll
+    for (int j = 0; j < 8; j++) tile[p | ((j & 1u) << rb[0]) | (((j >> 1) & 1u) << rb[1]) | ((unsigned)(j >> 2) << rb[2])] = v[j];
+}
+
+// EXACT = true: the same radix-8 structure for passes of nothing but Hadamards in the BIT-EXACT modes (the fused Hadamard
+// sweep): exact butterflies (separate roundings, no FMA), canonical zeros once at the store; no tables, no diagonals.
+template <int BLOCK, int TT, int OCC, bool EXACT = false>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) void k_fused_q3(
+    amp_t *__restrict__ amp, unsigned n, FusePass P, const FuseOp *__restrict__ ops, uint64_t ntiles)
+{
+    static_assert((1u << TT) == 8u * BLOCK, "radix-8 rounds: 8 amplitudes per thread");
+    extern __shared__ __attribute__((aligned(16))) unsigned char qcx_lds_raw[];
+    amp_t *tile = reinterpret_cast<amp_t *>(qcx_lds_raw);
+    constexpr unsigned tsize = 1u << TT;
+    amp_t *dg = reinterpret_cast<amp_t *>(reinterpret_cast<unsigned char *>(tile + tsize) + P.dg_lds_off);
+    const amp_t *dg_area = reinterpret_cast<const amp_t *>(ops + P.dg_rec_off);
+    if constexpr (!EXACT)
+        for (unsigned b = threadIdx.x; b < P.dg_cnt * 48u; b += BLOCK) dg[P.dg_cnt + b] = dg_area[2u * P.dg_cnt + b];
+    __syncthreads();
+    const amp_t *gtab = dg + P.dg_cnt;
+    const unsigned c = P.c, nh = P.nh;
+    const unsigned lowmask = (1u << c) - 1u;
+    auto scatter = [&](unsigned e) -> uint64_t {
+        uint64_t off = e & lowmask;
+        for (unsigned j = 0; j < nh; j++) off |= (uint64_t)((e >> (c + j)) & 1u) << P.hbit[j];
+        return off;
+    };
+    const uint64_t off_t = scatter(threadIdx.x);
+    uint64_t off_k[8];
+#pragma unroll
+    for (unsigned k = 0; k < 8; k++) off_k[k] = scatter(k * BLOCK);
+    const unsigned wbase = (threadIdx.x >> 6) * 64;
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        uint64_t base = t << c;
+        for (unsigned j = 0; j < nh; j++) base = insert_zero(base, P.hbit[j]);
+        amp_t *g = amp + (base | off_t);
+        if (!(P.dbg & 4u)) {
+#pragma unroll
+            for (unsigned k = 0; k < 8; k++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + off_k[k]),
+                                                 (__attribute__((address_space(3))) void *)(tile + k * BLOCK + wbase), 16, 0, 2);
+        }
+        if (!EXACT && threadIdx.x < P.dg_cnt) {           // E_out of this tile for every diagonal of the pass, while the fill is in flight
+            const DiagInfo *info = reinterpret_cast<const DiagInfo *>(dg_area) + threadIdx.x;
+            const uint32_t present = info->present;
+            amp_t E; E.x = 1.0; E.y = 0.0;
+#pragma unroll
+            for (unsigned f = 0; f < 5; f++)
+                if ((present >> f) & 1u) cmul_tol(E, dg_area[info->field_off[f] + (unsigned)((base >> (8u * f)) & 255u)]);
+            dg[threadIdx.x] = E;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (!(P.dbg & 1u)) {
+            for (unsigned i = 0; i < P.nops; i += 2) {
+                const uint32_t a = ops[i].a;
+                const unsigned rb[3] = {a & 0xffu, (a >> 8) & 0xffu, (a >> 16) & 0xffu};
+                const unsigned nsteps = a >> 24;
+                const uint32_t sA = ops[i + 1].type, sB = ops[i + 1].a, sC = (uint32_t)ops[i + 1].mask;
+                const unsigned p = (unsigned)insert_zero(insert_zero(insert_zero(threadIdx.x, rb[0]), rb[1]), rb[2]);
+                // (which register bit each step works on is a compile-time fact of the variant: see qround_run)
+                const unsigned perm = (sA & 3u) | ((sB & 3u) << 2) | ((sC & 3u) << 4);
+                switch (perm) {
+                case 0x06: q3_run<2, 1, 0, EXACT>(tile, p, rb, nsteps, sA, sB, sC, dg, gtab); break;     // sA=2, sB=1, sC=0: descending (Q:682-689)
+                case 0x12: q3_run<2, 0, 1, EXACT>(tile, p, rb, nsteps, sA, sB, sC, dg, gtab); break;
+                case 0x09: q3_run<1, 2, 0, EXACT>(tile, p, rb, nsteps, sA, sB, sC, dg, gtab); break;
+                case 0x21: q3_run<1, 0, 2, EXACT>(tile, p, rb, nsteps, sA, sB, sC, dg, gtab); break;
+                case 0x18: q3_run<0, 2, 1, EXACT>(tile, p, rb, nsteps, sA, sB, sC, dg, gtab); break;
+                default:   q3_run<0, 1, 2, EXACT>(tile, p, rb, nsteps, sA, sB, sC, dg, gtab); break;     // 0x24: ascending
+                }
+                __syncthreads();
+            }
+        }
+        amp_t v[8];
+        const double sc = (P.dbg & 1u) ? 1.0 : P.tol_scale;
+#pragma unroll
+        for (unsigned k = 0; k < 8; k++) {
+            v[k] = tile[k * BLOCK + threadIdx.x];
+            if constexpr (EXACT) { v[k].x += 0.0; v[k].y += 0.0; }          // the reference's canonical zeros, once per pass
+            else { v[k].x *= sc; v[k].y *= sc; }
+        }
+        if (!(P.dbg & 2u)) {
+#pragma unroll
+            for (unsigned k = 0; k < 8; k++) __builtin_nontemporal_store(v[k], g + off_k[k]);
         }
         __syncthreads();
     }

@@ -12,7 +12,7 @@ import struct
 
 import numpy as np
 
-FUSE_H, FUSE_PHASE, FUSE_CAMODC, FUSE_ROUND, FUSE_PRUN, FUSE_CAMRUN, FUSE_DIAG, FUSE_QROUND = 0, 1, 2, 3, 4, 5, 6, 7
+FUSE_H, FUSE_PHASE, FUSE_CAMODC, FUSE_ROUND, FUSE_PRUN, FUSE_CAMRUN, FUSE_DIAG, FUSE_QROUND, FUSE_QROUND3 = 0, 1, 2, 3, 4, 5, 6, 7, 8
 SQRT1_2 = 0.70710678118654752440
 
 
@@ -265,6 +265,39 @@ def apply_pass(state, n, act, recs):
                         rec = Rec(); rec.a = (hb + 1) | (slot << 8) | (groups << 16); rec.mask = 0
                         rec.c = struct.unpack("<d", struct.pack("<Q", tloc))[0]
                         _diag(P, re, im, rec, area, nd); stats["diags"] += 1
+                i += 2
+            elif t == FUSE_QROUND3:
+                # tolerance mode, radix-8 fast round (k_fused_q3): up to three steps H(x) [D(x)] on three register bits
+                rb = [r.a & 0xFF, (r.a >> 8) & 0xFF, (r.a >> 16) & 0xFF]
+                ns = r.a >> 24
+                assert rb[0] < rb[1] < rb[2] < P.T and int(r.mask) == 1 and 1 <= ns <= 3
+                steps = [R[i + 1].type, R[i + 1].a, int(R[i + 1].mask) & 0xFFFFFFFF]
+                assert sorted(sw & 3 for sw in steps) == [0, 1, 2], "the three step words name the three register bits"
+                stats["rounds"] += 1
+                for sw in steps[:ns]:
+                    Rr = sw & 3
+                    hb = rb[Rr]
+                    others = [rb[k] for k in range(3) if k != Rr]
+                    _h(re, im, P.gbit(hb), False); stats["h"] += 1
+                    if sw & 4:
+                        assert nd, "a diagonal in a pass without tables"
+                        slot, groups = (sw >> 8) & 0xFF, (sw >> 16) & 7
+                        G = area[2 * nd + 48 * slot: 2 * nd + 48 * (slot + 1)]
+                        tloc = 0
+                        for lb in range(12):
+                            if G[16 * (lb >> 2) + (1 << (lb & 3))] != 1.0:
+                                tloc |= 1 << lb
+                        for k, ob in enumerate(others):
+                            flagged = (sw >> (19 + k)) & 1
+                            assert ((tloc >> ob) & 1) <= flagged, "a target on another register bit must be flagged"
+                            if not flagged:
+                                assert G[16 * (ob >> 2) + (1 << (ob & 3))] == 1.0
+                        class Rec: pass
+                        rec = Rec(); rec.a = (hb + 1) | (slot << 8) | (groups << 16); rec.mask = 0
+                        rec.c = struct.unpack("<d", struct.pack("<Q", tloc))[0]
+                        _diag(P, re, im, rec, area, nd); stats["diags"] += 1
+                if not nd:
+                    re += 0.0; im += 0.0         # the exact form (Hadamards only): canonical zeros (the kernel: once per pass, same values)
                 i += 2
             elif t == FUSE_CAMRUN:
                 i += 1 + _camrun(P, re, im, R, i, blob)

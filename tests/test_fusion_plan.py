@@ -14,7 +14,7 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 
 
-TUNE_KEYS = ("fuse_T", "fuse_c", "fuse_rounds", "fuse_camruns", "fuse_T_phase", "fuse_c_phase", "fuse_phase_ratio", "fuse_tol_T")
+TUNE_KEYS = ("fuse_T", "fuse_c", "fuse_rounds", "fuse_camruns", "fuse_T_phase", "fuse_c_phase", "fuse_phase_ratio", "fuse_tol_T", "fuse_q3")
 
 
 @pytest.fixture()
@@ -192,7 +192,7 @@ def max_delta(a, b):
 def test_tolerance_mode_iqft_merges_every_run_into_one_diagonal(qc, ob, tune_guard, n, M, T, c):
     if T > n:
         pytest.skip("tile larger than the register")
-    qc.tune(fuse_T=T, fuse_c=c, fuse_T_phase=0, fuse_tol_T=0)         # the geometry under test, not the planner's own choice
+    qc.tune(fuse_T=T, fuse_c=c, fuse_T_phase=0, fuse_tol_T=0, fuse_q3=0)         # the geometry under test, not the planner's own choice
     descs = iqft_descs(qc, n, M)
     L = n - M
     acts, recs, _ = qc.fusion_plan(n, M, descs, mode=2)
@@ -262,17 +262,35 @@ def test_tolerance_mode_random_programs(qc, ob, tune_guard, seed):
 
 
 def test_tolerance_mode_plan_of_the_n28_iqft(qc, tune_guard):
-    """config 3 in tolerance mode: 28 H + 378 phases -> 4 passes of fast rounds only (slim kernel), 27 diagonals, on 2^10
-    tiles (the smaller tile costs no pass here)"""
+    """config 3 in tolerance mode: 28 H + 378 phases -> THREE passes of radix-8 fast rounds on 2^12 tiles (8 hot bits each,
+    k_fused_q3), 27 diagonals; with the radix-8 form off: four passes of radix-4 fast rounds on 2^10 tiles"""
     n = 28
     descs = iqft_descs(qc, n, 0)
     actions, recs, nrec = qc.fusion_plan(n, 0, descs, mode=2)
-    assert [a.fused for a in actions] == [1, 1, 1, 1] and sum(a.ngates for a in actions) == 406
-    assert [(a.T, a.c) for a in actions] == [(10, 4)] * 4
+    assert [a.fused for a in actions] == [1, 1, 1] and sum(a.ngates for a in actions) == 406
+    assert [(a.T, a.c) for a in actions] == [(12, 4)] * 3
     assert sum(a.diag_cnt for a in actions) == 27
     for a in actions:
         kinds = {recs[a.rec_off + k].type & 0xFF for k in range(0, a.nops, 2)}
-        assert kinds == {emu.FUSE_QROUND}, kinds
+        assert kinds == {emu.FUSE_QROUND3}, kinds
+    qc.tune(fuse_q3=0)
+    actions, recs, nrec = qc.fusion_plan(n, 0, descs, mode=2)
+    assert [(a.T, a.c) for a in actions] == [(10, 4)] * 4 and sum(a.diag_cnt for a in actions) == 27
+    for a in actions:
+        assert {recs[a.rec_off + k].type & 0xFF for k in range(0, a.nops, 2)} == {emu.FUSE_QROUND}
+
+
+@pytest.mark.parametrize("n,M", [(12, 0), (12, 3), (20, 0), (21, 5)])
+def test_tolerance_mode_radix8_rounds(qc, ob, tune_guard, n, M):
+    """registers where the radix-8 form saves a pass (2^12 tiles against 2^10 / 2^11): emulated against the oracle"""
+    descs = iqft_descs(qc, n, M)
+    acts, recs, _ = qc.fusion_plan(n, M, descs, mode=2)
+    state = ob.fill_random(n, 5)
+    want = state.copy(); ob.iqft(want, n, M)
+    tot = emu.run_plan(state, n, M, descs, acts, recs, ob)
+    assert max_delta(state, want) <= TOL
+    q3 = [a for a in acts if a.fused and (recs[a.rec_off].type & 0xFF) == emu.FUSE_QROUND3]
+    assert len(q3) == (n - max(M, 4) + 7) // 8, [(a.T, a.c) for a in acts]
 
 
 def test_mode_1_plan_is_unchanged_by_the_tolerance_code(qc, ob, tune_guard):
@@ -282,3 +300,23 @@ def test_mode_1_plan_is_unchanged_by_the_tolerance_code(qc, ob, tune_guard):
     a2, r2, n2 = qc.fusion_plan(13, 0, descs, mode=1)
     assert n1 == n2 and all(x.diag_cnt == 0 for x in a1)
     assert bytes(memoryview(r1).cast("B"))[:32 * n1] == bytes(memoryview(r2).cast("B"))[:32 * n2]
+
+
+@pytest.mark.parametrize("n", [21])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_hadamard_sweep_takes_the_exact_radix8_form(qc, ob, tune_guard, n, mode):
+    """an all-Hadamard queue on 2^12 tiles (12 + 9 + 9 hot bits at n = 30): radix-8 rounds with EXACT butterflies
+    (k_fused_q3<.., EXACT>), bit for bit -- in the tolerance mode too, there is nothing to merge"""
+    descs = [(0, q, 0, 0.0, 0.0, 0, 0) for q in range(n)]
+    acts, recs, _ = qc.fusion_plan(n, 0, descs, mode=mode)
+    state = ob.fill_random(n, 2)
+    want = state.copy()
+    for q in range(n):
+        ob.hadamard(want, n, q, 8)
+    emu.run_plan(state, n, 0, descs, acts, recs, ob)
+    assert np.array_equal(bits(state), bits(want))
+    fused = [a for a in acts if a.fused]
+    assert fused and all((recs[a.rec_off].type & 0xFF) == emu.FUSE_QROUND3 and a.diag_cnt == 0 and (a.T, a.c) == (12, 3) for a in fused)
+    qc.tune(fuse_q3=0)
+    acts, recs, _ = qc.fusion_plan(n, 0, descs, mode=mode)
+    assert all((recs[a.rec_off].type & 0xFF) == emu.FUSE_ROUND for a in acts if a.fused)

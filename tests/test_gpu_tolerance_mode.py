@@ -28,7 +28,7 @@ def max_delta(a, b):
 
 @pytest.fixture()
 def tune_guard(qc):
-    keys = ("fuse_T", "fuse_c", "fuse_grid_cap", "fuse_T_phase", "fuse_c_phase", "fuse_phase_ratio", "fuse_tol_occ", "fuse_hsweep_T", "fuse_tol_T")
+    keys = ("fuse_T", "fuse_c", "fuse_grid_cap", "fuse_T_phase", "fuse_c_phase", "fuse_phase_ratio", "fuse_tol_occ", "fuse_hsweep_T", "fuse_tol_T", "fuse_q3")
     old = {k: qc.lib().qcx_tune_get(k.encode()) for k in keys}
     yield
     qc.tune(**old)
@@ -40,7 +40,7 @@ def test_inverse_qft_within_tolerance(qc, ob, tune_guard, n, M, geom):
     if geom:
         if geom[0] > n:
             pytest.skip("tile larger than the register")
-        qc.tune(fuse_T=geom[0], fuse_c=geom[1], fuse_T_phase=0, fuse_tol_T=0)
+        qc.tune(fuse_T=geom[0], fuse_c=geom[1], fuse_T_phase=0, fuse_tol_T=0, fuse_q3=0)
     with qc.Register(n - M, M) as reg:
         reg.set_fusion(qc.FUSION_TOLERANCE)
         reg.fill_random(21)
@@ -78,7 +78,7 @@ def test_random_programs_within_tolerance(qc, ob, tune_guard, seed):
     n, M = int(rs.randint(10, 19)), int(rs.choice([0, 3, 4, 5]))
     Cn = int(rs.randint(3, 1 << M)) if M else 1
     T, c = [(10, 4), (11, 4), (12, 3), (11, 2), (12, 4), (10, 6), (11, 4), (12, 0)][seed]
-    qc.tune(fuse_T=min(T, n), fuse_c=min(c, T, n), fuse_grid_cap=[0, 5][seed % 2] or 24576, fuse_tol_T=[0, 10][seed % 2])
+    qc.tune(fuse_T=min(T, n), fuse_c=min(c, T, n), fuse_grid_cap=[0, 5][seed % 2] or 24576, fuse_tol_T=[0, 10][seed % 2], fuse_q3=[1, 0, 1, 1][seed % 4])
     want = ob.fill_random(n, seed)
     with qc.Register(n - M, M) as reg:
         reg.set_fusion(2)
@@ -100,6 +100,21 @@ def test_random_programs_within_tolerance(qc, ob, tune_guard, seed):
                 qc.c_amodc_gate(Cn, atox, ctl, reg); ob.camodc(want, n, M, Cn, atox, ctl)
         got = reg.read()
     assert max_delta(got, want) <= TOL, (n, M, T, c)
+
+
+@pytest.mark.parametrize("n,M", [(12, 0), (12, 3), (20, 0), (21, 5), (24, 0), (20, 4)])
+def test_radix8_rounds_within_tolerance(qc, ob, n, M):
+    """registers where 2^12 tiles with radix-8 fast rounds (k_fused_q3) save a pass: that kernel runs, against the oracle"""
+    with qc.Register(n - M, M) as reg:
+        reg.set_fusion(2)
+        reg.fill_random(8)
+        p0 = reg.fusion_stats()[0]
+        qc.inverse_QFT(reg)
+        got = reg.read()
+        passes = reg.fusion_stats()[0] - p0
+    want = ob.fill_random(n, 8); ob.iqft(want, n, M, 8)
+    assert max_delta(got, want) <= TOL
+    assert passes == (n - max(M, 4) + 7) // 8          # 8 hot bits per pass
 
 
 def test_seeded_histogram_is_unchanged(qc):
@@ -168,7 +183,7 @@ def test_config3_iqft_n28_on_basis_states_within_tolerance(qc, ob):
             for s in sorted(starts):
                 got = reg.read(s, 1 << W)
                 assert max_delta(got, ob.basis_iqft_window(x, n, 0, s, 1 << W)) <= TOL * 2.0 ** -14, (x, s)
-        assert 1 <= reg.fusion_stats()[0] // 4 <= 4          # passes per transform
+        assert reg.fusion_stats()[0] == 4 * 3                  # three radix-8 passes per transform
 
 
 def test_config3_iqft_n28_dense_input_close_to_the_exact_mode(qc):

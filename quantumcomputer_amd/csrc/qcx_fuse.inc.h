@@ -664,7 +664,6 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
                 lds = ((size_t)16 << act.P.T) + (n_other ? (size_t)act.P.cam_ctl_local[3] : 16) + blob.size() + 64 + 8 * (nrec + 66) + 16 * 49 * pass_diags.size();
                 limit = (size_t)80 * 1024;
             }
-            if (getenv("QCX_FUSE_DUMP")) fprintf(stderr, "[qcx fuse] lds %zu limit %zu keep %d nd %zu nrec %zu\n", lds, limit, (int)keep_diags, pass_diags.size(), nrec);
             if (lds > limit) {
                 all_ops.resize(act.op_off); rounds = false;
                 if (keep_diags) {        // the plain gate list has no diagonal interpreter: back to the phases

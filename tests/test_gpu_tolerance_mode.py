@@ -197,3 +197,24 @@ def test_config3_iqft_n28_dense_input_close_to_the_exact_mode(qc):
         assert abs(a.norm2() - n0) < 1e-12
         for s in sorted({0, (1 << n) - (1 << W)} | {int(v) << W for v in rs.randint(0, 1 << (n - W), 8)}):
             assert max_delta(a.read(s, 1 << W), b.read(s, 1 << W)) <= TOL * 2.0 ** -13, s
+
+
+def test_config5_shor_n30_tolerance_against_the_exact_mode(qc):
+    """BASELINE config 5 on one GPU at full size: the n = 30 Shor N = 21 circuit in tolerance mode next to the bit-exact
+    default (itself checked against the oracle in tests/test_gpu_fullsize.py / test_gpu_basis_front.py): windows agree to
+    1e-12 of the amplitude scale, norm is kept, the same uniform draw measures the same index"""
+    L, M, Cn, a = 25, 5, 21, 2
+    n = L + M
+    rs = np.random.RandomState(30)
+    with qc.Register(L, M) as ex, qc.Register(L, M) as tl:
+        tl.set_fusion(2)
+        for reg in (ex, tl):
+            qc.reset_register(reg); qc.quantum_computation(Cn, a, reg)
+        assert abs(tl.norm2() - 1.0) < 1e-12
+        scale = 2.0 ** -(L // 2)
+        for s in sorted({0, (1 << n) - (1 << W)} | {int(v) << W for v in rs.randint(0, 1 << (n - W), 8)}):
+            assert max_delta(tl.read(s, 1 << W), ex.read(s, 1 << W)) <= TOL * scale, s
+        for r in (0.123456789, 0.5, 0.987654321):
+            for reg in (ex, tl):
+                qc.reset_register(reg); qc.quantum_computation(Cn, a, reg)
+            assert qc.measure_state(ex, r) == qc.measure_state(tl, r)

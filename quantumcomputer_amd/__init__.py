@@ -3,7 +3,7 @@
 Only what the path needs: csrc/ (HIP kernels + the C ABI, built into libqcx.so),
 the ctypes loader and the host-side mirror of the reference's gate interface.
 """
-from ._lib import LIB_PATH, QcxError, fusion_plan, idle_devices, lib, polar, spread_devices, tune  # noqa: F401
+from ._lib import LIB_PATH, QcxError, front_plan, fusion_plan, idle_devices, lib, polar, spread_devices, tune  # noqa: F401
 from .register import (Register, Rng, load_state_file, c_amodc_gate, c_phase_shift_gate, check_normalisation,  # noqa: F401
                        display_state, hadamard_gate,
                        inverse_QFT, measure_state, quantum_computation, read_omega,

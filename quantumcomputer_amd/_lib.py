@@ -102,7 +102,25 @@ _EXTRA = {
     "qcx_sharded_relay_stats": (_i, [_p, C.POINTER(_u), C.POINTER(_ul)]),
     "qcx_sharded_overlap_stats": (_i, [_p, C.POINTER(_u), C.POINTER(_ul)]),
     "qcx_sharded_layout": (_i, [_p, C.POINTER(_u), _u]),
+    "qcx_front_plan": (_i, [_u, _u, _u64, _u, _p, C.POINTER(_u), _p, C.c_size_t]),
 }
+
+
+class BasisFront(C.Structure):
+    """struct BasisFront (csrc/qcx_kernels.h): the parameters of k_basis_front"""
+    _fields_ = [("basis", C.c_uint64), ("hmask", C.c_uint64), ("fixed_mask", C.c_uint64), ("sign_mask", C.c_uint64),
+                ("v", C.c_double), ("M", C.c_uint), ("ncam", C.c_uint), ("C", C.c_uint32 * 64), ("A", C.c_uint32 * 64),
+                ("ctl", C.c_uint8 * 64)]
+
+
+def front_plan(n_local, M, basis, descs):
+    """host half of the basis-state front (no GPU): (gates consumed, BasisFront)"""
+    arr = (GateDesc * max(len(descs), 1))()
+    for i, d in enumerate(descs):
+        arr[i].type, arr[i].q, arr[i].mask, arr[i].c, arr[i].s, arr[i].C, arr[i].A = d
+    used, B = C.c_uint(0), BasisFront()
+    check(lib().qcx_front_plan(n_local, M, basis, len(descs), C.cast(arr, C.c_void_p), C.byref(used), C.byref(B), C.sizeof(B)), "qcx_front_plan")
+    return used.value, B
 
 class GateDesc(C.Structure):
     """qcx_gate_desc (include/qcx.h)"""

@@ -1056,6 +1056,21 @@ extern "C" int qcx_fusion_plan_mode(int mode, unsigned n_local, unsigned M, unsi
     return QCX_NO_ERROR;
 }
 
+// The host half of the basis-state circuit front alone (no GPU needed; test interface, not in the public header): how many
+// leading gates of the list have the closed form on basis state `basis` of an (n_local, M) register, and the parameters
+// k_basis_front would get (struct BasisFront, csrc/qcx_kernels.h).
+extern "C" int qcx_front_plan(unsigned n_local, unsigned M, uint64_t basis, unsigned count, const qcx_gate_desc *gates,
+                              unsigned *used, void *front_out, size_t front_bytes)
+{
+    if (n_local == 0 || n_local > 40 || M > n_local || (count && !gates) || !used || !front_out || front_bytes < sizeof(BasisFront)) return QCX_BAD_ARGUMENTS;
+    std::vector<QGate> q;
+    QCX_TRY(descs_to_gates(n_local, M, count, gates, q));
+    BasisFront B;
+    *used = (unsigned)front_plan(n_local, M, basis, tune_now(), q, &B);
+    memcpy(front_out, &B, sizeof B);
+    return QCX_NO_ERROR;
+}
+
 // gate fusion: 1 = queue gates and run them as fused LDS-tile passes; results are
 // bit-identical to the per-gate kernels.  Observing calls (read, norm, measure, synchronize, timers) flush.
 extern "C" int qcx_set_fusion(qcx_register *r, int enable)

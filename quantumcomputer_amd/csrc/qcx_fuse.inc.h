@@ -725,12 +725,11 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
 // The register is the basis state r->basis_index but nothing has been written yet (lazy reset / collapse).  Write it now --
 // together with the longest prefix of the queue that has a closed form on a basis state: Hadamards on distinct qubits, then
 // controlled modular multiplies (K0b, k_basis_front; the front of Q:712-737 is exactly that).  *used = gates consumed.
-static int basis_front(qcx_register *r, const std::vector<QGate> &gates, size_t *used)
+// the host half of the front: which prefix of `gates` has the closed form on basis state `basis`, and the kernel's
+// parameters for it.  Pure (no HIP call): qcx_front_plan exposes it to the CPU-only tests, which emulate k_basis_front in
+// numpy and compare with the oracle.  Returns the number of gates consumed (0: nothing to fuse).
+static size_t front_plan(unsigned n, unsigned M, uint64_t basis, const Tune &tn, const std::vector<QGate> &gates, BasisFront *Bout)
 {
-    *used = 0;
-    const unsigned n = r->n, M = (unsigned)r->M;
-    r->basis_pending = 0;
-    const Tune tn = tune_now();
     size_t k = 0;
     uint64_t hmask = 0;
     unsigned nh = 0;
@@ -743,17 +742,31 @@ static int basis_front(qcx_register *r, const std::vector<QGate> &gates, size_t 
                 B.C[B.ncam] = gates[k].C; B.A[B.ncam] = gates[k].A % gates[k].C; B.ctl[B.ncam] = (uint8_t)gates[k].q; B.ncam++; k++;
             }
     }
+    const uint64_t nmask = (n >= 64) ? ~(uint64_t)0 : (((uint64_t)1 << n) - 1);
+    B.basis = basis; B.hmask = hmask; B.M = M;
+    B.fixed_mask = ~hmask & ~lowmask & nmask;
+    B.sign_mask = basis & hmask;
+    double v = 1.0;
+    for (unsigned q = 0; q < nh; q++) v = QCX_SQRT1_2 * v;              // fl(s * v), one rounding per Hadamard like the kernels
+    B.v = v;
+    *Bout = B;
+    return k;
+}
+
+// The register is the basis state r->basis_index but nothing has been written yet (lazy reset / collapse).  Write it now --
+// together with the longest prefix of the queue that has a closed form on a basis state: Hadamards on distinct qubits, then
+// controlled modular multiplies (K0b, k_basis_front; the front of Q:712-737 is exactly that).  *used = gates consumed.
+static int basis_front(qcx_register *r, const std::vector<QGate> &gates, size_t *used)
+{
+    *used = 0;
+    const unsigned n = r->n, M = (unsigned)r->M;
+    r->basis_pending = 0;
+    BasisFront B;
+    const size_t k = front_plan(n, M, r->basis_index, tune_now(), gates, &B);
     if (k == 0) {                                                       // nothing to fuse: the plain write
         if (r->basis_index == 1) return qcx_shard_reset(r->amp, n, 1, r->stream);
         return qcx_shard_collapse(r->amp, n, (int64_t)r->basis_index, r->stream);
     }
-    const uint64_t nmask = (n >= 64) ? ~(uint64_t)0 : (((uint64_t)1 << n) - 1);
-    B.basis = r->basis_index; B.hmask = hmask; B.M = M;
-    B.fixed_mask = ~hmask & ~lowmask & nmask;
-    B.sign_mask = r->basis_index & hmask;
-    double v = 1.0;
-    for (unsigned q = 0; q < nh; q++) v = QCX_SQRT1_2 * v;              // fl(s * v), one rounding per Hadamard like the kernels
-    B.v = v;
     const uint64_t nwaves = ((uint64_t)1 << n) >> (6 + M);
     hipLaunchKernelGGL(k_basis_front, dim3(grid_for(nwaves, 4, 65536, 256)), dim3(256), 0, r->stream, r->amp, n, B);
     HIP_TRY(hipGetLastError());

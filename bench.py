@@ -30,6 +30,8 @@ Extra objects on the JSON line:
                 measure_state).  Each with ms, passes, GB/s per pass, FP64-op/s and the fraction of each roof.
   config4       (N > 1) BASELINE config 4: H on every global qubit vs a local one at n = 29 + log2 N
                 (n = 32 on 8 GPUs), exchange GB/s per GPU.
+  config5       (N > 1) BASELINE config 5 in its N-GPU form: n = 30 Shor N = 21 (L = 25, M = 5) sharded over the ranks, circuit
+                time, exchanges, measured omega (also inside c_host for the one-process host).
   c_host        (N > 1) the same sweep and the config-4 shape through the ONE-process C-ABI sharded register
                 (qcx_register_create_sharded: peer stores over xGMI, no RCCL), run by a fresh child process of rank 0
                 before rank 0 touches a GPU; the register checks its exchange bit for bit at creation.
@@ -247,6 +249,7 @@ def main():
     dim = float(1 << n)
     sharded = args.gpus > 1 or args.force_sharded
     config4 = None
+    config5 = None
     exchange_mode = None
 
     if not sharded:
@@ -393,6 +396,31 @@ def main():
             if min(g) > res["local_h_ms"]:
                 config4["exchange_GBps_per_gpu"] = shard_bytes * (world - 1) / world / ((min(g) - res["local_h_ms"]) * 1e-3) / 1e9
             del r4
+            torch.cuda.empty_cache()
+            # BASELINE config 5 in its N-GPU form: n = 30 Shor N = 21 (L = 25, M = 5) sharded over the ranks, + measurement
+            # (full-size runs only: small --n-local rehearsals skip it)
+            try:
+                if args.n_local < 27:
+                    raise RuntimeError("skipped: --n-local below 27 (rehearsal run)")
+                r5 = ShardedRegister(25, 5, fusion=True, **({"slices_log2": 0} if exchange_mode == "sync" else {}))
+                if exchange_mode == "sync":
+                    r5.overlap = r5.async_exchange = False
+
+                def shor():
+                    r5.reset_register(); r5.quantum_computation(21, 2); r5.synchronize()
+                shor()
+                ex5 = r5.exchanges
+                t5 = min(timed(shor) for _ in range(2)) * 1e3
+                ex5 = (r5.exchanges - ex5) / 2
+                nrm5 = r5.norm2()
+                idx5 = r5.measure_state(0.37)
+                w5 = sum(((idx5 >> (29 - p)) & 1) << p for p in range(25)) / float(1 << 25)
+                config5 = {"workload": "n=30 Shor N=21 a=2 L=25 M=5 (375 gates) over %d GPUs, then measure_state" % world, "circuit_ms": t5,
+                           "exchanges_per_circuit": ex5, "total_probability": nrm5, "measured_index": idx5, "omega": w5,
+                           "nearest_multiple_of_one_sixth": min((abs(w5 - k6 / 6.0), k6) for k6 in range(7))[1]}
+                del r5
+            except Exception as e:      # reported, never fatal for the line
+                config5 = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         bytes_per_launch = 32.0 * float(1 << args.n_local)           # 16 B read + 16 B written per amplitude, per GPU
@@ -441,6 +469,7 @@ def main():
         if sharded:
             out["exchange_mode"] = exchange_mode
             out["config4"] = config4
+            out["config5"] = config5
             out["c_host"] = c_host
         if not args.no_cpu_baseline and args.gpus == 1:
             cpu_n = args.cpu_n or (30 if mem_available_gib() >= 48 else 28)
@@ -617,6 +646,23 @@ def c_host_child(args):
             if min(g) > res["local_h_ms"]:
                 c4["exchange_GBps_per_gpu"] = shard_bytes * (W - 1) / W / ((min(g) - res["local_h_ms"]) * 1e-3) / 1e9
             out["config4"] = c4
+        # BASELINE config 5 in its N-GPU form through the C host: n = 30 Shor N = 21 (L = 25, M = 5), + measurement
+        if n >= 30:
+            with qc.Register(25, 5, shards=W) as reg:
+                def shor():
+                    qc.reset_register(reg); qc.quantum_computation(21, 2, reg); reg.synchronize()
+                shor()
+                e0 = reg.sharded_stats()[0]
+                best = 1e9
+                for _ in range(2):
+                    t1 = time.perf_counter(); shor(); best = min(best, time.perf_counter() - t1)
+                ex = (reg.sharded_stats()[0] - e0) / 2
+                nrm = reg.norm2()
+                idx = qc.measure_state(reg, 0.37)
+                w = qc.read_omega(idx, reg)
+                out["config5"] = {"workload": "n=30 Shor N=21 a=2 L=25 M=5 (375 gates) over %d shards, then measure_state" % W,
+                                  "circuit_ms": best * 1e3, "exchanges_per_circuit": ex, "total_probability": nrm, "measured_index": idx,
+                                  "omega": w, "nearest_multiple_of_one_sixth": min((abs(w - k6 / 6.0), k6) for k6 in range(7))[1]}
     except Exception as e:      # reported, never fatal for the line
         out["error"] = f"{type(e).__name__}: {e}"
     print(json.dumps(out), flush=True)

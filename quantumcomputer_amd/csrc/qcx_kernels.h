@@ -1649,24 +1649,21 @@ __global__ __launch_bounds__(256) void k_basis_front(amp_t *__restrict__ amp, un
         bool pop = (bi & B.fixed_mask) == (B.basis & B.fixed_mask);
         for (unsigned g = 0; g < B.ncam; g++)
             if (((bi >> B.ctl[g]) & 1u) && f < B.C[g]) f = (B.A[g] * f) % B.C[g];
-        const int fcode = pop ? (int)f : -1;
+        // one packed word per block for the shuffles: residue | sign << 16, or -1 for an empty block
         const unsigned sgn_blk = (unsigned)__builtin_popcountll(bi & B.sign_mask) & 1u;
+        const int code = pop ? (int)(f | (sgn_blk << 16)) : -1;
+        const unsigned free_low = (unsigned)(B.hmask & lowmask), sign_low = (unsigned)(B.sign_mask & lowmask);
+        const double vp = B.v, vm = -B.v;
         for (unsigned j = 0; j < (1u << M); j++) {
             const unsigned e = j * 64u + lane;                      // element of the tile this lane stores
-            const unsigned src = e >> M;                            // its block
-            const int fc = __shfl(fcode, (int)src, 64);
-            const unsigned sb = (unsigned)__shfl((int)sgn_blk, (int)src, 64);
+            const int bc = __shfl(code, (int)(e >> M), 64);        // its block's word
             const unsigned low = e & lowmask;
             amp_t v; v.x = 0.0; v.y = 0.0;
-            if (fc >= 0) {
-                // with a block structure (ncam > 0, or M bits outside the Hadamard set) the low bits must equal the residue;
-                // low bits inside the Hadamard set are free (then ncam == 0 and fixed_mask covers the rest)
-                const unsigned free_low = (unsigned)(B.hmask & lowmask);
-                const bool hit = ((low ^ (unsigned)fc) & ~free_low) == 0;
-                if (hit) {
-                    const unsigned sg = (sb ^ ((unsigned)__builtin_popcount(low & (unsigned)(B.sign_mask & lowmask)) & 1u));
-                    v.x = sg ? -B.v : B.v;
-                }
+            // with a block structure (ncam > 0, or M bits outside the Hadamard set) the low bits must equal the residue;
+            // low bits inside the Hadamard set are free (then ncam == 0 and fixed_mask covers the rest)
+            if (bc >= 0 && ((low ^ (unsigned)bc) & ~free_low & lowmask) == 0) {
+                const unsigned sg = ((unsigned)bc >> 16) ^ ((unsigned)__builtin_popcount(low & sign_low) & 1u);
+                v.x = sg ? vm : vp;
             }
             __builtin_nontemporal_store(v, amp + tile0 + e);
         }

@@ -108,7 +108,7 @@ _EXTRA = {
 
 class BasisFront(C.Structure):
     """struct BasisFront (csrc/qcx_kernels.h): the parameters of k_basis_front"""
-    _fields_ = [("basis", C.c_uint64), ("hmask", C.c_uint64), ("fixed_mask", C.c_uint64), ("sign_mask", C.c_uint64),
+    _fields_ = [("first", C.c_uint64), ("basis", C.c_uint64), ("hmask", C.c_uint64), ("fixed_mask", C.c_uint64), ("sign_mask", C.c_uint64),
                 ("v", C.c_double), ("M", C.c_uint), ("ncam", C.c_uint), ("C", C.c_uint32 * 64), ("A", C.c_uint32 * 64),
                 ("ctl", C.c_uint8 * 64)]
 

@@ -1093,7 +1093,7 @@ extern "C" int qcx_flush(qcx_register *r)
 extern "C" int qcx_fusion_stats(qcx_register *r, unsigned long *passes, unsigned long *gates)
 {
     if (!r) return QCX_BAD_ARGUMENTS;
-    if (r->sh) { if (passes) *passes = 0; if (gates) *gates = 0; return QCX_NO_ERROR; }     // (per-device queues: see qcx_sharded_stats)
+    if (r->sh) { if (passes) *passes = r->sh->fronts; if (gates) *gates = 0; return QCX_NO_ERROR; }     // (circuit fronts written in one pass; the per-device pass queues are not counted: see qcx_sharded_stats)
     if (passes) *passes = (r->queue ? r->queue->passes_launched : 0) + r->fronts;
     if (gates) *gates = r->queue ? r->queue->gates_fused : 0;
     return QCX_NO_ERROR;

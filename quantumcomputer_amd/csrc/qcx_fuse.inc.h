@@ -743,7 +743,7 @@ static size_t front_plan(unsigned n, unsigned M, uint64_t basis, const Tune &tn,
             }
     }
     const uint64_t nmask = (n >= 64) ? ~(uint64_t)0 : (((uint64_t)1 << n) - 1);
-    B.basis = basis; B.hmask = hmask; B.M = M;
+    B.first = 0; B.basis = basis; B.hmask = hmask; B.M = M;
     B.fixed_mask = ~hmask & ~lowmask & nmask;
     B.sign_mask = basis & hmask;
     double v = 1.0;

@@ -1626,6 +1626,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
 // then the wave writes the 64 * 2^M amplitudes with coalesced 1-KiB stores, fetching each store's residues by shuffle.
 // ---------------------------------------------------------------------------
 struct BasisFront {
+    uint64_t first;                         // global index of the shard's amplitude 0 (0 for an unsharded register)
     uint64_t basis, hmask, fixed_mask;      // populated blocks: (i & fixed_mask) == (basis & fixed_mask)
     uint64_t sign_mask;                     // sign = parity of popcount(i & sign_mask)
     double   v;                             // magnitude after the Hadamards
@@ -1643,8 +1644,8 @@ __global__ __launch_bounds__(256) void k_basis_front(amp_t *__restrict__ amp, un
     const unsigned lowmask = (1u << M) - 1u;
     for (uint64_t t = wave; t < ntiles; t += nwaves) {
         const uint64_t tile0 = t << (6 + M);
-        // lane l: block l of the tile
-        const uint64_t bi = tile0 + ((uint64_t)lane << M);
+        // lane l: block l of the tile (bi = its GLOBAL index: controls, signs and the populated test may involve shard-id bits)
+        const uint64_t bi = B.first + tile0 + ((uint64_t)lane << M);
         unsigned f = (unsigned)(B.basis & lowmask);
         bool pop = (bi & B.fixed_mask) == (B.basis & B.fixed_mask);
         for (unsigned g = 0; g < B.ncam; g++)

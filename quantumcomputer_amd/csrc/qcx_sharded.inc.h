@@ -63,6 +63,9 @@ struct ShardSet {
     uint32_t nb_direct = 0, nb_relay = 0;         // blocks of 256 amplitudes of a chunk: direct stripe, each relay's stripe
     uint64_t stage_amps = 0;                      // amplitudes per staging slot (the last relay's stripe, the longest)
     unsigned long relayed_bytes = 0;
+    bool     basis_pending = false;               // reset_register is lazy: the basis state |1> is written at the next flush, together with
+                                                  // the closed-form circuit front if the queue starts with one (K0b, zero communication)
+    unsigned long fronts = 0;
     bool     in_selfcheck = false;                // this set IS the small register of a self-check (no nested checks)
     unsigned long selfchecks = 0;                 // pre-flight checks this register has passed (qcx_sharded_selfchecks)
     int      fusion = 1;                          // 1: each shard's gate list goes through the fused-pass scheduler; -1/0: one launch per gate
@@ -530,8 +533,38 @@ static std::vector<unsigned> sh_choose_give(const ShardSet *sh, const std::vecto
 // qubit of the shard id)
 static bool sh_sliceable(const ShardSet *sh, const SGate &g) { return g.type != FUSE_H || sh->perm[g.q] < sh->slice_bits; }
 
+// a lazily pending reset: every shard writes its part of the basis state |1> -- fused with the circuit front (Hadamards on
+// distinct qubits, then controlled modular multiplies, Q:720-731) when the queue starts with one.  The front's closed form
+// only looks at GLOBAL index bits, so a Hadamard or a control on a shard-id qubit costs nothing here: no exchange.
+static int sh_materialize_basis(ShardSet *sh)
+{
+    sh->basis_pending = false;                      // (the layout is the identity: sh_reset set it)
+    std::vector<QGate> qg;
+    for (const SGate &g : sh->queue) {
+        QGate q; memset(&q, 0, sizeof q);
+        if (g.type == FUSE_H) { q.type = FUSE_H; q.q = g.q; }
+        else if (g.type == FUSE_CAMODC && camodc_closed_form(sh->n, sh->M, g.C, g.A % g.C, g.q)) { q.type = FUSE_CAMODC; q.q = g.q; q.C = g.C; q.A = g.A; }
+        else break;
+        qg.push_back(q);
+    }
+    BasisFront B;
+    size_t used = 0;
+    if (sh->n_local >= sh->M + 6) used = front_plan(sh->n, sh->M, 1, tune_now(), qg, &B);
+    for (unsigned r = 0; r < sh->W; r++) {
+        SH_DEV(sh, r);
+        if (!used) { QCX_TRY(qcx_shard_reset(sh->buf[sh->cur][r], sh->n_local, r == 0, sh->st[r])); continue; }
+        B.first = (uint64_t)r << sh->n_local;
+        const uint64_t nwaves = ((uint64_t)1 << sh->n_local) >> (6 + sh->M);
+        hipLaunchKernelGGL(k_basis_front, dim3(grid_for(nwaves, 4, 65536, 256)), dim3(256), 0, sh->st[r], sh->buf[sh->cur][r], sh->n_local, B);
+        HIP_TRY(hipGetLastError());
+    }
+    if (used) { sh->queue.erase(sh->queue.begin(), sh->queue.begin() + used); sh->fronts++; }
+    return QCX_NO_ERROR;
+}
+
 static int sh_flush(ShardSet *sh)
 {
+    if (sh->basis_pending) QCX_TRY(sh_materialize_basis(sh));
     if (sh->queue.empty()) return QCX_NO_ERROR;
     std::vector<SGate> q;
     q.swap(sh->queue);
@@ -704,6 +737,8 @@ static int sh_reset(ShardSet *sh)
     sh->queue.clear();                              // pending gates act on a state that is being overwritten
     sh_identity_perm(sh);
     if (sh->dry) { sh->trace += "reset\n"; return QCX_NO_ERROR; }
+    if (sh->fusion > 0) { sh->basis_pending = true; return QCX_NO_ERROR; }      // lazily: see sh_materialize_basis
+    sh->basis_pending = false;
     for (unsigned r = 0; r < sh->W; r++) { SH_DEV(sh, r); QCX_TRY(qcx_shard_reset(sh->buf[sh->cur][r], sh->n_local, r == 0, sh->st[r])); }
     return QCX_NO_ERROR;
 }
@@ -711,6 +746,7 @@ static int sh_reset(ShardSet *sh)
 static int sh_fill_random(ShardSet *sh, uint64_t seed)
 {
     sh->queue.clear();
+    sh->basis_pending = false;
     sh_identity_perm(sh);
     if (sh->dry) return QCX_UNSUPPORTED;
     const double scale = sqrt(6.0 / (double)((uint64_t)1 << sh->n));

@@ -55,6 +55,11 @@ def test_shor_circuit_and_measurement(qc, ob, shards, C, L, M, a):
             picks.append((qc.measure_state(reg, rng), ob.measure(want, n, orng.uniform())))
             assert np.array_equal(bits(reg.read()), bits(want))          # collapsed the same way
         assert all(x == y for x, y in picks), picks
+        k = shards.bit_length() - 1
+        if n - k >= M + 6:
+            # the circuit front (reset + Hadamard layer, shard-id qubits included + multiply ladder) went out as one write
+            # pass per shard, without an exchange: one front per shot
+            assert reg.fusion_stats()[0] == 4
 
 
 def test_measurement_edges(qc, ob):

@@ -202,6 +202,14 @@ typedef struct {
     uint32_t C, A;      /* modular multiply: modulus and multiplier (A < C) */
 } qcx_gate_desc;
 int  qcx_shard_run_fused(void *amp, unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates, void *stream);
+/* This shard's part of the basis state |basis> of an (n, M) register -- amplitudes [first_global, first_global + 2^n_local)
+ * -- written together with the longest prefix of `gates` that has a closed form on a basis state: Hadamards on distinct
+ * qubits, then controlled modular multiplies (the front of Q:712-737).  Qubit numbers in `gates` are GLOBAL (identity
+ * layout); a Hadamard or a control on a shard-id qubit costs nothing.  Every rank calls it with the same list and gets
+ * the same *used (gates consumed; 0 = the plain basis state was written).  Replaces reset (Q:318-324) + those gates. */
+int  qcx_shard_basis_front(void *amp, unsigned n_local, uint64_t first_global, unsigned n, unsigned M, uint64_t basis,
+                           unsigned count, const qcx_gate_desc *gates, unsigned *used, void *stream);
+
 /* qcx_shard_run_fused keeps record buffers per (device, stream); call this before destroying a stream it was used on */
 int  qcx_shard_release_stream(void *stream);
 

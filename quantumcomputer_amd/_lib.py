@@ -85,6 +85,7 @@ SIGNATURES = {
     "qcx_shard_norm2": (_i, [_p, _u, C.POINTER(_d), _p]),
     "qcx_shard_run_fused": (_i, [_p, _u, _u, _u, _p, _p]),
     "qcx_shard_release_stream": (_i, [_p]),
+    "qcx_shard_basis_front": (_i, [_p, _u, _u64, _u, _u, _u64, _u, _p, C.POINTER(_u), _p]),
     "qcx_state_save": (_i, [_p, C.c_char_p]),
     "qcx_state_load": (_i, [_p, C.c_char_p]),
     "qcx_fusion_plan": (_i, [_u, _u, _u, _p, _p, _u, C.POINTER(_u), _p, C.c_size_t, C.POINTER(C.c_size_t)]),

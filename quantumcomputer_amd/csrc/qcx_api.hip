@@ -1056,6 +1056,40 @@ extern "C" int qcx_fusion_plan_mode(int mode, unsigned n_local, unsigned M, unsi
     return QCX_NO_ERROR;
 }
 
+// One shard's part of the basis state |basis> of an (n, M) register -- amplitudes [first_global, first_global + 2^n_local) --
+// written together with the longest prefix of `gates` (GLOBAL qubit numbers, identity layout) that has the closed form on
+// a basis state: Hadamards on distinct qubits, then controlled modular multiplies (K0b).  Every rank of a multi-process
+// host calls it with the same list and gets the same *used; no communication.  used = 0: the plain basis state.
+extern "C" int qcx_shard_basis_front(void *amp, unsigned n_local, uint64_t first_global, unsigned n, unsigned M, uint64_t basis,
+                                     unsigned count, const qcx_gate_desc *gates, unsigned *used, void *stream)
+{
+    if (!amp || !used || n_local == 0 || n_local > 40 || n < n_local || n > 40 || M > n_local || (count && !gates)) return QCX_BAD_ARGUMENTS;
+    if (basis >> n) return QCX_BAD_ARGUMENTS;
+    if (first_global & (((uint64_t)1 << n_local) - 1)) return QCX_BAD_ARGUMENTS;
+    *used = 0;
+    std::vector<QGate> q;
+    for (unsigned k = 0; k < count; k++) {                 // the front ends at the first gate that cannot be part of it
+        std::vector<QGate> one;
+        if (gates[k].type == 1 || descs_to_gates(n, M, 1, gates + k, one) != QCX_NO_ERROR) break;
+        q.push_back(one[0]);
+    }
+    BasisFront B;
+    size_t k = 0;
+    if (n_local >= M + 6 && M <= 12) k = front_plan(n, M, basis, tune_now(), q, &B);
+    hipStream_t st = (hipStream_t)stream;
+    if (k == 0) {
+        const uint64_t per = (uint64_t)1 << n_local;
+        const bool mine = basis >= first_global && basis - first_global < per;
+        return qcx_shard_collapse(amp, n_local, mine ? (int64_t)(basis - first_global) : -1, st);
+    }
+    B.first = first_global;
+    const uint64_t nwaves = ((uint64_t)1 << n_local) >> (6 + M);
+    hipLaunchKernelGGL(k_basis_front, dim3(grid_for(nwaves, 4, 65536, 256)), dim3(256), 0, st, (amp_t *)amp, n_local, B);
+    HIP_TRY(hipGetLastError());
+    *used = (unsigned)k;
+    return QCX_NO_ERROR;
+}
+
 // The host half of the basis-state circuit front alone (no GPU needed; test interface, not in the public header): how many
 // leading gates of the list have the closed form on basis state `basis` of an (n_local, M) register, and the parameters
 // k_basis_front would get (struct BasisFront, csrc/qcx_kernels.h).

@@ -76,6 +76,17 @@ class HipEngine:
             arr[i].type, arr[i].q, arr[i].mask, arr[i].c, arr[i].s, arr[i].C, arr[i].A = d
         check(lib().qcx_shard_run_fused(self._p(t), n_local, M, len(descs), C.cast(arr, C.c_void_p), self._s()), "qcx_shard_run_fused")
 
+    def basis_front(self, t, n_local, first_global, n, M, basis, descs):
+        """this shard's part of the basis state, fused with the closed-form front of `descs` (global qubit numbers);
+        returns the number of gates consumed (qcx_shard_basis_front)"""
+        arr = (GateDesc * max(len(descs), 1))()
+        for i, d in enumerate(descs):
+            arr[i].type, arr[i].q, arr[i].mask, arr[i].c, arr[i].s, arr[i].C, arr[i].A = d
+        used = C.c_uint(0)
+        check(lib().qcx_shard_basis_front(self._p(t), n_local, first_global, n, M, basis, len(descs), C.cast(arr, C.c_void_p),
+                                          C.byref(used), self._s()), "qcx_shard_basis_front")
+        return int(used.value)
+
     def swap_bits(self, src, dst, n_local, pos_a, pos_b):
         m = len(pos_a)
         a = (C.c_uint * max(m, 1))(*pos_a)
@@ -162,6 +173,8 @@ class ShardedRegister:
         self.queue = []
         self.max_queue = max_queue
         self.exchanges = 0                # all-to-alls performed
+        self.fronts = 0                   # circuit fronts written as one pass (qcx_shard_basis_front)
+        self._basis_pending = False
         self.pack_passes = 0              # local pack passes performed
         self.profile = None               # set to [] to collect (gate, ms, exchanged) per executed gate (cuda only)
 
@@ -387,6 +400,8 @@ class ShardedRegister:
         return g[0] != "h" or self.perm[g[1]] < self.slice_bits
 
     def flush(self):
+        if getattr(self, "_basis_pending", False):
+            self._materialize_basis()
         if not self.queue:
             return
         q, nl, S = self.queue, self.n_local, 1 << self.sigma
@@ -447,9 +462,32 @@ class ShardedRegister:
         self.queue = []                                   # pending gates act on a state that is being overwritten
         n = self.num_qubits
         self.perm, self.inv = list(range(n)), list(range(n))
+        if self.fusion and hasattr(self.engine, "basis_front"):
+            self._basis_pending = True                    # lazily: written at the next flush, fused with the circuit front (K0b)
+            return
+        self._basis_pending = False
         self.engine.reset(self.shard, self.n_local, self.rank == 0)
 
+    def _materialize_basis(self):
+        """a lazily pending reset: this rank's part of |0...01>, together with the queue's closed-form front (Hadamards on
+        distinct qubits -- shard-id qubits included --, then controlled modular multiplies): no exchange.  Every rank sees
+        the same queue and drops the same number of gates."""
+        self._basis_pending = False
+        descs = []
+        for g in self.queue:
+            if g[0] == "h":
+                descs.append((0, g[1], 0, 0.0, 0.0, 0, 0))
+            elif g[0] == "c":
+                descs.append((2, g[3], 0, 0.0, 0.0, g[1], g[2]))
+            else:
+                break
+        used = self.engine.basis_front(self.shard, self.n_local, self.rank << self.n_local, self.num_qubits, self.M_size, 1, descs)
+        if used:
+            self.queue = self.queue[used:]
+            self.fronts += 1
+
     def fill_random(self, seed):
+        self._basis_pending = False
         self.queue = []
         n = self.num_qubits
         self.perm, self.inv = list(range(n)), list(range(n))

@@ -145,12 +145,13 @@ def test_virtual_ranks_shor_and_measurement(ob, world, fusion):
         nrm = reg.norm2()
         reg.reset_register(); reg.quantum_computation(Cn, a)
         idx = reg.measure_state(r)
-        return state, nrm, idx, reg.gather(), reg.exchanges
+        return state, nrm, idx, reg.gather(), reg.exchanges, reg.fronts
 
     outs = run_virtual(world, body)
     want = np.zeros(2 << n); ob.reset(want, n); ob.quantum_computation(want, n, M, Cn, a, threads=8)
     w2 = want.copy(); widx = ob.measure(w2, n, r)
-    for state, nrm, idx, collapsed, ex in outs:
+    for state, nrm, idx, collapsed, ex, fronts in outs:
+        assert fronts == (2 if fusion else 0)           # reset + Hadamard layer + multiply ladder: one write pass per rank, no exchange
         assert np.array_equal(bits(state), bits(want))
         assert abs(nrm - 1.0) < 1e-12
         assert idx == widx

@@ -194,6 +194,7 @@ def sc_measure_edges(rank, world, ob, make):
         want = ob.fill_random(n, 21)
         res.append((reg.measure_state(r), ob.measure(want, n, r)))
     reg.reset_register()                        # all-zero state: r beyond total probability -> last index
+    reg.flush()                                 # (a reset is lazy on the HIP engine; the next line writes behind the register's back)
     reg.engine.collapse(reg.shard, reg.n_local, -1)
     res.append((reg.measure_state(0.5), (1 << n) - 1))
     return res

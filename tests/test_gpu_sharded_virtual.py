@@ -35,7 +35,7 @@ class FakeDist:
     def get_global_rank(self, group, r): return r
 
     def _sync_all(self):
-        for d in range(self.torch.cuda.device_count()):          # ranks may sit on different GPUs (multi-GPU box)
+        for d in range(max(1, self.torch.cuda.device_count())):          # ranks may sit on different GPUs (multi-GPU box)
             self.torch.cuda.synchronize(d)
 
     def _exchange(self, payload):
@@ -74,13 +74,15 @@ def run_virtual(world, body):
     import torch
     from quantumcomputer_amd import sharded
     fake = FakeDist(world)
+    torch.cuda.init()
+    ndev = max(1, torch.cuda.device_count())
     real = sharded.dist
     sharded.dist = fake
     out, err = [None] * world, []
 
     def worker(rank):
         try:
-            torch.cuda.set_device(rank % torch.cuda.device_count())      # spread over the visible GPUs (one GPU: all on 0)
+            torch.cuda.set_device(rank % ndev)      # spread over the visible GPUs (one GPU: all on 0)
             fake.tls.rank = rank
             out[rank] = body(rank, sharded.ShardedRegister)
         except Exception as e:      # pragma: no cover

@@ -130,7 +130,7 @@ unsigned qcx_ref_int_pow(double base, double power);
  *                multiply per amplitude by the product of the factors of its set target bits, FMA allowed.  Amplitudes
  *                differ from the bit-exact modes by rounding only: |delta| <= 1e-14 * |amplitude| per merged diagonal
  *                (tests bound the whole n <= 16 circuits at 1e-12; north_star asks 1e-10); zero signs are not
- *                canonicalised.  Unsharded registers only (a sharded register treats 2 as 1). */
+ *                canonicalised.  On a sharded register (qcx_register_create_sharded) every shard's passes run in this mode. */
 int  qcx_set_fusion(qcx_register *reg, int enable);
 int  qcx_flush(qcx_register *reg);
 int  qcx_fusion_stats(qcx_register *reg, unsigned long *passes_launched, unsigned long *gates_fused);
@@ -202,6 +202,8 @@ typedef struct {
     uint32_t C, A;      /* modular multiply: modulus and multiplier (A < C) */
 } qcx_gate_desc;
 int  qcx_shard_run_fused(void *amp, unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates, void *stream);
+/* the same in a fusion mode: 1 = bit-exact (qcx_shard_run_fused), 2 = tolerance mode (merged diagonals, see qcx_set_fusion) */
+int  qcx_shard_run_fused_mode(int mode, void *amp, unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates, void *stream);
 /* This shard's part of the basis state |basis> of an (n, M) register -- amplitudes [first_global, first_global + 2^n_local)
  * -- written together with the longest prefix of `gates` that has a closed form on a basis state: Hadamards on distinct
  * qubits, then controlled modular multiplies (the front of Q:712-737).  Qubit numbers in `gates` are GLOBAL (identity

@@ -84,6 +84,7 @@ SIGNATURES = {
     "qcx_shard_swap_bits": (_i, [_p, _p, _u, _u, C.POINTER(_u), C.POINTER(_u), _p]),
     "qcx_shard_norm2": (_i, [_p, _u, C.POINTER(_d), _p]),
     "qcx_shard_run_fused": (_i, [_p, _u, _u, _u, _p, _p]),
+    "qcx_shard_run_fused_mode": (_i, [_i, _p, _u, _u, _u, _p, _p]),
     "qcx_shard_release_stream": (_i, [_p]),
     "qcx_shard_basis_front": (_i, [_p, _u, _u64, _u, _u, _u64, _u, _p, C.POINTER(_u), _p]),
     "qcx_state_save": (_i, [_p, C.c_char_p]),

@@ -980,7 +980,16 @@ static int descs_to_gates(unsigned n_local, unsigned M, unsigned count, const qc
     return QCX_NO_ERROR;
 }
 
+extern "C" int qcx_shard_run_fused_mode(int mode, void *amp, unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates, void *stream);
+
 extern "C" int qcx_shard_run_fused(void *amp, unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates, void *stream)
+{
+    return qcx_shard_run_fused_mode(1, amp, n_local, M, count, gates, stream);
+}
+
+// mode 1: bit-exact passes; 2: the tolerance mode's passes (merged diagonals; a phase with ONE mask bit -- its other qubit
+// is a constant 1 of the shard -- joins the diagonal of its run as a constant factor)
+extern "C" int qcx_shard_run_fused_mode(int mode, void *amp, unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates, void *stream)
 {
     if (!amp || n_local == 0 || n_local > 40 || M > n_local || (count && !gates)) return QCX_BAD_ARGUMENTS;
     if (M > 12) return QCX_UNSUPPORTED;
@@ -999,7 +1008,7 @@ extern "C" int qcx_shard_run_fused(void *amp, unsigned n_local, unsigned M, unsi
     memset(&tmp, 0, sizeof tmp);
     tmp.L = (int)(n_local - M); tmp.M = (int)M; tmp.n = n_local; tmp.dim = (uint64_t)1 << n_local;
     tmp.amp = (amp_t *)amp; tmp.stream = tmp.own_stream = (hipStream_t)stream;
-    tmp.fusion = 1; tmp.queue = &sq->q;
+    tmp.fusion = mode == 2 ? 2 : 1; tmp.queue = &sq->q;
     tmp.queue->gates.clear();
     QCX_TRY(descs_to_gates(n_local, M, count, gates, tmp.queue->gates));
     return fuse_flush(&tmp);
@@ -1110,7 +1119,7 @@ extern "C" int qcx_front_plan(unsigned n_local, unsigned M, uint64_t basis, unsi
 extern "C" int qcx_set_fusion(qcx_register *r, int enable)
 {
     if (!r) return QCX_BAD_ARGUMENTS;
-    if (r->sh) { QCX_TRY(sh_flush(r->sh)); r->sh->fusion = enable >= 0 ? 1 : -1; return QCX_NO_ERROR; }   // (gates are always queued; -1 = one launch per gate)
+    if (r->sh) { QCX_TRY(sh_flush(r->sh)); r->sh->fusion = enable >= 2 ? 2 : (enable >= 0 ? 1 : -1); return QCX_NO_ERROR; }   // (gates are always queued; -1 = one launch per gate, 2 = tolerance mode per shard)
     FLUSH(r);
     r->fusion = enable >= 2 ? 2 : (enable > 0 ? 1 : (enable < 0 ? -1 : 0));
     return QCX_NO_ERROR;

@@ -26,22 +26,28 @@ struct DiagSpec {
     unsigned ctl;                 // the shared qubit
     uint64_t tmask;               // the other qubits of the run
     double   wc[40], ws[40];      // their factors (cos, sin), (1, 0) where not a target
+    double   kc, ks;              // constant factor: the run's phases on the shared qubit ALONE (their other qubit is a constant 1 of
+                                  // the view -- a shard-id or slice bit: sharded registers hand such gates down with one mask bit)
     size_t   first, count;        // the run in the ORIGINAL gate list
 };
 
 static void merge_diagonals(const std::vector<QGate> &in, std::vector<QGate> &out, std::vector<DiagSpec> &specs,
                             std::vector<size_t> &ofirst, std::vector<size_t> &ocnt)
 {
-    auto two_bit_phase = [&](size_t i) { return in[i].type == FUSE_PHASE && __builtin_popcountll(in[i].mask) == 2; };
+    auto phase_bits = [&](size_t i) { return in[i].type == FUSE_PHASE ? __builtin_popcountll(in[i].mask) : -1; };
+    // a run member on shared qubit b: a two-qubit phase containing b, or a phase on b alone
+    auto member = [&](size_t i, unsigned b) { const int pb = phase_bits(i); return (pb == 2 && ((in[i].mask >> b) & 1)) || (pb == 1 && in[i].mask == ((uint64_t)1 << b)); };
     size_t i = 0;
     unsigned last_h = 64;                  // target of the Hadamard just before (a single phase takes it as its control)
     while (i < in.size()) {
         size_t best_len = 0; unsigned best_ctl = 0;
-        if (two_bit_phase(i)) {
+        const int pb0 = phase_bits(i);
+        if (pb0 == 1 || pb0 == 2) {
             for (unsigned b = 0; b < 64; b++) {
                 if (!((in[i].mask >> b) & 1)) continue;
-                size_t j = i;
-                while (j < in.size() && two_bit_phase(j) && ((in[j].mask >> b) & 1)) j++;
+                size_t j = i, two = 0;
+                while (j < in.size() && member(j, b)) { two += phase_bits(j) == 2; j++; }
+                if (!two) continue;                                        // nothing but constants: not worth a diagonal
                 if (j - i > best_len || (j - i == best_len && b == last_h)) { best_len = j - i; best_ctl = b; }
             }
         }
@@ -52,15 +58,18 @@ static void merge_diagonals(const std::vector<QGate> &in, std::vector<QGate> &ou
         last_h = 64;
         DiagSpec d; memset(&d, 0, sizeof d);
         d.ctl = best_ctl; d.first = i; d.count = best_len;
-        long double wc[40], ws[40];
+        long double wc[40], ws[40], kc = 1.0L, ks = 0.0L;
         for (unsigned k = 0; k < 40; k++) { wc[k] = 1.0L; ws[k] = 0.0L; }
         for (size_t j = i; j < i + best_len; j++) {
+            const long double c = in[j].c, s2 = in[j].s;
+            if (phase_bits(j) == 1) { const long double x = kc, y = ks; kc = x * c - y * s2; ks = x * s2 + y * c; continue; }
             const unsigned k = (unsigned)__builtin_ctzll(in[j].mask & ~((uint64_t)1 << best_ctl));
             d.tmask |= (uint64_t)1 << k;
-            const long double c = in[j].c, s2 = in[j].s, x = wc[k], y = ws[k];
+            const long double x = wc[k], y = ws[k];
             wc[k] = x * c - y * s2; ws[k] = x * s2 + y * c;
         }
         for (unsigned k = 0; k < 40; k++) { d.wc[k] = (double)wc[k]; d.ws[k] = (double)ws[k]; }
+        d.kc = (double)kc; d.ks = (double)ks;
         QGate g; memset(&g, 0, sizeof g);
         g.type = FUSE_DIAG; g.q = best_ctl; g.mask = d.tmask; g.C = (unsigned)specs.size();
         specs.push_back(d);
@@ -199,13 +208,13 @@ static void build_pass_ops(const qcx_register *r, const std::vector<QGate> &gate
 }
 
 // tolerance mode: the table area of a pass's merged diagonals, in 16-byte units (one complex double each):
-//   [DiagInfo x nd (2 units each)] [G tables: nd x 48] [field tables: 256 entries per (diagonal, byte of the base index)
+//   [DiagInfo x nd (3 units each)] [G tables: nd x 48] [field tables: 256 entries per (diagonal, byte of the base index)
 //   that holds targets outside the tile]
 static void diag_tables(unsigned n, unsigned c, const std::vector<unsigned> &hbits, const std::vector<DiagSpec> &specs,
                         const std::vector<unsigned> &pass_diags, std::vector<double> &area)
 {
     const size_t nd = pass_diags.size();
-    area.assign(2 * (2 * nd + 48 * nd), 0.0);
+    area.assign(2 * (3 * nd + 48 * nd), 0.0);
     std::vector<int> local_of_bit(64, -1);
     for (unsigned b = 0; b < c; b++) local_of_bit[b] = (int)b;
     for (size_t j = 0; j < hbits.size(); j++) local_of_bit[hbits[j]] = (int)(c + j);
@@ -224,7 +233,7 @@ static void diag_tables(unsigned n, unsigned c, const std::vector<unsigned> &hbi
                     const long double cc = d.wc[gb], ss = d.ws[gb], nx = x * cc - y * ss, ny = x * ss + y * cc;
                     x = nx; y = ny;
                 }
-                double *e = &area[2 * (2 * nd + 48 * s + 16 * g + j)];
+                double *e = &area[2 * (3 * nd + 48 * s + 16 * g + j)];
                 e[0] = (double)x; e[1] = (double)y;
             }
         // field tables: byte f of the tile's base index (global bits 8f .. 8f+7), targets outside the tile only
@@ -251,7 +260,8 @@ static void diag_tables(unsigned n, unsigned c, const std::vector<unsigned> &hbi
                 area[at + 2 * j] = (double)x; area[at + 2 * j + 1] = (double)y;
             }
         }
-        memcpy(&area[2 * (2 * s)], &info, sizeof info);
+        info.kc = d.kc; info.ks = d.ks;
+        memcpy(&area[2 * (3 * s)], &info, sizeof info);
     }
     if (area.size() % 4) area.resize(area.size() + 2, 0.0);       // whole 32-byte records
 }

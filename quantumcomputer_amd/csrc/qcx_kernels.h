@@ -1145,7 +1145,10 @@ __device__ __forceinline__ unsigned fuse_camrun_step(amp_t *tile, unsigned short
 // between the butterflies.  Step word: bit 0 = the step's bit is rb1, bit 1 = a diagonal follows the H, bits 8-15 its
 // slot, bits 16-18 its groups, bit 19 = the round's OTHER register bit is one of its targets; 0xffffffff = no step.
 enum : uint32_t { FUSE_DIAG = 6, FUSE_QROUND = 7 };
-struct DiagInfo { uint32_t field_off[5]; uint32_t present; uint32_t pad[2]; };      // 32 B; offsets in 16-B units from the table area
+struct DiagInfo {               // 48 B = 3 units of 16 B; offsets in 16-B units from the table area
+    uint32_t field_off[5]; uint32_t present; uint32_t pad[2];
+    double   kc, ks;            // constant factor of the diagonal: the product of the run's phases whose other qubit is a constant 1
+};                              // of the view (a shard-id or slice bit): a sharded register hands such phases down with one mask bit
 
 __device__ __forceinline__ void cmul_tol(amp_t &v, const amp_t w)        // v *= w, 2 mul + 2 fma
 {
@@ -1381,7 +1384,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
     amp_t *dg = reinterpret_cast<amp_t *>(reinterpret_cast<unsigned char *>(lut) + P.dg_lds_off);
     const amp_t *dg_area = reinterpret_cast<const amp_t *>(ops + P.dg_rec_off);             // global: DiagInfo[], G tables, field tables
     if constexpr (TOL)
-        for (unsigned b = threadIdx.x; b < P.dg_cnt * 48u; b += BLOCK) dg[P.dg_cnt + b] = dg_area[2u * P.dg_cnt + b];
+        for (unsigned b = threadIdx.x; b < P.dg_cnt * 48u; b += BLOCK) dg[P.dg_cnt + b] = dg_area[3u * P.dg_cnt + b];
     __syncthreads();
     const unsigned c = P.c, nh = P.nh;
     const unsigned lowmask = (1u << c) - 1u;
@@ -1418,7 +1421,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
             if (threadIdx.x < P.dg_cnt) {
                 const DiagInfo *info = reinterpret_cast<const DiagInfo *>(dg_area) + threadIdx.x;
                 const uint32_t present = info->present;
-                amp_t E; E.x = 1.0; E.y = 0.0;
+                amp_t E; E.x = info->kc; E.y = info->ks;
 #pragma unroll
                 for (unsigned f = 0; f < 5; f++)
                     if ((present >> f) & 1u) cmul_tol(E, dg_area[info->field_off[f] + (unsigned)((base >> (8u * f)) & 255u)]);
@@ -1529,7 +1532,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
     amp_t *dg = reinterpret_cast<amp_t *>(reinterpret_cast<unsigned char *>(tile + tsize) + P.dg_lds_off);
     const amp_t *dg_area = reinterpret_cast<const amp_t *>(ops + P.dg_rec_off);
     if constexpr (!EXACT)
-        for (unsigned b = threadIdx.x; b < P.dg_cnt * 48u; b += BLOCK) dg[P.dg_cnt + b] = dg_area[2u * P.dg_cnt + b];
+        for (unsigned b = threadIdx.x; b < P.dg_cnt * 48u; b += BLOCK) dg[P.dg_cnt + b] = dg_area[3u * P.dg_cnt + b];
     __syncthreads();
     const amp_t *gtab = dg + P.dg_cnt;
     const unsigned c = P.c, nh = P.nh;
@@ -1557,7 +1560,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
         if (!EXACT && threadIdx.x < P.dg_cnt) {           // E_out of this tile for every diagonal of the pass, while the fill is in flight
             const DiagInfo *info = reinterpret_cast<const DiagInfo *>(dg_area) + threadIdx.x;
             const uint32_t present = info->present;
-            amp_t E; E.x = 1.0; E.y = 0.0;
+            amp_t E; E.x = info->kc; E.y = info->ks;
 #pragma unroll
             for (unsigned f = 0; f < 5; f++)
                 if ((present >> f) & 1u) cmul_tol(E, dg_area[info->field_off[f] + (unsigned)((base >> (8u * f)) & 255u)]);

@@ -306,7 +306,7 @@ static int sh_run_view(ShardSet *sh, const std::vector<POp> &ops, unsigned r, am
     for (const POp &o : ops) { qcx_gate_desc d; if (sh_desc(sh, o, r, nbits, sidx, &d)) descs.push_back(d); }
     if (descs.empty()) return QCX_NO_ERROR;
     if (sh->fusion > 0 && descs.size() > 1)
-        return qcx_shard_run_fused(a, nbits, sh->M, (unsigned)descs.size(), descs.data(), sh->st[r]);
+        return qcx_shard_run_fused_mode(sh->fusion, a, nbits, sh->M, (unsigned)descs.size(), descs.data(), sh->st[r]);
     for (const qcx_gate_desc &d : descs) {
         if (d.type == 0) QCX_TRY(qcx_shard_hadamard(a, nbits, d.q, sh->st[r]));
         else if (d.type == 1) QCX_TRY(qcx_shard_phase(a, nbits, d.mask, d.c, d.s, sh->st[r]));

@@ -67,14 +67,15 @@ class HipEngine:
     def camodc(self, t, n_local, M, Cn, A, ctl_local):
         check(lib().qcx_shard_camodc(self._p(t), n_local, M, Cn, A, ctl_local, self._s()), "qcx_shard_camodc")
 
-    def run_ops(self, t, n_local, M, descs):
-        """a list of (type, q, mask, c, s, C, A) tuples through the fusion scheduler (qcx_shard_run_fused)"""
+    def run_ops(self, t, n_local, M, descs, mode=1):
+        """a list of (type, q, mask, c, s, C, A) tuples through the fusion scheduler (qcx_shard_run_fused_mode: 1 = bit-exact
+        passes, 2 = the tolerance mode's passes)"""
         if not descs:
             return
         arr = (GateDesc * len(descs))()
         for i, d in enumerate(descs):
             arr[i].type, arr[i].q, arr[i].mask, arr[i].c, arr[i].s, arr[i].C, arr[i].A = d
-        check(lib().qcx_shard_run_fused(self._p(t), n_local, M, len(descs), C.cast(arr, C.c_void_p), self._s()), "qcx_shard_run_fused")
+        check(lib().qcx_shard_run_fused_mode(int(mode), self._p(t), n_local, M, len(descs), C.cast(arr, C.c_void_p), self._s()), "qcx_shard_run_fused_mode")
 
     def basis_front(self, t, n_local, first_global, n, M, basis, descs):
         """this shard's part of the basis state, fused with the closed-form front of `descs` (global qubit numbers);
@@ -156,6 +157,7 @@ class ShardedRegister:
         # run each window's gate list through the fused-pass scheduler (qcx_shard_run_fused): same bits, fewer HBM passes.
         # False: one kernel launch per gate (bench.py --gpus N uses that to stay comparable with its N = 1 headline)
         self.fusion = bool(fusion)
+        self.fusion_mode = 2 if (fusion is not True and fusion is not False and int(fusion) == 2) else 1     # 2: tolerance mode per shard
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = torch.device(device)
@@ -389,7 +391,10 @@ class ShardedRegister:
         ev0 = None
         if self.profile is not None and self.device.type == "cuda":
             ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True); ev0.record()
-        self.engine.run_ops(view, nbits, self.M_size, descs)
+        if self.fusion_mode == 2:
+            self.engine.run_ops(view, nbits, self.M_size, descs, 2)
+        else:
+            self.engine.run_ops(view, nbits, self.M_size, descs)
         if ev0 is not None:
             ev1.record()
             self.profile.append(("f", -1, ev0, ev1, nbits))

@@ -147,10 +147,10 @@ def _diag(P, re, im, rec, area, nd):
     for j in range(P.T):
         e |= P.bit(j).astype(np.int64) << j
     assert tloc < (1 << P.T) and all(((tloc >> (4 * g)) & 15) == 0 for g in range(3) if not (groups >> g) & 1)
-    G = area[2 * nd + 48 * slot: 2 * nd + 48 * (slot + 1)]
-    F = np.ones(P.idx.shape, dtype=np.complex128)
-    info = struct.unpack("<8I", area[2 * slot: 2 * slot + 2].tobytes())
+    G = area[3 * nd + 48 * slot: 3 * nd + 48 * (slot + 1)]
+    info = struct.unpack("<8I", area[3 * slot: 3 * slot + 2].tobytes())
     field_off, present = info[:5], info[5]
+    F = np.full(P.idx.shape, area[3 * slot + 2], dtype=np.complex128)        # the diagonal's constant factor (kc, ks)
     base = P.base.astype(np.int64)
     for f in range(5):
         if (present >> f) & 1:
@@ -253,7 +253,7 @@ def apply_pass(state, n, act, recs):
                     if sw & 2:
                         slot, groups, t_other = (sw >> 8) & 0xFF, (sw >> 16) & 7, (sw >> 19) & 1
                         # the same diagonal through the generic record: control = the H's bit, local target mask from the tables
-                        G = area[2 * nd + 48 * slot: 2 * nd + 48 * (slot + 1)]
+                        G = area[3 * nd + 48 * slot: 3 * nd + 48 * (slot + 1)]
                         tloc = 0
                         for lb in range(12):
                             if G[16 * (lb >> 2) + (1 << (lb & 3))] != 1.0:
@@ -282,7 +282,7 @@ def apply_pass(state, n, act, recs):
                     if sw & 4:
                         assert nd, "a diagonal in a pass without tables"
                         slot, groups = (sw >> 8) & 0xFF, (sw >> 16) & 7
-                        G = area[2 * nd + 48 * slot: 2 * nd + 48 * (slot + 1)]
+                        G = area[3 * nd + 48 * slot: 3 * nd + 48 * (slot + 1)]
                         tloc = 0
                         for lb in range(12):
                             if G[16 * (lb >> 2) + (1 << (lb & 3))] != 1.0:

@@ -320,3 +320,39 @@ def test_hadamard_sweep_takes_the_exact_radix8_form(qc, ob, tune_guard, n, mode)
     qc.tune(fuse_q3=0)
     acts, recs, _ = qc.fusion_plan(n, 0, descs, mode=mode)
     assert all((recs[a.rec_off].type & 0xFF) == emu.FUSE_ROUND for a in acts if a.fused)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_tolerance_mode_shard_level_lists(qc, ob, tune_guard, seed):
+    """what a sharded register hands to qcx_shard_run_fused_mode(2, ...): phases whose other qubit lives in the shard id arrive
+    with ONE mask bit (the shard's bit is 1) -- they join the diagonal of their run as its constant factor"""
+    rs = np.random.RandomState(700 + seed)
+    n = int(rs.randint(11, 15))
+    descs, ops = [], []
+    for l in range(n - 1, max(n - 9, 0), -1):
+        descs.append((0, l, 0, 0.0, 0.0, 0, 0)); ops.append(("h", l))
+        for k in range(l - 1, -1, -1):
+            c, s = qc.polar(math.pi / float(1 << (l - k)))
+            descs.append((1, 0, (1 << l) | (1 << k), c, s, 0, 0)); ops.append(("p2", l, k, c, s))
+        for _ in range(int(rs.randint(0, 4))):                         # targets in the shard id: a phase on l alone
+            th = float(rs.uniform(-1, 1)); c, s = qc.polar(th)
+            descs.append((1, 0, 1 << l, c, s, 0, 0)); ops.append(("p1", l, c, s))
+    acts, recs, _ = qc.fusion_plan(n, 0, descs, mode=2)
+    state = ob.fill_random(n, seed)
+    z = state[0::2] + 1j * state[1::2]
+    idx = np.arange(1 << n)
+    for o in ops:                                                      # independent complex128 evaluation (tolerance compare)
+        if o[0] == "h":
+            b = 1 << o[1]; lo = idx[(idx & b) == 0]; a0, a1 = z[lo].copy(), z[lo | b].copy()
+            z[lo], z[lo | b] = (a0 + a1) * emu.SQRT1_2, (a0 - a1) * emu.SQRT1_2
+        elif o[0] == "p2":
+            sel = ((idx >> o[1]) & 1).astype(bool) & ((idx >> o[2]) & 1).astype(bool); z[sel] *= complex(o[3], o[4])
+        else:
+            sel = ((idx >> o[1]) & 1).astype(bool); z[sel] *= complex(o[2], o[3])
+    class OneBitOracle:            # run_plan only needs the oracle for stand-alone gates: none of the one-bit phases stays alone here
+        def __getattr__(self, name):
+            return getattr(ob, name)
+    tot = emu.run_plan(state, n, 0, descs, acts, recs, OneBitOracle())
+    got = state[0::2] + 1j * state[1::2]
+    assert float(np.max(np.abs(got - z))) <= 1e-12
+    assert tot["diags"] >= 6

@@ -268,3 +268,31 @@ def test_exchange_selfcheck_passes_and_catches_a_wrong_trade(qc, monkeypatch, sh
     monkeypatch.setenv("QCX_SHARD_SELFCHECK", "0")                     # skipped: creation succeeds again
     with qc.Register(n, 0, shards=shards) as reg:
         assert reg.selfchecks == 0
+
+
+@pytest.mark.parametrize("shards,L,M", [(2, 12, 0), (4, 13, 4), (8, 14, 5), (4, 16, 0)])
+def test_tolerance_mode_on_a_sharded_register(qc, ob, shards, L, M):
+    """qcx_set_fusion(reg, 2) on a sharded register: every shard's passes merge their phase runs; phases whose other qubit
+    sits in the shard id join the diagonals as constant factors.  Within 1e-12 of the oracle, not bit-identical, and the
+    same measured indices as the exact mode for the same draws."""
+    n = L + M
+    Cn, a = (21, 2) if M >= 5 else (15, 7) if M == 4 else (1, 1)
+    with qc.Register(L, M, shards=shards, devices=qc.spread_devices(shards)) as reg:
+        reg.set_fusion(2)
+        reg.fill_random(6)
+        qc.inverse_QFT(reg)
+        got = reg.read()
+        want = ob.fill_random(n, 6); ob.iqft(want, n, M, 8)
+        d = got - want
+        assert float(np.max(np.hypot(d[0::2], d[1::2]))) <= 1e-12
+        assert not np.array_equal(bits(got), bits(want))
+        if M:
+            picks = []
+            for mode in (1, 2):
+                reg.set_fusion(mode)
+                out = []
+                for r in (0.11, 0.52, 0.93):
+                    qc.reset_register(reg); qc.quantum_computation(Cn, a, reg)
+                    out.append(qc.measure_state(reg, r))
+                picks.append(out)
+            assert picks[0] == picks[1]

@@ -133,7 +133,7 @@ def test_virtual_ranks_sweeps_and_mixed_gates(ob, world, slices):
         assert outs[0][1][1] > 10
 
 
-@pytest.mark.parametrize("world,fusion", [(2, False), (4, False), (2, True), (4, True)])
+@pytest.mark.parametrize("world,fusion", [(2, False), (4, False), (2, True), (4, True), (2, 2), (4, 2)])
 def test_virtual_ranks_shor_and_measurement(ob, world, fusion):
     L, M, Cn, a = 13, 5, 21, 2
     n = L + M
@@ -154,6 +154,10 @@ def test_virtual_ranks_shor_and_measurement(ob, world, fusion):
     w2 = want.copy(); widx = ob.measure(w2, n, r)
     for state, nrm, idx, collapsed, ex, fronts in outs:
         assert fronts == (2 if fusion else 0)           # reset + Hadamard layer + multiply ladder: one write pass per rank, no exchange
+        if fusion == 2:                                 # tolerance mode per shard: rounding-level differences only
+            d = np.asarray(state) - want
+            assert float(np.max(np.hypot(d[0::2], d[1::2]))) <= 1e-12 and abs(nrm - 1.0) < 1e-12 and idx == widx
+            continue
         assert np.array_equal(bits(state), bits(want))
         assert abs(nrm - 1.0) < 1e-12
         assert idx == widx

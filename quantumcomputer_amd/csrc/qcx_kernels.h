@@ -1144,7 +1144,7 @@ __device__ __forceinline__ unsigned fuse_camrun_step(amp_t *tile, unsigned short
 // and the kernel runs them as straight-line code: every table read of the round is issued up front, nothing is fetched
 // between the butterflies.  Step word: bit 0 = the step's bit is rb1, bit 1 = a diagonal follows the H, bits 8-15 its
 // slot, bits 16-18 its groups, bit 19 = the round's OTHER register bit is one of its targets; 0xffffffff = no step.
-enum : uint32_t { FUSE_DIAG = 6, FUSE_QROUND = 7 };
+enum : uint32_t { FUSE_DIAG = 6 /* planner-side only: a merged diagonal before the rounds are formed; never reaches a kernel */, FUSE_QROUND = 7 };
 struct DiagInfo {               // 48 B = 3 units of 16 B; offsets in 16-B units from the table area
     uint32_t field_off[5]; uint32_t present; uint32_t pad[2];
     double   kc, ks;            // constant factor of the diagonal: the product of the run's phases whose other qubit is a constant 1

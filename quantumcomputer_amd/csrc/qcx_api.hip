@@ -1084,7 +1084,7 @@ extern "C" int qcx_shard_basis_front(void *amp, unsigned n_local, uint64_t first
     }
     BasisFront B;
     size_t k = 0;
-    if (n_local >= M + 6 && M <= 12) k = front_plan(n, M, basis, tune_now(), q, &B);
+    if (M <= 12) k = front_plan(n, M, basis, tune_now(), q, &B);
     hipStream_t st = (hipStream_t)stream;
     if (k == 0) {
         const uint64_t per = (uint64_t)1 << n_local;
@@ -1092,9 +1092,7 @@ extern "C" int qcx_shard_basis_front(void *amp, unsigned n_local, uint64_t first
         return qcx_shard_collapse(amp, n_local, mine ? (int64_t)(basis - first_global) : -1, st);
     }
     B.first = first_global;
-    const uint64_t nwaves = ((uint64_t)1 << n_local) >> (6 + M);
-    hipLaunchKernelGGL(k_basis_front, dim3(grid_for(nwaves, 4, 65536, 256)), dim3(256), 0, st, (amp_t *)amp, n_local, B);
-    HIP_TRY(hipGetLastError());
+    QCX_TRY(launch_basis_front((amp_t *)amp, n_local, B, st));
     *used = (unsigned)k;
     return QCX_NO_ERROR;
 }

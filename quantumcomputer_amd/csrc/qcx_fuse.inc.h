@@ -507,6 +507,12 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
     case 11: QCX_FUSE_LAUNCH(512, 11); break;
     case 10: QCX_FUSE_LAUNCH(256, 10); break;
     case 9:  QCX_FUSE_LAUNCH(256, 9); break;
+    // registers of the reference's own sizes (n = 5 ... 8: the whole state is one tile): one wave, everything known at compile time
+    // (the generic kernel below took 60 us for the 13 gates of the C = 15, L = 3, M = 4 circuit; these take ~10)
+    case 8:  hipLaunchKernelGGL((k_fused<64, 8, false>), dim3(grid), dim3(64), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); break;
+    case 7:  hipLaunchKernelGGL((k_fused<64, 7, false>), dim3(grid), dim3(64), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); break;
+    case 6:  hipLaunchKernelGGL((k_fused<64, 6, false>), dim3(grid), dim3(64), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); break;
+    case 5:  hipLaunchKernelGGL((k_fused<64, 5, false>), dim3(grid), dim3(64), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); break;
     default: hipLaunchKernelGGL((k_fused<256, 0, false>), dim3(grid), dim3(256), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); break;
     }
 #undef QCX_FUSE_LAUNCH
@@ -730,11 +736,6 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
     }
 }
 
-// plan -> upload every pass's records in one copy -> launch in order.  No host synchronisation except waiting for
-// the PREVIOUS flush's kernels before its record buffers are reused.
-// The register is the basis state r->basis_index but nothing has been written yet (lazy reset / collapse).  Write it now --
-// together with the longest prefix of the queue that has a closed form on a basis state: Hadamards on distinct qubits, then
-// controlled modular multiplies (K0b, k_basis_front; the front of Q:712-737 is exactly that).  *used = gates consumed.
 // the host half of the front: which prefix of `gates` has the closed form on basis state `basis`, and the kernel's
 // parameters for it.  Pure (no HIP call): qcx_front_plan exposes it to the CPU-only tests, which emulate k_basis_front in
 // numpy and compare with the oracle.  Returns the number of gates consumed (0: nothing to fuse).
@@ -745,7 +746,7 @@ static size_t front_plan(unsigned n, unsigned M, uint64_t basis, const Tune &tn,
     unsigned nh = 0;
     const uint64_t lowmask = ((uint64_t)1 << M) - 1;
     BasisFront B; memset(&B, 0, sizeof B);
-    if (tn.fuse_front && n >= M + 6 && M <= 12) {
+    if (tn.fuse_front && M <= 12) {
         while (k < gates.size() && gates[k].type == FUSE_H && !((hmask >> gates[k].q) & 1)) { hmask |= (uint64_t)1 << gates[k].q; nh++; k++; }
         if (!(hmask & lowmask))
             while (k < gates.size() && gates[k].type == FUSE_CAMODC && gates[k].q != 0xffffffffu && B.ncam < 64) {
@@ -763,6 +764,21 @@ static size_t front_plan(unsigned n, unsigned M, uint64_t basis, const Tune &tn,
     return k;
 }
 
+// one shard's (or the whole register's) front: the wave-tile kernel, or one thread per amplitude for tiny registers
+static int launch_basis_front(amp_t *amp, unsigned n_local, const BasisFront &B, hipStream_t st)
+{
+    if (n_local >= B.M + 6) {
+        const uint64_t nwaves = ((uint64_t)1 << n_local) >> (6 + B.M);
+        hipLaunchKernelGGL(k_basis_front, dim3(grid_for(nwaves, 4, 65536, 256)), dim3(256), 0, st, amp, n_local, B);
+    } else
+        hipLaunchKernelGGL(k_basis_front_small, dim3(grid_for((uint64_t)1 << n_local, 256, 1024, 256)), dim3(256), 0, st, amp, n_local, B);
+    HIP_TRY(hipGetLastError());
+    return QCX_NO_ERROR;
+}
+
+// The register is the basis state r->basis_index but nothing has been written yet (lazy reset / collapse).  Write it now --
+// together with the longest prefix of the queue that has a closed form on a basis state: Hadamards on distinct qubits, then
+// controlled modular multiplies (K0b, k_basis_front; the front of Q:712-737 is exactly that).  *used = gates consumed.
 // The register is the basis state r->basis_index but nothing has been written yet (lazy reset / collapse).  Write it now --
 // together with the longest prefix of the queue that has a closed form on a basis state: Hadamards on distinct qubits, then
 // controlled modular multiplies (K0b, k_basis_front; the front of Q:712-737 is exactly that).  *used = gates consumed.
@@ -777,14 +793,14 @@ static int basis_front(qcx_register *r, const std::vector<QGate> &gates, size_t 
         if (r->basis_index == 1) return qcx_shard_reset(r->amp, n, 1, r->stream);
         return qcx_shard_collapse(r->amp, n, (int64_t)r->basis_index, r->stream);
     }
-    const uint64_t nwaves = ((uint64_t)1 << n) >> (6 + M);
-    hipLaunchKernelGGL(k_basis_front, dim3(grid_for(nwaves, 4, 65536, 256)), dim3(256), 0, r->stream, r->amp, n, B);
-    HIP_TRY(hipGetLastError());
+    QCX_TRY(launch_basis_front(r->amp, n, B, r->stream));
     r->fronts++;
     *used = k;
     return QCX_NO_ERROR;
 }
 
+// plan -> upload every pass's records in one copy -> launch in order.  No host synchronisation except waiting for
+// the PREVIOUS flush's kernels before its record buffers are reused.
 static int fuse_flush(qcx_register *r)
 {
     GateQueue *gq = r->queue;

@@ -1638,6 +1638,25 @@ struct BasisFront {
     uint8_t  ctl[64];
 };
 
+// the same rule, one thread per amplitude, for registers too small for a wave tile (n < M + 6: the reference's own sizes,
+// e.g. L = 3, M = 4): every thread walks the residue chain of its block itself -- a few thousand amplitudes at most
+__global__ __launch_bounds__(256) void k_basis_front_small(amp_t *__restrict__ amp, unsigned n, BasisFront B)
+{
+    const unsigned M = B.M;
+    const uint64_t lowmask = ((uint64_t)1 << M) - 1;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < ((uint64_t)1 << n); i += (uint64_t)gridDim.x * 256) {
+        const uint64_t gi = B.first + i, bi = gi & ~lowmask;
+        unsigned f = (unsigned)(B.basis & lowmask);
+        for (unsigned g = 0; g < B.ncam; g++)
+            if (((bi >> B.ctl[g]) & 1u) && f < B.C[g]) f = (B.A[g] * f) % B.C[g];
+        const unsigned low = (unsigned)(gi & lowmask), free_low = (unsigned)(B.hmask & lowmask);
+        amp_t v; v.x = 0.0; v.y = 0.0;
+        if ((bi & B.fixed_mask) == (B.basis & B.fixed_mask) && ((low ^ f) & ~free_low) == 0)
+            v.x = (__builtin_popcountll(gi & B.sign_mask) & 1) ? -B.v : B.v;
+        amp[i] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_basis_front(amp_t *__restrict__ amp, unsigned n, BasisFront B)
 {
     const unsigned lane = threadIdx.x & 63u;

@@ -549,14 +549,12 @@ static int sh_materialize_basis(ShardSet *sh)
     }
     BasisFront B;
     size_t used = 0;
-    if (sh->n_local >= sh->M + 6) used = front_plan(sh->n, sh->M, 1, tune_now(), qg, &B);
+    used = front_plan(sh->n, sh->M, 1, tune_now(), qg, &B);
     for (unsigned r = 0; r < sh->W; r++) {
         SH_DEV(sh, r);
         if (!used) { QCX_TRY(qcx_shard_reset(sh->buf[sh->cur][r], sh->n_local, r == 0, sh->st[r])); continue; }
         B.first = (uint64_t)r << sh->n_local;
-        const uint64_t nwaves = ((uint64_t)1 << sh->n_local) >> (6 + sh->M);
-        hipLaunchKernelGGL(k_basis_front, dim3(grid_for(nwaves, 4, 65536, 256)), dim3(256), 0, sh->st[r], sh->buf[sh->cur][r], sh->n_local, B);
-        HIP_TRY(hipGetLastError());
+        QCX_TRY(launch_basis_front(sh->buf[sh->cur][r], sh->n_local, B, sh->st[r]));
     }
     if (used) { sh->queue.erase(sh->queue.begin(), sh->queue.begin() + used); sh->fronts++; }
     return QCX_NO_ERROR;

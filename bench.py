@@ -517,6 +517,22 @@ def single_gpu_configs(qc, reps=3):
             d.update(fp64_ops=flops, fp64_ops_per_s=flops / (ms * 1e-3), fp64_vector_roof_frac=flops / (ms * 1e-3) / FP64_VECTOR_PEAK)
         return d
 
+    # config 1 on the GPU (BASELINE config 1 is the reference's own CPU case, n = 12 Shor N = 15): whole period-finding
+    # attempts -- reset, circuit (16 H + 8 C_AMODC + 28 CPHASE), measurement -- in a warm process, wall clock
+    for label, (L, M, Cn, a) in (("n7_C15_L3_M4", (3, 4, 15, 7)), ("n12_C15_L8_M4", (8, 4, 15, 7))):
+        rng = qc.Rng(1)
+        with qc.Register(L, M) as reg:
+            def attempt():
+                qc.reset_register(reg); qc.quantum_computation(Cn, a, reg); return qc.measure_state(reg, rng)
+            for _ in range(20):
+                attempt()
+            reg.synchronize(); t0 = time.perf_counter()
+            for _ in range(200):
+                attempt()
+            us = (time.perf_counter() - t0) / 200 * 1e6
+        out.setdefault("config1_on_gpu", {"workload": "one period-finding attempt (reset_register + quantum_computation + measure_state), "
+                                                      "warm process, 200 attempts, wall clock"})[label + "_us_per_attempt"] = us
+
     # config 2: n = 26 Hadamard sweep, one launch per gate
     n = 26
     with qc.Register(n, 0) as reg:

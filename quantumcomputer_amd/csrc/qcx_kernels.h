@@ -528,7 +528,8 @@ __global__ __launch_bounds__(1024) void k_meas_prefix(const double *__restrict__
     __syncthreads();
     if (threadIdx.x == 0) {
         double run = base;
-        for (unsigned k = 0; k < 1024; k++) { const double v = part[k]; part[k] = run; run += v; }
+        const unsigned used = (nblocks + per - 1u) / per;            // threads that hold blocks (the rest hold 0: 64 of 1024 at n = 14)
+        for (unsigned k = 0; k < used; k++) { const double v = part[k]; part[k] = run; run += v; }
     }
     __syncthreads();
     double run = part[threadIdx.x];

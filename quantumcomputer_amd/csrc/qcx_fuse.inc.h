@@ -613,7 +613,8 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
                 else if (gates[k].type != FUSE_DIAG && gates[k].type != FUSE_PHASE) { pure = false; break; }
             }
             const unsigned hb = (unsigned)__builtin_popcountll(hot), Ts = (unsigned)tn.fuse_tol_T;
-            auto passes_at = [&](unsigned TT) { return (hb + (TT - ccur) - 1) / (TT - ccur); };
+            // (a tile needs at least one hot bit: with fuse_c == the tile bits the estimate would divide by zero)
+            auto passes_at = [&](unsigned TT) { return TT > ccur ? (hb + (TT - ccur) - 1) / (TT - ccur) : 0xffffffffu; };
             // radix-8 rounds on 2^12 tiles (k_fused_q3) when they save a pass against both radix-4 geometries
             if (pure && hb && q3_allowed && tn.fuse_q3 && n >= 12 && ccur <= 4 && passes_at(12) < std::min(passes_at(Ts), passes_at(Tcur))) { Tcur = 12; want_q3 = true; }
             else if (pure && hb && passes_at(Ts) == passes_at(Tcur)) Tcur = Ts;
@@ -682,6 +683,8 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
             }
             if (lds > limit) {
                 all_ops.resize(act.op_off); rounds = false;
+                if (want_q3) { q3_refused = true; i = first; continue; }       // radix-8 records mean nothing to the plain gate list: plan again
+                act.P.dg_slim = 0; act.P.tol_scale = 1.0;                       // (launch_pass looks at dg_slim first)
                 if (keep_diags) {        // the plain gate list has no diagonal interpreter: back to the phases
                     legacy.clear(); pass_diags.clear(); keep_diags = false;
                     build_pass_ops(r, gates, first, i, c, hbits, legacy, &specs, &gates_in, true, &pass_diags);
@@ -786,14 +789,17 @@ static int basis_front(qcx_register *r, const std::vector<QGate> &gates, size_t 
 {
     *used = 0;
     const unsigned n = r->n, M = (unsigned)r->M;
-    r->basis_pending = 0;
     BasisFront B;
     const size_t k = front_plan(n, M, r->basis_index, tune_now(), gates, &B);
+    // (basis_pending is the only record of the logical state: it is cleared once the write has been launched, not before)
     if (k == 0) {                                                       // nothing to fuse: the plain write
-        if (r->basis_index == 1) return qcx_shard_reset(r->amp, n, 1, r->stream);
-        return qcx_shard_collapse(r->amp, n, (int64_t)r->basis_index, r->stream);
+        if (r->basis_index == 1) QCX_TRY(qcx_shard_reset(r->amp, n, 1, r->stream));
+        else QCX_TRY(qcx_shard_collapse(r->amp, n, (int64_t)r->basis_index, r->stream));
+        r->basis_pending = 0;
+        return QCX_NO_ERROR;
     }
     QCX_TRY(launch_basis_front(r->amp, n, B, r->stream));
+    r->basis_pending = 0;
     r->fronts++;
     *used = k;
     return QCX_NO_ERROR;

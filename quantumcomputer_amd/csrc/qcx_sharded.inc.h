@@ -538,8 +538,7 @@ static bool sh_sliceable(const ShardSet *sh, const SGate &g) { return g.type != 
 // only looks at GLOBAL index bits, so a Hadamard or a control on a shard-id qubit costs nothing here: no exchange.
 static int sh_materialize_basis(ShardSet *sh)
 {
-    sh->basis_pending = false;                      // (the layout is the identity: sh_reset set it)
-    std::vector<QGate> qg;
+    std::vector<QGate> qg;                          // (the layout is the identity: sh_reset set it)
     for (const SGate &g : sh->queue) {
         QGate q; memset(&q, 0, sizeof q);
         if (g.type == FUSE_H) { q.type = FUSE_H; q.q = g.q; }
@@ -556,6 +555,7 @@ static int sh_materialize_basis(ShardSet *sh)
         B.first = (uint64_t)r << sh->n_local;
         QCX_TRY(launch_basis_front(sh->buf[sh->cur][r], sh->n_local, B, sh->st[r]));
     }
+    sh->basis_pending = false;                      // only now: a failed launch above leaves the reset pending (and the queue whole)
     if (used) { sh->queue.erase(sh->queue.begin(), sh->queue.begin() + used); sh->fronts++; }
     return QCX_NO_ERROR;
 }

@@ -477,7 +477,6 @@ class ShardedRegister:
         """a lazily pending reset: this rank's part of |0...01>, together with the queue's closed-form front (Hadamards on
         distinct qubits -- shard-id qubits included --, then controlled modular multiplies): no exchange.  Every rank sees
         the same queue and drops the same number of gates."""
-        self._basis_pending = False
         descs = []
         for g in self.queue:
             if g[0] == "h":
@@ -487,6 +486,7 @@ class ShardedRegister:
             else:
                 break
         used = self.engine.basis_front(self.shard, self.n_local, self.rank << self.n_local, self.num_qubits, self.M_size, 1, descs)
+        self._basis_pending = False        # only after the write was launched: a failed launch leaves the reset pending
         if used:
             self.queue = self.queue[used:]
             self.fronts += 1

@@ -123,6 +123,9 @@ struct Tune {
     long meas_block_log = 0;   // parallel measurement: 2^this amplitudes per block (8..13); 0 = from the shard size
     long meas_parallel = 1;    // 0: always the single-wave sequential scan
     long meas_min_log2 = 12;   // shards below 2^this amplitudes use the single-wave scan (tools/probe_shots.py)
+    long meas_onepass = 1;     // parallel measurement: 1 = K4c (one read of the state: look-back + tree walk), 0 = K4b (two reads + one-wave chain)
+    long meas_dbg = 0;         // K4c diagnostics: bit 0 = no look-back (every binade guess from cum_in alone: times the pass without it)
+    long meas_spin_limit = 4000000;   // K4c: polls a look-back may spend on one window before it gives up (the block is then scanned exactly)
 };
 static Tune g_tune;
 static std::mutex g_tune_mutex;
@@ -132,7 +135,7 @@ static Tune tune_now() { std::lock_guard<std::mutex> lock(g_tune_mutex); return 
 extern "C" int qcx_tune_set(const char *key, long value)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); g_tune.name = value; return QCX_NO_ERROR; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_full) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_full) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_onepass) K(meas_spin_limit) K(meas_dbg) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact)
 #undef K
     return QCX_BAD_ARGUMENTS;
 }
@@ -140,7 +143,7 @@ extern "C" int qcx_tune_set(const char *key, long value)
 extern "C" long qcx_tune_get(const char *key)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); return g_tune.name; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_full) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_full) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_onepass) K(meas_spin_limit) K(meas_dbg) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact)
 #undef K
     return -1;
 }
@@ -170,6 +173,9 @@ struct Workspace {
     MeasBlock  *meas_blocks = nullptr;
     unsigned    meas_cap = 0;
     unsigned   *meas_stats = nullptr, *h_meas_stats = nullptr; // [slow-path blocks, blocks] of the last scan
+    meas_slot_t *meas_look = nullptr;   // K4c: look-back area (one allocation): agg, incl per workgroup, gincl per group (filled with ones), then
+                                        // gsum, gcount per group and the ticket (zeroed)
+    MeasBlock  *meas_up = nullptr;      // K4c: the levels above the records (sums of 64, 64^2, ... records), back to back
 };
 static const unsigned NORM_BLOCKS = 2048;
 static std::mutex g_ws_mutex;
@@ -619,26 +625,60 @@ extern "C" int qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_
             while (bits < 63 && ((uint64_t)1 << bits) < count) bits++;
             blog = bits ? (bits - 1) / 2 : 8;
         }
-        blog = std::min<unsigned>(std::max<unsigned>(blog, 8u), (unsigned)MEAS_BLOCK_LOG_MAX);
+        blog = std::min<unsigned>(std::max<unsigned>(blog, 8u), tn.meas_onepass ? 11u : (unsigned)MEAS_BLOCK_LOG_MAX);     // K4c: a record is one wave's 2^8 .. 2^11 amplitudes
         const uint64_t nb64 = (count + (((uint64_t)1 << blog) - 1)) >> blog;
         if (nb64 > 0x7fffffffULL) return QCX_UNSUPPORTED;
         const unsigned nblocks = (unsigned)nb64;
         {
             std::lock_guard<std::mutex> lock(g_ws_mutex);
             if (w->meas_cap < nblocks) {
-                if (w->meas_sums) { HIP_TRY(hipFree(w->meas_sums)); HIP_TRY(hipFree(w->meas_prefix)); HIP_TRY(hipFree(w->meas_blocks)); }
+                if (w->meas_sums) { HIP_TRY(hipFree(w->meas_sums)); HIP_TRY(hipFree(w->meas_prefix)); HIP_TRY(hipFree(w->meas_blocks));
+                                    HIP_TRY(hipFree(w->meas_look)); HIP_TRY(hipFree(w->meas_up)); }
                 w->meas_sums = w->meas_prefix = nullptr; w->meas_blocks = nullptr; w->meas_cap = 0;
+                w->meas_look = nullptr; w->meas_up = nullptr;
                 HIP_TRY(hipMalloc(&w->meas_sums, (size_t)nblocks * sizeof(double)));
                 HIP_TRY(hipMalloc(&w->meas_prefix, (size_t)nblocks * sizeof(double)));
-                HIP_TRY(hipMalloc(&w->meas_blocks, (size_t)nblocks * sizeof(MeasBlock)));
+                HIP_TRY(hipMalloc(&w->meas_blocks, ((size_t)nblocks + 4) * sizeof(MeasBlock)));
+                HIP_TRY(hipMalloc(&w->meas_look, (2 * (size_t)nblocks + 4 * ((size_t)nblocks / 64 + 2) + 8) * sizeof(meas_slot_t)));
+                HIP_TRY(hipMalloc(&w->meas_up, ((size_t)nblocks / 32 + 16) * sizeof(MeasBlock)));
                 w->meas_cap = nblocks;
             }
         }
+        if (tn.meas_onepass) {
+            // K4c: one read of the state (look-back for the binade guesses), a few tiny group launches, the tree walk.
+            // Here a "block" of 2^blog amplitudes is one RECORD (one wave); a workgroup takes four of them.
+            const unsigned nwg = (nblocks + 3u) / 4u, ngrp = (nwg + 63u) / 64u;
+            MeasLookback LB;
+            LB.agg = w->meas_look; LB.incl = LB.agg + nwg; LB.gsum = LB.incl + nwg; LB.gincl = LB.gsum + ngrp;
+            LB.ticket = reinterpret_cast<unsigned *>(LB.gincl + ngrp);
+            HIP_TRY(hipMemsetAsync(w->meas_look, 0xff, (2 * (size_t)nwg + 2 * (size_t)ngrp) * sizeof(meas_slot_t), st));
+            HIP_TRY(hipMemsetAsync(LB.ticket, 0, 2 * sizeof(meas_slot_t), st));
+            const unsigned spin = (unsigned)std::max<long>(1000, tn.meas_spin_limit);
+#define QCX_ONEPASS(B) hipLaunchKernelGGL((k_meas_onepass<B>), dim3(nwg), dim3(256), 0, st, (const amp_t *)amp, count, cum_in, LB, w->meas_blocks, spin, (unsigned)tn.meas_dbg)
+            switch (blog) {
+            case 8: QCX_ONEPASS(8); break;   case 9: QCX_ONEPASS(9); break;   case 10: QCX_ONEPASS(10); break;
+            default: QCX_ONEPASS(11); break;
+            }
+#undef QCX_ONEPASS
+            MeasLevels T;
+            memset(&T, 0, sizeof T);
+            T.lv[0] = w->meas_blocks; T.n[0] = nblocks; T.top = 0;
+            MeasBlock *up = w->meas_up;
+            while (T.n[T.top] > 64u && T.top < 4) {
+                const unsigned nin = T.n[T.top], nout = (nin + 63u) / 64u;
+                hipLaunchKernelGGL(k_meas_groups, dim3(nout), dim3(64), 0, st, T.lv[T.top], nin, up);
+                T.top++;
+                T.lv[T.top] = up; T.n[T.top] = nout;
+                up += nout;
+            }
+            hipLaunchKernelGGL(k_meas_walk, dim3(1), dim3(64), 0, st, (const amp_t *)amp, count, T, cum_in, r, w->mout, w->meas_stats, blog);
+        } else {
         hipLaunchKernelGGL((k_meas_blocksum<256>), dim3(nblocks), dim3(256), 0, st, (const amp_t *)amp, count, w->meas_sums, blog);
         hipLaunchKernelGGL(k_meas_prefix, dim3(1), dim3(1024), 0, st, w->meas_sums, nblocks, cum_in, w->meas_prefix);
         hipLaunchKernelGGL((k_meas_composite<256>), dim3(nblocks), dim3(256), 0, st, (const amp_t *)amp, count, w->meas_prefix, w->meas_blocks, blog);
         hipLaunchKernelGGL(k_meas_chain, dim3(1), dim3(64), 0, st, (const amp_t *)amp, count, w->meas_blocks, nblocks,
                            cum_in, r, w->mout, w->meas_stats, blog);
+        }
     }
     HIP_TRY(hipGetLastError());
     if (parallel) HIP_TRY(hipMemcpyAsync(w->h_meas_stats, w->meas_stats, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));

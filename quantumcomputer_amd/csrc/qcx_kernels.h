@@ -685,6 +685,399 @@ __global__ __launch_bounds__(64) void k_meas_chain(const amp_t *__restrict__ amp
 }
 
 // ---------------------------------------------------------------------------
+// K4c  measurement scan, exact and parallel, in ONE read of the state (round 4).
+//
+// K4b above reads the vector twice (approximate block sums for the binade guesses, then the integer increments under
+// those guesses) and walks the block records on one wave.  Here:
+//   1. k_meas_onepass   a workgroup of four waves takes four consecutive RECORDS of 2^RLOG amplitudes (one per wave, kept
+//                       as |amp|^2 in registers), publishes the (tree) sum of the four, obtains the approximate sum of
+//                       everything before it by a DECOUPLED LOOK-BACK, and every wave computes the integer increment S of
+//                       its record under the binade that prefix falls in -- one pass over HBM.  Workgroup ids are handed
+//                       out by an atomic ticket, so a workgroup only ever waits for workgroups that are already running.
+//                       The XCDs' L2s are not coherent, so every poll is a round trip to the memory side, and ~1300
+//                       workgroups run at once: polling their slots one by one costs more traffic than it hides (measured:
+//                       +0.45 ms per 16 GiB with 64 slots per poll, +2.3 ms with 512).  The look-back therefore has two
+//                       levels: the last member of every group of 64 workgroups publishes the group's sum as soon as it has seen
+//                       the other 63, and a later workgroup reads (a) the slots of the earlier members of its own group and
+//                       (b) ONE entry per earlier group -- its sum, or the running total through it.
+//                       The look-back only feeds the GUESS: the order of the approximate additions may differ from run to
+//                       run; the walk below validates every guess against the exact running sum, so the measured index
+//                       never depends on it;
+//   2. k_meas_groups    sums of 64, 64^2, ... consecutive records (a few tiny launches);
+//   3. k_meas_walk      one wave descends that tree with the EXACT running sum: 64 entries per step, whole groups at a
+//                       time while they are plain (integer additions inside one binade are associative); only a record with
+//                       a tie, an oversized element, a wrong guess, a binade crossing or the crossing of r is redone: as one
+//                       integer addition per 1024 amplitudes where that holds, per 64 below that, and the strictly
+//                       sequential chain only for the 64 amplitudes in which something happens.
+// ---------------------------------------------------------------------------
+typedef unsigned long long meas_slot_t;      // bits of a double; all ones = not published yet
+
+struct MeasLookback {
+    meas_slot_t *agg, *incl;                 // per workgroup: its sum / the running total through it
+    meas_slot_t *gsum, *gincl;               // per group of 64 workgroups: the group's sum (published by its last member) / the running total through it
+    unsigned    *ticket;
+};
+
+__device__ __forceinline__ uint64_t meas_inc(uint64_t b, int e, uint32_t &flags)    // b = bits of p > 0; increment of the running sum in ulps of binade e
+{
+    // branch-free (the callers unroll this 32 times): p/u = mp * 2^-sh, rounded to nearest; a tie (fraction exactly 1/2) is
+    // flagged, as is an element at or above the binade (sh <= 0).  sh = 53: quotient 0, remainder mp against half = 2^52;
+    // sh >= 54: half > mp, the increment is 0 (the shift is clamped to 63 for the far-away exponents).
+    const int ex = (int)((b >> 52) & 0x7ff);
+    const uint64_t mp = (b & 0xfffffffffffffULL) | (ex ? (uint64_t)1 << 52 : 0);       // subnormal: no implicit bit
+    const int sh = e - (ex ? ex : 1);
+    const bool big = sh <= 0;
+    const unsigned shc = (unsigned)(sh < 1 ? 1 : (sh > 63 ? 63 : sh));
+    const uint64_t rem = mp & (((uint64_t)1 << shc) - 1), half = (uint64_t)1 << (shc - 1);
+    const uint64_t inc = (mp >> shc) + (rem > half ? 1u : 0u);
+    flags |= big ? (uint32_t)MEAS_BIG : (rem == half ? (uint32_t)MEAS_TIE : 0u);
+    return big ? (uint64_t)1 << 54 : inc;
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return readlane_f64(v, 0);
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane)
+{
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), lane) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(v & 0xffffffffu), lane);
+}
+__device__ __forceinline__ meas_slot_t meas_poll(const meas_slot_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void meas_post(meas_slot_t *p, double v) { __hip_atomic_store(p, (meas_slot_t)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// one look-back window: lane l holds the slot at distance l (vi = a running total, or all ones; va = a plain sum, or all
+// ones; lanes at or beyond `lanes` hold nothing).  1: a running total was found and `run` is complete; 0: all `lanes`
+// sums consumed, go on further back; -1: a slot before the first running total is still unpublished
+__device__ __forceinline__ int meas_window(unsigned lane, unsigned lanes, meas_slot_t vi, meas_slot_t va, double &run)
+{
+    const bool in = lane < lanes;
+    const bool has_i = in && vi != ~0ULL, has_a = has_i || (in && va != ~0ULL);
+    const unsigned long long mi = __ballot(has_i), ma = __ballot(has_a);
+    const unsigned first = mi ? (unsigned)__builtin_ctzll(mi) : lanes;          // slots before it must have published their sums
+    const unsigned long long need = first >= 64 ? ~0ULL : (((unsigned long long)1 << first) - 1);
+    if ((ma & need) != need) return -1;
+    double c = 0.0;
+    if (lane < first) c = __longlong_as_double((long long)va);
+    else if (lane == first && mi) c = __longlong_as_double((long long)vi);
+    run += wave_sum_f64(c);
+    return mi ? 1 : 0;
+}
+
+template <int RLOG>
+__global__ __launch_bounds__(256) void k_meas_onepass(const amp_t *__restrict__ amp, uint64_t count, double cum_in,
+                                                       MeasLookback LB, MeasBlock *out, unsigned spin_limit, unsigned dbg)
+{
+    constexpr unsigned PER = (1u << RLOG) / 64u;            // amplitudes per lane: 4 .. 32
+    __shared__ unsigned s_blk;
+    __shared__ double red[4];
+    __shared__ uint64_t s_pref;
+    if (threadIdx.x == 0) s_blk = atomicAdd(LB.ticket, 1u);
+    __syncthreads();
+    const unsigned blk = s_blk, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint64_t rec = (uint64_t)blk * 4u + wave;
+    const uint64_t base = rec << RLOG;
+    double p[PER];
+    // loads in batches of 8 (8 x 16 B in flight per lane); the record's probabilities stay in registers
+    constexpr unsigned BATCH = PER < 8u ? PER : 8u;
+    if (((uint64_t)(blk + 1u) << (RLOG + 2)) <= count) {            // (all workgroups but the last: no per-load bounds test)
+#pragma unroll
+        for (unsigned kb = 0; kb < PER; kb += BATCH) {
+            amp_t v[BATCH];
+#pragma unroll
+            for (unsigned g = 0; g < BATCH; g++) v[g] = __builtin_nontemporal_load(amp + base + (uint64_t)(kb + g) * 64u + lane);
+#pragma unroll
+            for (unsigned g = 0; g < BATCH; g++) p[kb + g] = prob_of(v[g]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (unsigned k = 0; k < PER; k++) {            // (unrolled too: a run-time index would put p[] into scratch memory)
+            const uint64_t i = base + (uint64_t)k * 64u + lane;
+            double pk = 0.0;
+            if (i < count) pk = prob_of(amp[i]);
+            p[k] = pk;
+        }
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (unsigned k = 0; k < PER; k++) acc += p[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        double t = (red[0] + red[1]) + (red[2] + red[3]);
+        if (!(t < __builtin_inf())) t = __builtin_inf();          // NaN / Inf input: every later guess is "unknown" (exact path)
+        const unsigned g = blk >> 6, q = blk & 63u;
+        if (lane == 0) meas_post(&LB.agg[blk], t);
+        double run = 0.0;
+        int state = (dbg & 1u) ? 1 : 0;                            // dbg bit 0 (diagnostics): no look-back, every guess from cum_in alone
+        if (state) run = cum_in;
+        unsigned spins = 0;
+        // (a) the earlier members of this workgroup's own group, nearest first.  The LAST member of a group (q = 63) waits for
+        // all 63 sums whether or not a running total turns up among them: it publishes the group's sum (no atomics: float
+        // atomic adds from every workgroup plus a release-ordered count cost 6 ms per 16 GiB when tried)
+        while (state == 0 && q > 0) {
+            meas_slot_t vi = ~0ULL, va = ~0ULL;
+            if (lane < q) { vi = meas_poll(&LB.incl[blk - 1u - lane]); if (vi == ~0ULL || q == 63u) va = meas_poll(&LB.agg[blk - 1u - lane]); }
+            bool ready = true;
+            if (q == 63u) {
+                ready = __ballot(lane < q && va == ~0ULL) == 0ULL;
+                if (ready) {
+                    double gs = wave_sum_f64(lane < q ? __longlong_as_double((long long)va) : 0.0) + t;
+                    if (!(gs < __builtin_inf())) gs = __builtin_inf();
+                    if (lane == 0) meas_post(&LB.gsum[g], gs);
+                }
+            }
+            const int w = ready ? meas_window(lane, q, vi, va, run) : -1;
+            if (w >= 0) { state = w; break; }
+            if (++spins > spin_limit) { state = -1; break; }
+            __builtin_amdgcn_s_sleep(32);
+        }
+        // (b) whole groups before it, nearest first; "group -1" holds cum_in
+        int64_t gj = (int64_t)g - 1;
+        while (state == 0) {
+            const int64_t gi = gj - (int64_t)lane;
+            meas_slot_t vi = ~0ULL, va = ~0ULL;
+            unsigned lanes = 64;
+            if (gj < 63) lanes = (unsigned)(gj + 2);               // groups gj .. 0, then the virtual one
+            if (gi == -1) vi = (meas_slot_t)__double_as_longlong(cum_in);
+            else if (gi >= 0) { vi = meas_poll(&LB.gincl[gi]); if (vi == ~0ULL) va = meas_poll(&LB.gsum[gi]); }
+            const int w = meas_window(lane, lanes, vi, va, run);
+            if (w > 0) { state = 1; break; }
+            if (w == 0) { gj -= 64; continue; }
+            if (++spins > spin_limit) { state = -1; break; }       // (never seen; a bound, so that nothing can hang)
+            __builtin_amdgcn_s_sleep(32);
+        }
+        if (state < 0) run = __builtin_inf();
+        if (lane == 0) {
+            double through = run + t;
+            if (!(through < __builtin_inf())) through = __builtin_inf();
+            meas_post(&LB.incl[blk], through);
+            if (q == 63u) meas_post(&LB.gincl[g], through);
+            s_pref = (uint64_t)__double_as_longlong(run);
+        }
+    }
+    __syncthreads();
+    double pref = __longlong_as_double((long long)s_pref);
+    for (unsigned w = 0; w < wave; w++) pref += red[w];           // the waves before this one in the workgroup
+    const int e = (int)(((uint64_t)__double_as_longlong(pref) >> 52) & 0x7ff);
+    uint64_t S = 0;
+    uint32_t flags = (e == 0 || e == 0x7ff) ? (uint32_t)MEAS_EUNK : 0u;
+    bool nonzero = false;
+    const uint64_t SAT = (uint64_t)1 << 54;
+#pragma unroll
+    for (unsigned k = 0; k < PER; k++) {
+        const uint64_t b = (uint64_t)__double_as_longlong(p[k]);
+        uint32_t f1 = 0;
+        const uint64_t inc = meas_inc(b, e, f1);
+        nonzero |= b != 0;
+        S += b ? inc : 0;
+        flags |= b ? f1 : 0u;
+        if (S > SAT) S = SAT;
+    }
+    const unsigned long long any_nz = __ballot(nonzero);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        S += (uint64_t)__shfl_down((unsigned long long)S, o, 64);
+        flags |= (uint32_t)__shfl_down((int)flags, o, 64);
+    }
+    if (lane == 0) {
+        if (S > SAT) S = SAT;
+        MeasBlock mb; mb.S = S; mb.meta = (uint32_t)e | (flags & 0x7fff0000u) | (any_nz ? 0u : (uint32_t)MEAS_ALLZERO); mb.pad = 0;
+        out[rec] = mb;
+    }
+}
+
+// one level up: record g = 64 consecutive records of the level below (one wave each).  A group is PLAIN when all its
+// non-zero members are unflagged and were computed under the same binade; anything else sets MEAS_EUNK = "descend".
+__global__ __launch_bounds__(64) void k_meas_groups(const MeasBlock *__restrict__ in, unsigned nin, MeasBlock *__restrict__ outg)
+{
+    const unsigned lane = threadIdx.x, i = blockIdx.x * 64u + lane;
+    MeasBlock m; m.S = 0; m.meta = MEAS_ALLZERO; m.pad = 0;
+    if (i < nin) m = in[i];
+    const bool zero = (m.meta & MEAS_ALLZERO) != 0;
+    const unsigned long long nz = __ballot(!zero);
+    MeasBlock g; g.S = 0; g.meta = MEAS_ALLZERO; g.pad = 0;
+    if (nz) {
+        const int e_ref = __builtin_amdgcn_readlane((int)(m.meta & 0x7ffu), __builtin_ctzll(nz));
+        const bool bad = !zero && ((m.meta & (MEAS_TIE | MEAS_BIG | MEAS_EUNK)) || (int)(m.meta & 0x7ffu) != e_ref);
+        unsigned long long tot = zero ? 0ULL : (unsigned long long)m.S;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o, 64);
+        tot = readlane_u64(tot, 0);
+        if (tot > ((uint64_t)1 << 54)) tot = (uint64_t)1 << 54;
+        g.S = tot;
+        g.meta = (uint32_t)e_ref | (__ballot(bad) ? (uint32_t)MEAS_EUNK : 0u);
+    }
+    if (lane == 0) outg[blockIdx.x] = g;
+}
+
+// exact scan of one block.  Batches of 1024 amplitudes (16 per lane, the next batch's loads in flight meanwhile): when a
+// whole batch has no tie / oversized element and stays inside the binade and below r, it is ONE integer addition (one
+// wave reduction); otherwise its 16 groups of 64 are tried the same way, and only the group in which something happens
+// runs the strictly sequential chain.
+__device__ __forceinline__ bool meas_try_int(double &cum, double r, unsigned long long inc, uint32_t fl)
+{
+    // all lanes: inc = this lane's integer increments under the binade of cum, fl = its flags.  true: cum advanced exactly
+    const uint64_t cb = (uint64_t)__double_as_longlong(cum);
+    const int ec = (int)((cb >> 52) & 0x7ff);
+    if (ec == 0 || ec == 0x7ff) return false;
+    if (__ballot(fl != 0) != 0ULL) return false;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) inc += __shfl_down(inc, o, 64);
+    const uint64_t tot = readlane_u64(inc, 0);                                  // <= 1024 increments < 2^53 each: no overflow
+    const uint64_t Kn = ((cb & 0xfffffffffffffULL) | ((uint64_t)1 << 52)) + tot;
+    if (Kn >= ((uint64_t)1 << 53)) return false;
+    const double cn = __longlong_as_double((long long)(((uint64_t)ec << 52) | (Kn & 0xfffffffffffffULL)));
+    if (cn >= r) return false;
+    cum = cn;
+    return true;
+}
+
+__device__ __forceinline__ bool wave_exact_block(const amp_t *__restrict__ amp, uint64_t first, uint64_t len,
+                                                 double &cum, double r, uint64_t *hit_index, double *hit_cum)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    constexpr int G = 16;                                   // groups of 64 per batch
+    double nx[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) { const uint64_t o = (uint64_t)g * 64 + lane; nx[g] = 0.0; if (o < len) nx[g] = prob_of(amp[first + o]); }
+    for (uint64_t base0 = 0; base0 < len; base0 += 64 * G) {
+        double pv[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) pv[g] = nx[g];
+#pragma unroll
+        for (int g = 0; g < G; g++) {                       // prefetch the next batch
+            const uint64_t o = base0 + 64 * G + (uint64_t)g * 64 + lane;
+            nx[g] = 0.0;
+            if (o < len) nx[g] = prob_of(amp[first + o]);
+        }
+        if (!(cum >= r)) {                                  // the whole batch as one integer addition
+            const int ec = (int)(((uint64_t)__double_as_longlong(cum) >> 52) & 0x7ff);
+            unsigned long long inc = 0; uint32_t fl = 0;
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                const uint64_t pb = (uint64_t)__double_as_longlong(pv[g]);
+                uint32_t f1 = 0;
+                const uint64_t i1 = meas_inc(pb, ec, f1);
+                inc += pb ? i1 : 0; fl |= pb ? f1 : 0u;
+            }
+            if (meas_try_int(cum, r, inc, fl)) continue;
+        }
+#pragma unroll 1
+        for (int g = 0; g < G; g++) {
+            const uint64_t base = base0 + (uint64_t)g * 64;
+            if (base >= len) break;
+            double p = pv[0];                               // pv[g] without a run-time register index
+#pragma unroll
+            for (int q = 1; q < G; q++) p = (q == g) ? pv[q] : p;
+            if (!(cum >= r)) {
+                const int ec = (int)(((uint64_t)__double_as_longlong(cum) >> 52) & 0x7ff);
+                const uint64_t pb = (uint64_t)__double_as_longlong(p);
+                uint32_t fl = 0;
+                const uint64_t i1 = meas_inc(pb, ec, fl);
+                if (meas_try_int(cum, r, pb ? i1 : 0, pb ? fl : 0u)) continue;
+            }
+            double run = cum;
+#pragma unroll
+            for (int jj = 0; jj < 64; jj++) {
+                const double pj = readlane_f64(p, jj);
+                run = run + ((int)lane >= jj ? pj : 0.0);
+            }
+            const bool hit = (base + lane < len) && (run >= r);
+            const unsigned long long m = __ballot(hit);
+            if (m) {
+                const int firstl = __builtin_ctzll(m);
+                *hit_index = first + base + (uint64_t)firstl;
+                *hit_cum = readlane_f64(run, firstl);
+                return true;
+            }
+            cum = readlane_f64(run, 63);
+        }
+    }
+    return false;
+}
+
+struct MeasLevels {
+    const MeasBlock *lv[5];          // lv[0]: the records, lv[L]: sums of 64^L consecutive records
+    unsigned n[5];
+    int top;                         // highest level present
+};
+
+__global__ __launch_bounds__(64) void k_meas_walk(const amp_t *__restrict__ amp, uint64_t count, MeasLevels T,
+                                                  double cum_in, double r, MeasureOut *out, unsigned *stats, unsigned rlog)
+{
+    const unsigned lane = threadIdx.x;
+    const unsigned n0 = T.n[0];
+    double cum = cum_in;
+    unsigned slow = 0;
+    uint64_t b = 0;                                   // next record
+    int cap = T.top;                                  // highest level the next step may use
+    uint64_t hi = 0; double hc = 0.0;
+    // r already reached before the first addition (Q:289 with cum_0 >= cum_in): the first examined element is the answer
+    if (cum_in >= r) {
+        const uint64_t len = min((uint64_t)1 << rlog, count);
+        slow++;
+        if (wave_exact_block(amp, 0, len, cum, r, &hi, &hc)) {
+            if (lane == 0) { out->found = 1; out->index = hi; out->cum = hc; if (stats) { stats[0] = slow; stats[1] = n0; } }
+            return;
+        }
+        b = 1;
+    }
+    while (b < n0) {
+        int L = 0;
+        while (L < cap && (b & (((uint64_t)1 << (6 * (L + 1))) - 1)) == 0) L++;       // the highest level b is aligned to
+        const MeasBlock *rec = T.lv[L];
+        const unsigned nL = T.n[L];
+        const unsigned shift = 6u * (unsigned)L;
+        const uint64_t i0 = b >> shift;
+        const unsigned lim = L == T.top ? 64u : 64u - (unsigned)(i0 & 63u);       // up to the next boundary of the level above
+        MeasBlock mine; mine.S = 0; mine.meta = MEAS_ALLZERO; mine.pad = 0;
+        if (lane < lim && i0 + lane < nL) mine = rec[i0 + lane];
+        const uint64_t cb = (uint64_t)__double_as_longlong(cum);
+        const int ec = (int)((cb >> 52) & 0x7ff);
+        const bool ecok = ec != 0 && ec != 0x7ff;
+        const bool zero = (mine.meta & MEAS_ALLZERO) != 0;
+        const bool plain = zero || (ecok && !(mine.meta & (MEAS_TIE | MEAS_BIG | MEAS_EUNK)) && (int)(mine.meta & 0x7ffu) == ec);
+        // inclusive sums of the increments over the lanes (saturated entries stay below 2^54 each: no overflow in 64 of them)
+        unsigned long long inc = zero ? 0ULL : (unsigned long long)mine.S;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long up = __shfl_up(inc, o, 64);
+            if ((int)lane >= o) inc += up;
+        }
+        const uint64_t Kn = ((cb & 0xfffffffffffffULL) | ((uint64_t)1 << 52)) + inc;
+        bool ok = plain && lane < lim;
+        double cn = cum;                                 // the exact running sum through this lane's entry, if ok
+        if (ok && (!zero || inc != 0)) {
+            // (an all-zero entry adds nothing: its value is the one through the last non-zero lane before it)
+            ok = ecok && Kn < ((uint64_t)1 << 53);
+            if (ok) { cn = __longlong_as_double((long long)(((uint64_t)ec << 52) | (Kn & 0xfffffffffffffULL))); ok = !(cn >= r); }
+        }
+        const unsigned long long bad = ~__ballot(ok);
+        const unsigned adv = bad ? (unsigned)__builtin_ctzll(bad) : 64u;        // entries taken in this step (monotone sums: a good lane validates all before it)
+        if (adv) { cum = readlane_f64(cn, (int)adv - 1); b += (uint64_t)adv << shift; }
+        if (adv >= lim) { cap = T.top; continue; }
+        if (L > 0) { cap = L - 1; continue; }                                    // the entry at b needs a closer look
+        // level 0: record b the slow way
+        slow++;
+        const uint64_t first = b << rlog;
+        if (first >= count) break;
+        const uint64_t len = min((uint64_t)1 << rlog, count - first);
+        if (wave_exact_block(amp, first, len, cum, r, &hi, &hc)) {
+            if (lane == 0) { out->found = 1; out->index = hi; out->cum = hc; if (stats) { stats[0] = slow; stats[1] = n0; } }
+            return;
+        }
+        b++;
+        cap = T.top;
+    }
+    if (lane == 0) { out->found = 0; out->index = 0; out->cum = cum; if (stats) { stats[0] = slow; stats[1] = n0; } }
+}
+
+// ---------------------------------------------------------------------------
 // K6  fused multi-gate pass.  A workgroup stages a TILE of 2^T amplitudes in
 // LDS -- the c lowest index bits (contiguous runs of 2^c amplitudes = 16*2^c bytes) plus nh = T - c
 // arbitrary higher bits hbit[0..nh) -- applies a whole list of gates to it and writes it back: one

@@ -236,11 +236,21 @@ typedef struct {
     unsigned nops;                  /* records the kernel walks (the rest, if any, are tables) */
     unsigned table_bytes, table_rec_off;    /* folded modular-multiply tables: size, and offset in records from rec_off */
     unsigned diag_cnt, diag_rec_off;        /* tolerance mode: merged diagonals of the pass, record offset of their table area */
+    /* tile addressing (round 4).  tl[j] = the qubit that is tile-local bit j in the records.  A CHAINED pass (chained = 1) reads
+     * the register's current buffer under one logical -> physical layout and writes the other buffer under another one: tile-local
+     * bit j is input index bit in_pos[j]; the j-th lowest output position of the tile's bits is output index bit st_pos[j] and
+     * belongs to tile-local bit st_loc[j]; bits [src, src + len) of the tile number go to index bits [dst, dst + len) of the
+     * input / output / logical index (seg_in / seg_out / seg_lg).  In place (chained = 0): out = in = logical, seg_in only. */
+    unsigned chained;
+    unsigned char tl[16], in_pos[16], st_loc[16], st_pos[16];
+    unsigned char nseg_in, nseg_out, nseg_lg, pad_;
+    struct { unsigned char src, dst, len, pad; } seg_in[16], seg_out[16], seg_lg[16];
 } qcx_plan_action;
 int  qcx_fusion_plan(unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates,
                      qcx_plan_action *actions, unsigned max_actions, unsigned *n_actions,
                      qcx_fuse_record *records, size_t max_records, size_t *n_records);
-/* the same for a fusion mode: 1 = the bit-exact plan (what qcx_fusion_plan returns), 2 = the tolerance mode's plan */
+/* the same for a fusion mode: 1 = the bit-exact plan (what qcx_fusion_plan returns), 2 = the tolerance mode's plan;
+ * | 4: as a register with a second buffer plans (runs of passes chained through it, see qcx_plan_action) */
 int  qcx_fusion_plan_mode(int mode, unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates,
                           qcx_plan_action *actions, unsigned max_actions, unsigned *n_actions,
                           qcx_fuse_record *records, size_t max_records, size_t *n_records);

@@ -105,6 +105,7 @@ _EXTRA = {
     "qcx_sharded_overlap_stats": (_i, [_p, C.POINTER(_u), C.POINTER(_ul)]),
     "qcx_sharded_layout": (_i, [_p, C.POINTER(_u), _u]),
     "qcx_front_plan": (_i, [_u, _u, _u64, _u, _p, C.POINTER(_u), _p, C.c_size_t]),
+    "qcx_chain_stats": (_i, [_p, C.POINTER(_ul)]),
 }
 
 
@@ -140,13 +141,16 @@ class PlanAction(C.Structure):
     _fields_ = [("fused", C.c_int), ("first_gate", C.c_uint), ("ngates", C.c_uint), ("T", C.c_uint), ("c", C.c_uint),
                 ("nh", C.c_uint), ("hbit", C.c_ubyte * 16), ("nopipe", C.c_uint), ("rounds_form", C.c_uint),
                 ("rec_off", C.c_size_t), ("rec_cnt", C.c_size_t), ("nops", C.c_uint), ("table_bytes", C.c_uint),
-                ("table_rec_off", C.c_uint), ("diag_cnt", C.c_uint), ("diag_rec_off", C.c_uint)]
+                ("table_rec_off", C.c_uint), ("diag_cnt", C.c_uint), ("diag_rec_off", C.c_uint),
+                ("chained", C.c_uint), ("tl", C.c_ubyte * 16), ("in_pos", C.c_ubyte * 16), ("st_loc", C.c_ubyte * 16),
+                ("st_pos", C.c_ubyte * 16), ("nseg_in", C.c_ubyte), ("nseg_out", C.c_ubyte), ("nseg_lg", C.c_ubyte), ("pad_", C.c_ubyte),
+                ("seg_in", C.c_ubyte * 64), ("seg_out", C.c_ubyte * 64), ("seg_lg", C.c_ubyte * 64)]      # segments: (src, dst, len, pad) x 16
 
 
 def fusion_plan(n_local, M, descs, mode=1):
     """The pass planner alone (host code, no GPU needed).  descs: (type, q, mask, c, s, C, A) tuples as for
     qcx_shard_run_fused.  Returns (actions, records): a list of PlanAction and a ctypes array of FuseRecord.
-    mode 1: the bit-exact plan; 2: the tolerance mode's plan (merged diagonals)."""
+    mode 1: the bit-exact plan; 2: the tolerance mode's plan (merged diagonals); | 4: with chained passes (PlanAction.chained)."""
     arr = (GateDesc * max(len(descs), 1))()
     for i, d in enumerate(descs):
         arr[i].type, arr[i].q, arr[i].mask, arr[i].c, arr[i].s, arr[i].C, arr[i].A = d

@@ -106,6 +106,7 @@ struct Tune {
     long fuse_q3_cap = 3072;   // workgroups of k_fused_q3 (n = 28 inverse QFT: 3072 -> 6.17 ms, 2048 6.36, 24576 7.0, one per tile 8.3)
     long fuse_q3_cap_exact = 8192;
     long fuse_q3 = 1;          // tolerance mode: radix-8 fast rounds on 2^12 tiles when they save a pass (k_fused_q3)
+    long fuse_q3_c3 = 1;       // tolerance mode: radix-8 passes with 2^3-amplitude runs (9 hot bits) when that saves a pass
     long fuse_front = 1;       // a pending reset / collapse is written together with the closed-form front of the queue (K0b)
     long fuse_tol_T = 10;      // tolerance mode: tile bits of diagonal passes when that costs no extra pass (0: same as the rest)
     long fuse_tol_occ = 6;     // tolerance-mode passes (merged diagonals): waves per SIMD the kernel is built for (6 or 8)
@@ -120,6 +121,9 @@ struct Tune {
     long fuse_rounds = 1;      // fused passes: rounds form (4 amplitudes per thread in registers, radix-4 H steps)
     long fuse_ldsdma = 1;      // fused passes: fill the tile with global_load_lds (LDS-DMA)
     long fuse_max_queue = 4096;
+    long fuse_chain  = 1;      // runs of consecutive rounds-form passes go through the register's second buffer: every pass but the first reads
+                               // contiguous tiles, only its stores are gathered, the last one stores the identity layout again (FusePass)
+    long fuse_chain_min_n = 20; // ... for registers of at least 2^this amplitudes
     long meas_block_log = 0;   // parallel measurement: 2^this amplitudes per block (8..13); 0 = from the shard size
     long meas_parallel = 1;    // 0: always the single-wave sequential scan
     long meas_min_log2 = 12;   // shards below 2^this amplitudes use the single-wave scan (tools/probe_shots.py)
@@ -135,7 +139,7 @@ static Tune tune_now() { std::lock_guard<std::mutex> lock(g_tune_mutex); return 
 extern "C" int qcx_tune_set(const char *key, long value)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); g_tune.name = value; return QCX_NO_ERROR; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_full) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_onepass) K(meas_spin_limit) K(meas_dbg) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_full) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_onepass) K(meas_spin_limit) K(meas_dbg) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_min_n) K(fuse_q3_c3)
 #undef K
     return QCX_BAD_ARGUMENTS;
 }
@@ -143,7 +147,7 @@ extern "C" int qcx_tune_set(const char *key, long value)
 extern "C" long qcx_tune_get(const char *key)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); return g_tune.name; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_full) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_onepass) K(meas_spin_limit) K(meas_dbg) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_full) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_onepass) K(meas_spin_limit) K(meas_dbg) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_min_n) K(fuse_q3_c3)
 #undef K
     return -1;
 }
@@ -712,7 +716,8 @@ struct qcx_register {
     hipEvent_t ev0, ev1;
     hipEvent_t *events;
     unsigned   n_events;
-    amp_t     *scratch;         // second buffer, allocated on first use (M > 12 modular multiply only)
+    amp_t     *scratch;         // second buffer, allocated on first use (chained passes; M > 12 modular multiply)
+    int        no_chain;        // the buffer pointer was handed out (qcx_device_pointer) or no second buffer fits: passes work in place
     int        fusion;          // 1: every gate call is queued (fused passes, qcx_fuse.inc.h); 0: only the whole-circuit entry points; -1: nothing
     int        composite;       // > 0 while a whole-circuit entry point is queueing its gates
     struct GateQueue *queue;
@@ -967,7 +972,13 @@ extern "C" unsigned qcx_num_qubits(const qcx_register *r) { return r ? r->n : 0;
 extern "C" unsigned long qcx_num_states(const qcx_register *r) { return r ? (unsigned long)r->dim : 0; }
 extern "C" int qcx_L_size(const qcx_register *r) { return r ? r->L : 0; }
 extern "C" int qcx_M_size(const qcx_register *r) { return r ? r->M : 0; }
-extern "C" void *qcx_device_pointer(qcx_register *r) { if (!r || r->sh) return nullptr; (void)fuse_flush(r); return (void *)r->amp; }
+extern "C" void *qcx_device_pointer(qcx_register *r)
+{
+    if (!r || r->sh) return nullptr;
+    (void)fuse_flush(r);
+    r->no_chain = 1;             // the caller may keep the pointer: from now on the state stays in THIS buffer (no chained passes, which alternate between two)
+    return (void *)r->amp;
+}
 
 // shard-level gate list through the fusion scheduler: one queue (record buffers + the event that guards them) per
 // (device, stream), one user at a time.  A queue's event is only ever recorded on its own stream; the owner of a
@@ -1049,6 +1060,7 @@ extern "C" int qcx_shard_run_fused_mode(int mode, void *amp, unsigned n_local, u
     tmp.L = (int)(n_local - M); tmp.M = (int)M; tmp.n = n_local; tmp.dim = (uint64_t)1 << n_local;
     tmp.amp = (amp_t *)amp; tmp.stream = tmp.own_stream = (hipStream_t)stream;
     tmp.fusion = mode == 2 ? 2 : 1; tmp.queue = &sq->q;
+    tmp.no_chain = 1;                                    // a view of somebody else's memory: there is no second buffer behind it
     tmp.queue->gates.clear();
     QCX_TRY(descs_to_gates(n_local, M, count, gates, tmp.queue->gates));
     return fuse_flush(&tmp);
@@ -1073,6 +1085,7 @@ extern "C" int qcx_fusion_plan_mode(int mode, unsigned n_local, unsigned M, unsi
                                     qcx_fuse_record *records, size_t max_records, size_t *n_records)
 {
     if (n_local == 0 || n_local > 40 || M > n_local || (count && !gates) || !n_actions || !n_records) return QCX_BAD_ARGUMENTS;
+    if ((mode & 3) != 1 && (mode & 3) != 2) return QCX_BAD_ARGUMENTS;
     if (M > 12) return QCX_UNSUPPORTED;
     static_assert(sizeof(qcx_fuse_record) == sizeof(FuseOp), "record layout");
     qcx_register tmp;
@@ -1082,7 +1095,7 @@ extern "C" int qcx_fusion_plan_mode(int mode, unsigned n_local, unsigned M, unsi
     QCX_TRY(descs_to_gates(n_local, M, count, gates, q));
     std::vector<FuseAction> acts;
     std::vector<FuseOp> ops;
-    fuse_plan(&tmp, tune_now(), q, acts, ops, mode == 2);
+    fuse_plan(&tmp, tune_now(), q, acts, ops, (mode & 3) == 2, (mode & 4) != 0);       // mode | 4: with chained passes (a register with a second buffer)
     *n_actions = (unsigned)acts.size();
     *n_records = ops.size();
     if (acts.size() > max_actions || ops.size() > max_records || (!actions && !acts.empty()) || (!records && !ops.empty()))
@@ -1100,6 +1113,12 @@ extern "C" int qcx_fusion_plan_mode(int mode, unsigned n_local, unsigned M, unsi
         o.rec_off = a.op_off; o.rec_cnt = a.op_cnt; o.nops = a.P.nops;
         o.table_bytes = (unsigned)a.P.cam_ctl_local[1]; o.table_rec_off = (unsigned)a.P.cam_ctl_local[2];
         o.diag_cnt = a.P.dg_cnt; o.diag_rec_off = a.P.dg_rec_off;
+        o.chained = a.P.chained;
+        memcpy(o.tl, a.tl, sizeof o.tl);
+        memcpy(o.in_pos, a.P.in_pos, sizeof o.in_pos); memcpy(o.st_loc, a.P.st_loc, sizeof o.st_loc); memcpy(o.st_pos, a.P.st_pos, sizeof o.st_pos);
+        o.nseg_in = a.P.nseg_in; o.nseg_out = a.P.nseg_out; o.nseg_lg = a.P.nseg_lg;
+        static_assert(sizeof o.seg_in == sizeof a.P.seg_in, "segment layout");
+        memcpy(o.seg_in, a.P.seg_in, sizeof o.seg_in); memcpy(o.seg_out, a.P.seg_out, sizeof o.seg_out); memcpy(o.seg_lg, a.P.seg_lg, sizeof o.seg_lg);
     }
     if (!ops.empty()) memcpy(records, ops.data(), ops.size() * sizeof(FuseOp));
     return QCX_NO_ERROR;
@@ -1177,6 +1196,14 @@ extern "C" int qcx_fusion_stats(qcx_register *r, unsigned long *passes, unsigned
     if (r->sh) { if (passes) *passes = r->sh->fronts; if (gates) *gates = 0; return QCX_NO_ERROR; }     // (circuit fronts written in one pass; the per-device pass queues are not counted: see qcx_sharded_stats)
     if (passes) *passes = (r->queue ? r->queue->passes_launched : 0) + r->fronts;
     if (gates) *gates = r->queue ? r->queue->gates_fused : 0;
+    return QCX_NO_ERROR;
+}
+
+// diagnostics (not in the public header): fused passes that went out of place through the second buffer
+extern "C" int qcx_chain_stats(qcx_register *r, unsigned long *chained_passes)
+{
+    if (!r || !chained_passes) return QCX_BAD_ARGUMENTS;
+    *chained_passes = (!r->sh && r->queue) ? r->queue->chained_passes : 0;
     return QCX_NO_ERROR;
 }
 

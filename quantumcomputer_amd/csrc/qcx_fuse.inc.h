@@ -84,7 +84,7 @@ struct GateQueue {
     size_t   d_cap = 0;
     FuseOp  *h_ops = nullptr;       // pinned staging
     size_t   h_cap = 0;
-    unsigned long passes_launched = 0, gates_fused = 0;
+    unsigned long passes_launched = 0, gates_fused = 0, chained_passes = 0;
     hipEvent_t ev;                  // recorded after the last kernel of a flush: guards the record buffers
     bool     ev_valid = false;
 };
@@ -122,6 +122,7 @@ struct FuseAction {
     FusePass P;
     size_t   op_off, op_cnt, ngates, first_gate;
     int      nopipe;         // phase-dominated pass (planned on the smaller tile of fuse_T_phase); reported by qcx_fusion_plan
+    uint8_t  tl[16];         // the qubit that is tile-local bit j (the records' numbering)
 };
 
 static int launch_standalone(qcx_register *r, const QGate &g)
@@ -138,15 +139,16 @@ static int launch_standalone(qcx_register *r, const QGate &g)
 // `pass_diags`, whose tables diag_tables() builds), or -- expand -- the plain phases it was merged from (passes that do not
 // run in the rounds form have no diagonal interpreter).
 static void build_pass_ops(const qcx_register *r, const std::vector<QGate> &gates, size_t first, size_t last,
-                           unsigned c, const std::vector<unsigned> &hbits, std::vector<FuseOp> &out,
+                           const std::vector<unsigned> &tl, std::vector<FuseOp> &out,
                            const std::vector<DiagSpec> *specs = nullptr, const std::vector<QGate> *orig = nullptr,
                            bool expand = false, std::vector<unsigned> *pass_diags = nullptr)
 {
+    // tl[j] = the qubit that is tile-local bit j (in place on the identity layout: the c low bits, then the hot bits ascending;
+    // a chained pass orders them by where its input layout puts them)
     const unsigned n = r->n;
     auto local_of = [&](unsigned b, bool *inside) -> unsigned {
-        if (b < c) { *inside = true; return b; }
-        auto it = std::find(hbits.begin(), hbits.end(), b);
-        if (it != hbits.end()) { *inside = true; return c + (unsigned)(it - hbits.begin()); }
+        auto it = std::find(tl.begin(), tl.end(), b);
+        if (it != tl.end()) { *inside = true; return (unsigned)(it - tl.begin()); }
         *inside = false; return 0;
     };
     for (size_t k = first; k < last; k++) {
@@ -158,7 +160,7 @@ static void build_pass_ops(const qcx_register *r, const std::vector<QGate> &gate
         if (g.type == FUSE_DIAG) {
             const DiagSpec &d = (*specs)[g.C];
             if (expand) {
-                build_pass_ops(r, *orig, d.first, d.first + d.count, c, hbits, out);
+                build_pass_ops(r, *orig, d.first, d.first + d.count, tl, out);
                 continue;
             }
             const unsigned lc = local_of(d.ctl, &in);
@@ -178,7 +180,7 @@ static void build_pass_ops(const qcx_register *r, const std::vector<QGate> &gate
             const uint64_t nalt = d.count;
             memcpy(&o.s, &nalt, sizeof nalt);
             out.push_back(o);
-            build_pass_ops(r, *orig, d.first, d.first + d.count, c, hbits, out);
+            build_pass_ops(r, *orig, d.first, d.first + d.count, tl, out);
             continue;
         }
         if (g.type == FUSE_H) {
@@ -210,14 +212,13 @@ static void build_pass_ops(const qcx_register *r, const std::vector<QGate> &gate
 // tolerance mode: the table area of a pass's merged diagonals, in 16-byte units (one complex double each):
 //   [DiagInfo x nd (3 units each)] [G tables: nd x 48] [field tables: 256 entries per (diagonal, byte of the base index)
 //   that holds targets outside the tile]
-static void diag_tables(unsigned n, unsigned c, const std::vector<unsigned> &hbits, const std::vector<DiagSpec> &specs,
+static void diag_tables(unsigned n, const std::vector<unsigned> &tl, const std::vector<DiagSpec> &specs,
                         const std::vector<unsigned> &pass_diags, std::vector<double> &area)
 {
     const size_t nd = pass_diags.size();
     area.assign(2 * (3 * nd + 48 * nd), 0.0);
     std::vector<int> local_of_bit(64, -1);
-    for (unsigned b = 0; b < c; b++) local_of_bit[b] = (int)b;
-    for (size_t j = 0; j < hbits.size(); j++) local_of_bit[hbits[j]] = (int)(c + j);
+    for (size_t j = 0; j < tl.size(); j++) local_of_bit[tl[j]] = (int)j;
     for (size_t s = 0; s < nd; s++) {
         const DiagSpec &d = specs[pass_diags[s]];
         // G tables: group g covers tile-local bits 4g .. 4g+3; entry j = product of the factors of the targets among them
@@ -439,13 +440,13 @@ static void to_rounds(const Tune &tn, const std::vector<FuseOp> &legacy, unsigne
 
 // the rounds-only kernel, built for 6, 7 or 8 waves per SIMD; false when the geometry has no rounds form
 template <int B, int TT>
-static bool launch_rounds_kernel(int occ, int tol_occ, unsigned grid, size_t lds, hipStream_t st, amp_t *amp, unsigned n, const FusePass &P,
+static bool launch_rounds_kernel(int occ, int tol_occ, unsigned grid, size_t lds, hipStream_t st, const amp_t *amp, amp_t *amp_out, unsigned n, const FusePass &P,
                                  const FuseOp *d_ops, uint64_t ntiles)
 {
     if constexpr ((1u << TT) == 4u * B) {
         const bool cam = P.has_cam != 0;
         if (P.dg_cnt) {       // tolerance mode: the pass holds merged diagonals (K6t); 2 = every round is a fast round (slim kernel)
-#define QCX_TOL_LAUNCH(O, C, S) hipLaunchKernelGGL((k_fused_rounds<B, TT, O, C, S>), dim3(grid), dim3(B), lds, st, amp, n, P, d_ops, ntiles, d_ops)
+#define QCX_TOL_LAUNCH(O, C, S) hipLaunchKernelGGL((k_fused_rounds<B, TT, O, C, S>), dim3(grid), dim3(B), lds, st, amp, amp_out, n, P, d_ops, ntiles, d_ops)
             if (P.dg_slim) {
                 if (tol_occ >= 8) { if (cam) QCX_TOL_LAUNCH(8, true, 2); else QCX_TOL_LAUNCH(8, false, 2); }
                 else { if (cam) QCX_TOL_LAUNCH(6, true, 2); else QCX_TOL_LAUNCH(6, false, 2); }
@@ -453,22 +454,25 @@ static bool launch_rounds_kernel(int occ, int tol_occ, unsigned grid, size_t lds
 #undef QCX_TOL_LAUNCH
             return true;
         }
-#define QCX_ROUNDS_LAUNCH(O, C) hipLaunchKernelGGL((k_fused_rounds<B, TT, O, C>), dim3(grid), dim3(B), lds, st, amp, n, P, d_ops, ntiles, d_ops)
+#define QCX_ROUNDS_LAUNCH(O, C) hipLaunchKernelGGL((k_fused_rounds<B, TT, O, C>), dim3(grid), dim3(B), lds, st, amp, amp_out, n, P, d_ops, ntiles, d_ops)
         if (occ >= 8) { if (cam) QCX_ROUNDS_LAUNCH(8, true); else QCX_ROUNDS_LAUNCH(8, false); }
         else if (occ == 7) { if (cam) QCX_ROUNDS_LAUNCH(7, true); else QCX_ROUNDS_LAUNCH(7, false); }
         else { if (cam) QCX_ROUNDS_LAUNCH(6, true); else QCX_ROUNDS_LAUNCH(6, false); }
 #undef QCX_ROUNDS_LAUNCH
         return true;
     } else {
-        (void)occ; (void)tol_occ; (void)grid; (void)lds; (void)st; (void)amp; (void)n; (void)P; (void)d_ops; (void)ntiles;
+        (void)occ; (void)tol_occ; (void)grid; (void)lds; (void)st; (void)amp; (void)amp_out; (void)n; (void)P; (void)d_ops; (void)ntiles;
         return false;
     }
 }
 
-static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, const FuseOp *d_ops, bool nopipe)
+// amp_in / amp_out: the buffer the pass reads / writes (the same for a pass that works in place; a chained pass goes from one of
+// the register's two buffers to the other)
+static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, const FuseOp *d_ops, bool nopipe, amp_t *amp_in, amp_t *amp_out)
 {
     (void)nopipe;
     FusePass P = P_in;
+    if ((P.chained != 0) != (amp_in != amp_out)) { set_error("fused pass: chained flag and buffers disagree"); return QCX_UNKNOWN_ERROR; }
     const unsigned n = r->n;
     const uint64_t ntiles = (uint64_t)1 << (n - P.T);
     const unsigned grid = grid_for(ntiles, 1, tn.fuse_grid_cap);
@@ -489,16 +493,17 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
     const size_t lds = ((size_t)16 << P.T) + lut_bytes;
     // 4 amplitudes per thread (all loads of a tile in flight at once, few registers): block = 2^T / 4
 #define QCX_FUSE_LAUNCH(B, TTv) do { \
-        if (P.cam_ctl_local[0] && tn.fuse_ldsdma && tn.fuse_rounds_occ >= 6 && launch_rounds_kernel<B, TTv>((int)tn.fuse_rounds_occ, (int)tn.fuse_tol_occ, grid, lds, r->stream, r->amp, n, P, d_ops, ntiles)) { \
-        } else if (tn.fuse_ldsdma) hipLaunchKernelGGL((k_fused<B, TTv, true>), dim3(grid), dim3(B), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); \
-        else hipLaunchKernelGGL((k_fused<B, TTv, false>), dim3(grid), dim3(B), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); } while (0)
+        if (P.cam_ctl_local[0] && tn.fuse_ldsdma && tn.fuse_rounds_occ >= 6 && launch_rounds_kernel<B, TTv>((int)tn.fuse_rounds_occ, (int)tn.fuse_tol_occ, grid, lds, r->stream, amp_in, amp_out, n, P, d_ops, ntiles)) { \
+        } else if (P.chained) { set_error("chained pass without a rounds kernel"); return QCX_UNKNOWN_ERROR; \
+        } else if (tn.fuse_ldsdma) hipLaunchKernelGGL((k_fused<B, TTv, true>), dim3(grid), dim3(B), lds, r->stream, amp_in, n, P, d_ops, ntiles, d_ops); \
+        else hipLaunchKernelGGL((k_fused<B, TTv, false>), dim3(grid), dim3(B), lds, r->stream, amp_in, n, P, d_ops, ntiles, d_ops); } while (0)
     if (P.dg_slim == 2) {                 // tolerance mode, radix-8 fast rounds only
         if (P.T != 12) { set_error("radix-8 pass on a tile of 2^%u amplitudes", P.T); return QCX_UNKNOWN_ERROR; }
         // (a few workgroups per CU that walk the tiles: 2048 workgroups 6.3 ms, 24576 7.0 ms, one per tile 8.3 ms at n = 28)
         // (the Hadamard-only exact form likes more of them: n = 30 sweep 23.5 ms with 8192, 23.9 with 3072)
         const unsigned grid3 = grid_for(ntiles, 1, P.dg_cnt ? tn.fuse_q3_cap : tn.fuse_q3_cap_exact);
-        if (P.dg_cnt) hipLaunchKernelGGL((k_fused_q3<512, 12, 4, false>), dim3(grid3), dim3(512), lds, r->stream, r->amp, n, P, d_ops, ntiles);
-        else hipLaunchKernelGGL((k_fused_q3<512, 12, 4, true>), dim3(grid3), dim3(512), lds, r->stream, r->amp, n, P, d_ops, ntiles);
+        if (P.dg_cnt) hipLaunchKernelGGL((k_fused_q3<512, 12, 4, false>), dim3(grid3), dim3(512), lds, r->stream, amp_in, amp_out, n, P, d_ops, ntiles);
+        else hipLaunchKernelGGL((k_fused_q3<512, 12, 4, true>), dim3(grid3), dim3(512), lds, r->stream, amp_in, amp_out, n, P, d_ops, ntiles);
         HIP_TRY(hipGetLastError());
         return QCX_NO_ERROR;
     }
@@ -509,15 +514,71 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
     case 9:  QCX_FUSE_LAUNCH(256, 9); break;
     // registers of the reference's own sizes (n = 5 ... 8: the whole state is one tile): one wave, everything known at compile time
     // (the generic kernel below took 60 us for the 13 gates of the C = 15, L = 3, M = 4 circuit; these take ~10)
-    case 8:  hipLaunchKernelGGL((k_fused<64, 8, false>), dim3(grid), dim3(64), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); break;
-    case 7:  hipLaunchKernelGGL((k_fused<64, 7, false>), dim3(grid), dim3(64), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); break;
-    case 6:  hipLaunchKernelGGL((k_fused<64, 6, false>), dim3(grid), dim3(64), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); break;
-    case 5:  hipLaunchKernelGGL((k_fused<64, 5, false>), dim3(grid), dim3(64), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); break;
-    default: hipLaunchKernelGGL((k_fused<256, 0, false>), dim3(grid), dim3(256), lds, r->stream, r->amp, n, P, d_ops, ntiles, d_ops); break;
+    case 8:  hipLaunchKernelGGL((k_fused<64, 8, false>), dim3(grid), dim3(64), lds, r->stream, amp_in, n, P, d_ops, ntiles, d_ops); break;
+    case 7:  hipLaunchKernelGGL((k_fused<64, 7, false>), dim3(grid), dim3(64), lds, r->stream, amp_in, n, P, d_ops, ntiles, d_ops); break;
+    case 6:  hipLaunchKernelGGL((k_fused<64, 6, false>), dim3(grid), dim3(64), lds, r->stream, amp_in, n, P, d_ops, ntiles, d_ops); break;
+    case 5:  hipLaunchKernelGGL((k_fused<64, 5, false>), dim3(grid), dim3(64), lds, r->stream, amp_in, n, P, d_ops, ntiles, d_ops); break;
+    default: hipLaunchKernelGGL((k_fused<256, 0, false>), dim3(grid), dim3(256), lds, r->stream, amp_in, n, P, d_ops, ntiles, d_ops); break;
     }
 #undef QCX_FUSE_LAUNCH
     HIP_TRY(hipGetLastError());
     return QCX_NO_ERROR;
+}
+
+// ---- general tile addressing of a pass (FusePass::in_pos ... seg_lg; round 4) -----------------------------------------------
+// run-length segments that deposit the bits of a tile number: bit k of the number goes to index bit pos[k]
+static bool make_segments(const std::vector<unsigned> &pos, FuseSeg *seg, uint8_t *nseg)
+{
+    unsigned cnt = 0;
+    for (size_t k = 0; k < pos.size();) {
+        size_t e = k + 1;
+        while (e < pos.size() && pos[e] == pos[e - 1] + 1) e++;
+        if (cnt == QCX_MAX_SEG) return false;
+        seg[cnt].src = (uint8_t)k; seg[cnt].dst = (uint8_t)pos[k]; seg[cnt].len = (uint8_t)(e - k); seg[cnt].pad = 0;
+        cnt++;
+        k = e;
+    }
+    *nseg = (uint8_t)cnt;
+    return true;
+}
+
+// the tables of a pass that works IN PLACE on the identity layout: tile-local bit j = index bit tl[j] (ascending)
+static bool pass_tables_inplace(FusePass &P, unsigned n, const std::vector<unsigned> &tl)
+{
+    P.chained = 0;
+    std::vector<bool> in_tile(n, false);
+    for (size_t j = 0; j < tl.size(); j++) { P.in_pos[j] = (uint8_t)tl[j]; P.st_loc[j] = (uint8_t)j; P.st_pos[j] = (uint8_t)tl[j]; in_tile[tl[j]] = true; }
+    std::vector<unsigned> fr;
+    for (unsigned b = 0; b < n; b++) if (!in_tile[b]) fr.push_back(b);
+    if (!make_segments(fr, P.seg_in, &P.nseg_in)) return false;
+    P.nseg_out = P.nseg_lg = 0;
+    return true;
+}
+
+// the tables of a CHAINED pass: reads the layout lin (lin[q] = physical index bit of qubit q in the input buffer), writes the
+// layout lout into the other buffer.  tl = the tile's qubits in local order: ascending input position.
+static bool pass_tables_chained(FusePass &P, unsigned n, const std::vector<unsigned> &tl, const std::vector<unsigned> &lin, const std::vector<unsigned> &lout, bool by_out)
+{
+    P.chained = 1;
+    const size_t T = tl.size();
+    std::vector<bool> in_tile(n, false);
+    for (size_t j = 0; j < T; j++) { P.in_pos[j] = (uint8_t)lin[tl[j]]; in_tile[tl[j]] = true; if (j && lin[tl[j]] <= lin[tl[j - 1]]) return false; }
+    // store order: the tile's bits by ascending OUTPUT position
+    std::vector<unsigned> ord(T);
+    for (size_t j = 0; j < T; j++) ord[j] = (unsigned)j;
+    std::sort(ord.begin(), ord.end(), [&](unsigned x, unsigned y) { return lout[tl[x]] < lout[tl[y]]; });
+    for (size_t j = 0; j < T; j++) { P.st_loc[j] = (uint8_t)ord[j]; P.st_pos[j] = (uint8_t)lout[tl[ord[j]]]; }
+    // the tile number's bits = the qubits outside the tile.  by_out: by ascending OUTPUT position -- tiles that run at the same
+    // time (consecutive numbers) then store NEIGHBOURING runs: 2^(T - c) consecutive tiles fill the same 2^(T - c) blocks of
+    // the output completely (a tile is read as one contiguous block wherever it lies).  Otherwise by ascending INPUT position
+    // (neighbouring tiles read neighbouring blocks).  Measured at n = 28 / 30 (tools/probe_chain.py): memory-bound passes
+    // (Hadamard sweeps, tolerance mode) gain 1-4 % from the output order, the FP64-bound exact phase passes lose 5 % with it.
+    std::vector<unsigned> fq;
+    for (unsigned q = 0; q < n; q++) if (!in_tile[q]) fq.push_back(q);
+    std::sort(fq.begin(), fq.end(), [&](unsigned x, unsigned y) { return by_out ? lout[x] < lout[y] : lin[x] < lin[y]; });
+    std::vector<unsigned> pin, pout, plg;
+    for (unsigned q : fq) { pin.push_back(lin[q]); pout.push_back(lout[q]); plg.push_back(q); }
+    return make_segments(pin, P.seg_in, &P.nseg_in) && make_segments(pout, P.seg_out, &P.nseg_out) && make_segments(plg, P.seg_lg, &P.nseg_lg);
 }
 
 // The planner: cut a gate list into actions (fused passes and stand-alone gates) and emit every pass's records.
@@ -525,8 +586,21 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
 // the oracle with an emulator of the pass kernels (tests/fuse_emulator.py).
 // tol: tolerance mode (qcx_set_fusion(reg, 2)).  Actions always refer to the ORIGINAL gate list (first_gate / ngates /
 // gate), whatever was merged.
+// chain: runs of consecutive rounds-form passes may be CHAINED through the register's second buffer (see FusePass): every
+// pass but the first then reads whole contiguous tiles, only its stores are gathered, and the last one stores the identity
+// layout again -- the same records, the same arithmetic, other addresses.
+struct PassShape {
+    size_t first, last;                 // gates [first, last) of the (merged) list
+    unsigned c;
+    std::vector<unsigned> hbits;        // the tile's qubits above the low c, ascending
+    std::vector<unsigned> tl;           // the tile's qubits in local order
+    bool want_q3;
+    size_t n_h, n_ph, n_other;
+    int nopipe;
+};
+
 static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<QGate> &gates_in, std::vector<FuseAction> &acts, std::vector<FuseOp> &all_ops,
-                      bool tol = false)
+                      bool tol = false, bool chain = false)
 {
     std::vector<QGate> merged;
     std::vector<DiagSpec> specs;
@@ -534,8 +608,10 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
     if (tol) merge_diagonals(gates_in, merged, specs, ofirst, ocnt);
     const std::vector<QGate> &gates = tol ? merged : gates_in;
     if (!tol) { ofirst.resize(gates.size()); ocnt.assign(gates.size(), 1); for (size_t k = 0; k < gates.size(); k++) ofirst[k] = k; }
+    std::vector<int> shape_of;                         // per action: index into shapes, or -1 (stand-alone gate)
+    std::vector<PassShape> shapes;
     auto standalone = [&](size_t k) {                  // gate k (merged numbering) as stand-alone kernel launches
-        for (size_t j = 0; j < ocnt[k]; j++) { FuseAction a; memset(&a, 0, sizeof a); a.gate = ofirst[k] + j; acts.push_back(a); }
+        for (size_t j = 0; j < ocnt[k]; j++) { FuseAction a; memset(&a, 0, sizeof a); a.gate = ofirst[k] + j; acts.push_back(a); shape_of.push_back(-1); }
     };
     const unsigned n = r->n;
     unsigned T = (unsigned)tn.fuse_T, c_def = (unsigned)tn.fuse_c;
@@ -544,7 +620,112 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
     if (T > n) T = n;
     if (c_def > T) c_def = T;
 
-    std::vector<FuseOp> legacy;
+    // records and FusePass fields of one pass; 0 = done, 1 = the radix-8 plan did not work out (plan the pass again, radix 4)
+    auto emit = [&](const PassShape &sh, FuseAction &act) -> int {
+        const size_t first = sh.first, i = sh.last;
+        const std::vector<unsigned> &tl = sh.tl;
+        act.fused = 1;
+        act.nopipe = sh.nopipe;
+        for (size_t j = 0; j < tl.size() && j < 16; j++) act.tl[j] = (uint8_t)tl[j];
+        act.first_gate = ofirst[first]; act.ngates = ofirst[i - 1] + ocnt[i - 1] - ofirst[first];
+        act.P.has_cam = sh.n_other ? 1u : 0u;
+        act.P.c = sh.c; act.P.nh = (uint32_t)sh.hbits.size(); act.P.T = sh.c + act.P.nh;
+        act.P.cam_ctl_local[3] = (int32_t)cam_lut_bytes((unsigned)r->M);           // table area sits behind the lut
+        for (unsigned j = 0; j < act.P.nh; j++) act.P.hbit[j] = (uint8_t)sh.hbits[j];
+        std::vector<FuseOp> legacy;
+        bool rounds = tn.fuse_rounds && act.P.T >= 10 && act.P.T <= 12;
+        if (sh.want_q3 && !(rounds && act.P.T == 12 && sh.n_other == 0)) return 1;
+        // (tolerance mode: merged diagonals exist in the rounds form only, at most 16 per pass -- their tables live in LDS;
+        // otherwise the pass gets the plain phases they were merged from)
+        std::vector<unsigned> pass_diags;
+        size_t n_diag = 0;
+        for (size_t k = first; k < i; k++) n_diag += gates[k].type == FUSE_DIAG;
+        bool keep_diags = tol && rounds && n_diag > 0 && n_diag <= 255;
+        build_pass_ops(r, gates, first, i, tl, legacy, &specs, &gates_in, !keep_diags, &pass_diags);
+        act.op_off = all_ops.size();
+        if (rounds) {
+            // ROUNDS form: phases run as "phase runs", which need the records' outside-tile masks in LDS next to the
+            // tiles (8 B per record); when that would cost a resident workgroup the pass uses the plain gate list
+            std::vector<unsigned char> blob;
+            std::vector<unsigned> kept;                  // old slot numbers of the diagonals that stayed merged, in new-slot order
+            unsigned generic_rounds = 0;
+            to_rounds(tn, legacy, act.P.T, all_ops, blob, keep_diags ? &kept : nullptr, &generic_rounds, sh.want_q3 ? 3u : 2u);
+            if (sh.want_q3 && (generic_rounds || (n_diag > 0 && (!keep_diags || kept.empty())) || (n_diag == 0 && sh.n_ph + sh.n_other > 0))) {       // not all radix-8 fast rounds: plan this pass again, radix 4
+                all_ops.resize(act.op_off); return 1;
+            }
+            act.P.dg_slim = sh.want_q3 ? 2u : (keep_diags && !kept.empty() && generic_rounds == 0) ? 1u : 0u;     // every round is a fast round (2: radix 8)
+            act.P.tol_scale = 1.0;
+            if (sh.want_q3) for (size_t k = 0; k < sh.n_h; k++) act.P.tol_scale *= QCX_SQRT1_2;
+            if (keep_diags) {
+                std::vector<unsigned> kd;
+                for (unsigned os : kept) kd.push_back(pass_diags[os]);
+                pass_diags.swap(kd);
+                keep_diags = !pass_diags.empty();
+            }
+            const size_t nrec = all_ops.size() - act.op_off;
+            size_t lds = 2 * ((size_t)16 << act.P.T) + (size_t)act.P.cam_ctl_local[3] + blob.size() + 64 + 8 * (nrec + 66);
+            size_t limit = (size_t)160 * 1024 / (act.P.T == 12 ? 1 : act.P.T == 11 ? 2 : 4);
+            if (keep_diags) {            // tolerance mode: what the workgroup really needs; two of them must fit a CU
+                lds = ((size_t)16 << act.P.T) + (sh.n_other ? (size_t)act.P.cam_ctl_local[3] : 16) + blob.size() + 64 + 8 * (nrec + 66) + 16 * 49 * pass_diags.size();
+                limit = (size_t)80 * 1024;
+            }
+            if (lds > limit) {
+                all_ops.resize(act.op_off); rounds = false;
+                if (sh.want_q3) return 1;                                       // radix-8 records mean nothing to the plain gate list: plan again
+                act.P.dg_slim = 0; act.P.tol_scale = 1.0;                       // (launch_pass looks at dg_slim first)
+                if (keep_diags) {        // the plain gate list has no diagonal interpreter: back to the phases
+                    legacy.clear(); pass_diags.clear(); keep_diags = false;
+                    build_pass_ops(r, gates, first, i, tl, legacy, &specs, &gates_in, true, &pass_diags);
+                }
+            }
+            else {
+                act.P.xm_cnt = (uint32_t)nrec;
+                act.P.cam_ctl_local[0] = 1;
+                if (!blob.empty()) {             // the tables ride behind the pass's records, padded to whole records
+                    blob.resize((blob.size() + sizeof(FuseOp) - 1) / sizeof(FuseOp) * sizeof(FuseOp), 0);
+                    act.P.cam_ctl_local[1] = (int32_t)blob.size();
+                    act.P.cam_ctl_local[2] = (int32_t)(all_ops.size() - act.op_off);
+                    const size_t at = all_ops.size();
+                    all_ops.resize(at + blob.size() / sizeof(FuseOp));
+                    memcpy(&all_ops[at], blob.data(), blob.size());
+                }
+                if (keep_diags) {                // the diagonals' table area rides behind everything else of the pass
+                    std::vector<double> area;
+                    diag_tables(n, tl, specs, pass_diags, area);
+                    act.P.dg_cnt = (uint32_t)pass_diags.size();
+                    act.P.dg_rec_off = (uint32_t)(all_ops.size() - act.op_off);
+                    const size_t at = all_ops.size();
+                    all_ops.resize(at + area.size() * sizeof(double) / sizeof(FuseOp));
+                    memcpy(&all_ops[at], area.data(), area.size() * sizeof(double));
+                }
+                act.P.nops = (uint32_t)nrec;
+            }
+        }
+        if (!rounds) { all_ops.insert(all_ops.end(), legacy.begin(), legacy.end()); act.P.nops = (uint32_t)legacy.size(); }
+        act.op_cnt = all_ops.size() - act.op_off;
+        static const bool dump = getenv("QCX_FUSE_DUMP") != nullptr;      // planner diagnostics (tools/probe_fuse3.py)
+        if (dump) {
+            unsigned nround = 0, nh = 0, nrun = 0, nsingle = 0, ncam = 0, run_gates[16] = {0}, ext = 0, loc = 0;
+            for (size_t q = act.op_off; q < act.op_off + act.P.nops; q++) {
+                const FuseOp &o = all_ops[q];
+                switch (o.type & 0xffu) {
+                case FUSE_ROUND: nround++; break;
+                case FUSE_H: nh++; break;
+                case FUSE_PRUN: nrun++; run_gates[o.a & 15u] += (unsigned)o.mask; break;
+                case FUSE_PHASE: nsingle++; if (o.mask) ext++; if (o.a) loc++; break;
+                default: ncam++; break;
+                }
+            }
+            fprintf(stderr, "[qcx fuse] pass T=%u c=%u tile=", act.P.T, act.P.c);
+            for (unsigned q : tl) fprintf(stderr, "%u,", q);
+            fprintf(stderr, " gates=%zu records=%u rounds=%u H=%u runs=%u phases=%u (ext-ctl %u, lane-ctl %u) other=%u run gates by rsel:",
+                    act.ngates, act.P.nops, nround, nh, nrun, nsingle, ext, loc, ncam);
+            for (unsigned q = 1; q < 16; q++) if (run_gates[q]) fprintf(stderr, " %x:%u", q, run_gates[q]);
+            fprintf(stderr, "\n");
+        }
+        return 0;
+    };
+
     std::vector<unsigned> need;
     size_t i = 0;
     bool q3_refused = false;               // the radix-8 plan of the pass starting at i did not work out: plan it the usual way
@@ -615,8 +796,21 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
             const unsigned hb = (unsigned)__builtin_popcountll(hot), Ts = (unsigned)tn.fuse_tol_T;
             // (a tile needs at least one hot bit: with fuse_c == the tile bits the estimate would divide by zero)
             auto passes_at = [&](unsigned TT) { return TT > ccur ? (hb + (TT - ccur) - 1) / (TT - ccur) : 0xffffffffu; };
-            // radix-8 rounds on 2^12 tiles (k_fused_q3) when they save a pass against both radix-4 geometries
-            if (pure && hb && q3_allowed && tn.fuse_q3 && n >= 12 && ccur <= 4 && passes_at(12) < std::min(passes_at(Ts), passes_at(Tcur))) { Tcur = 12; want_q3 = true; }
+            // radix-8 rounds on 2^12 tiles (k_fused_q3) when they save a pass against both radix-4 geometries -- with 2^3-amplitude
+            // runs (9 hot bits per pass) when that saves yet another one: the 25 Hadamards of the n = 30 Shor circuit's inverse
+            // QFT take 3 passes instead of 4 (runs of 128 B cost a pass ~10 %, a pass less saves 25 %)
+            unsigned hb3 = 0;
+            for (unsigned q = 3; q < ccur && pure; q++) {           // Hadamard targets in [3, c) would become hot bits with c = 3
+                bool tgt = false;
+                for (size_t k = first; k < gates.size() && !tgt; k++) tgt = gates[k].type == FUSE_H && gates[k].q == q;
+                hb3 += tgt;
+            }
+            const unsigned p12 = passes_at(12), p12c3 = ccur > 3 ? (hb + hb3 + 8) / 9 : p12;
+            const unsigned others = std::min(passes_at(Ts), passes_at(Tcur));
+            if (pure && hb && q3_allowed && tn.fuse_q3 && n >= 12 && ccur <= 4 && std::min(p12, p12c3) < others) {
+                if (p12c3 < p12 && tn.fuse_q3_c3) ccur = 3;
+                Tcur = 12; want_q3 = true;
+            }
             else if (pure && hb && passes_at(Ts) == passes_at(Tcur)) Tcur = Ts;
         }
         unsigned c = ccur, budget = Tcur - ccur;
@@ -638,103 +832,98 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
             if (std::find(hbits.begin(), hbits.end(), b) == hbits.end()) hbits.push_back(b);
         std::sort(hbits.begin(), hbits.end());
 
-        act.fused = 1;
-        act.first_gate = ofirst[first]; act.ngates = ofirst[i - 1] + ocnt[i - 1] - ofirst[first];
-        act.P.has_cam = n_other ? 1u : 0u;
-        act.P.c = c; act.P.nh = (uint32_t)hbits.size(); act.P.T = c + act.P.nh;
-        act.P.cam_ctl_local[3] = (int32_t)cam_lut_bytes((unsigned)r->M);           // table area sits behind the lut
-        for (unsigned j = 0; j < act.P.nh; j++) act.P.hbit[j] = (uint8_t)hbits[j];
-        legacy.clear();
-        bool rounds = tn.fuse_rounds && act.P.T >= 10 && act.P.T <= 12;
-        if (want_q3 && !(rounds && act.P.T == 12 && n_other == 0)) { q3_refused = true; i = first; continue; }
-        // (tolerance mode: merged diagonals exist in the rounds form only, at most 16 per pass -- their tables live in LDS;
-        // otherwise the pass gets the plain phases they were merged from)
-        std::vector<unsigned> pass_diags;
-        size_t n_diag = 0;
-        for (size_t k = first; k < i; k++) n_diag += gates[k].type == FUSE_DIAG;
-        bool keep_diags = tol && rounds && n_diag > 0 && n_diag <= 255;
-        build_pass_ops(r, gates, first, i, c, hbits, legacy, &specs, &gates_in, !keep_diags, &pass_diags);
-        act.op_off = all_ops.size();
-        if (rounds) {
-            // ROUNDS form: phases run as "phase runs", which need the records' outside-tile masks in LDS next to the
-            // tiles (8 B per record); when that would cost a resident workgroup the pass uses the plain gate list
-            std::vector<unsigned char> blob;
-            std::vector<unsigned> kept;                  // old slot numbers of the diagonals that stayed merged, in new-slot order
-            unsigned generic_rounds = 0;
-            to_rounds(tn, legacy, act.P.T, all_ops, blob, keep_diags ? &kept : nullptr, &generic_rounds, want_q3 ? 3u : 2u);
-            if (want_q3 && (generic_rounds || (n_diag > 0 && (!keep_diags || kept.empty())) || (n_diag == 0 && n_ph + n_other > 0))) {       // not all radix-8 fast rounds: plan this pass again, radix 4
-                all_ops.resize(act.op_off); q3_refused = true; i = first; continue;
+        PassShape sh;
+        sh.first = first; sh.last = i; sh.c = c; sh.hbits = hbits; sh.want_q3 = want_q3;
+        sh.n_h = n_h; sh.n_ph = n_ph; sh.n_other = n_other; sh.nopipe = act.nopipe;
+        for (unsigned b = 0; b < c; b++) sh.tl.push_back(b);
+        for (unsigned b : hbits) sh.tl.push_back(b);
+        if (emit(sh, act)) { q3_refused = true; i = first; continue; }
+        if (!pass_tables_inplace(act.P, n, sh.tl)) {                // (cannot happen: at most T - c + 1 segments)
+            all_ops.resize(act.op_off);
+            for (size_t k = first; k < i; k++) standalone(k);
+            continue;
+        }
+        acts.push_back(act);
+        shape_of.push_back((int)shapes.size());
+        shapes.push_back(sh);
+    }
+
+    // ---- chains ---------------------------------------------------------------------------------------------------------
+    if (!chain || !tn.fuse_chain || n < (unsigned)std::max<long>(tn.fuse_chain_min_n, 13)) return;
+    auto chainable = [&](size_t a) {
+        if (!acts[a].fused) return false;
+        const FusePass &P = acts[a].P;
+        if (!tn.fuse_ldsdma || tn.fuse_rounds_occ < 6) return false;               // (launch_pass would take the general kernel, which works in place only)
+        return P.cam_ctl_local[0] == 1 && !P.has_cam && P.T >= 10 && P.T <= 12 && P.T < n;
+    };
+    bool any = false;
+    for (size_t a0 = 0; a0 < acts.size();) {
+        if (!chainable(a0)) { a0++; continue; }
+        size_t a1 = a0;
+        while (a1 < acts.size() && chainable(a1)) a1++;
+        const size_t m = a1 - a0;
+        if (m >= 2) {
+            // layouts: lay[0] = identity (what the first pass reads); pass k of the chain writes lay[k + 1]; the last one the identity
+            std::vector<std::vector<unsigned>> lay(m + 1, std::vector<unsigned>(n));
+            for (unsigned q = 0; q < n; q++) lay[0][q] = lay[m][q] = q;
+            for (size_t k = 0; k + 1 < m; k++) {
+                const PassShape &cur = shapes[shape_of[a0 + k]], &nxt = shapes[shape_of[a0 + k + 1]];
+                std::vector<bool> in_cur(n, false), in_nxt(n, false), placed(n, false);
+                for (unsigned q : cur.tl) in_cur[q] = true;
+                for (unsigned q : nxt.tl) in_nxt[q] = true;
+                std::vector<unsigned> order;                       // qubits by ascending position in the layout this pass writes
+                // the next tile first (it will be read as one contiguous block): the qubits both tiles hold lowest -- they are
+                // what this pass's stores are contiguous in --, then the rest of the next tile
+                for (unsigned q = 0; q < n; q++) if (in_cur[q] && in_nxt[q]) { order.push_back(q); placed[q] = true; }
+                for (unsigned q = 0; q < n; q++) if (in_nxt[q] && !placed[q]) { order.push_back(q); placed[q] = true; }
+                // then the rest of this pass's tile (short strides for its stores), then everything else
+                for (unsigned q = 0; q < n; q++) if (in_cur[q] && !placed[q]) { order.push_back(q); placed[q] = true; }
+                for (unsigned q = 0; q < n; q++) if (!placed[q]) order.push_back(q);
+                for (unsigned pos = 0; pos < n; pos++) lay[k + 1][order[pos]] = pos;
             }
-            act.P.dg_slim = want_q3 ? 2u : (keep_diags && !kept.empty() && generic_rounds == 0) ? 1u : 0u;     // every round is a fast round (2: radix 8)
-            act.P.tol_scale = 1.0;
-            if (want_q3) for (size_t k = 0; k < n_h; k++) act.P.tol_scale *= QCX_SQRT1_2;
-            if (keep_diags) {
-                std::vector<unsigned> kd;
-                for (unsigned os : kept) kd.push_back(pass_diags[os]);
-                pass_diags.swap(kd);
-                keep_diags = !pass_diags.empty();
+            // the passes again, each with its tile ordered by where its input layout puts the qubits
+            std::vector<PassShape> ns;
+            bool ok = true;
+            for (size_t k = 0; k < m && ok; k++) {
+                PassShape sh = shapes[shape_of[a0 + k]];
+                std::sort(sh.tl.begin(), sh.tl.end(), [&](unsigned x, unsigned y) { return lay[k][x] < lay[k][y]; });
+                FusePass Pt; memset(&Pt, 0, sizeof Pt);
+                ok = pass_tables_chained(Pt, n, sh.tl, lay[k], lay[k + 1], false);
+                ns.push_back(sh);
             }
-            const size_t nrec = all_ops.size() - act.op_off;
-            size_t lds = 2 * ((size_t)16 << act.P.T) + (size_t)act.P.cam_ctl_local[3] + blob.size() + 64 + 8 * (nrec + 66);
-            size_t limit = (size_t)160 * 1024 / (act.P.T == 12 ? 1 : act.P.T == 11 ? 2 : 4);
-            if (keep_diags) {            // tolerance mode: what the workgroup really needs; two of them must fit a CU
-                lds = ((size_t)16 << act.P.T) + (n_other ? (size_t)act.P.cam_ctl_local[3] : 16) + blob.size() + 64 + 8 * (nrec + 66) + 16 * 49 * pass_diags.size();
-                limit = (size_t)80 * 1024;
-            }
-            if (lds > limit) {
-                all_ops.resize(act.op_off); rounds = false;
-                if (want_q3) { q3_refused = true; i = first; continue; }       // radix-8 records mean nothing to the plain gate list: plan again
-                act.P.dg_slim = 0; act.P.tol_scale = 1.0;                       // (launch_pass looks at dg_slim first)
-                if (keep_diags) {        // the plain gate list has no diagonal interpreter: back to the phases
-                    legacy.clear(); pass_diags.clear(); keep_diags = false;
-                    build_pass_ops(r, gates, first, i, c, hbits, legacy, &specs, &gates_in, true, &pass_diags);
+            if (ok) {
+                for (size_t k = 0; k < m; k++) {
+                    shapes[shape_of[a0 + k]] = ns[k];
+                    (void)pass_tables_chained(acts[a0 + k].P, n, ns[k].tl, lay[k], lay[k + 1], acts[a0 + k].P.dg_slim != 0);
                 }
-            }
-            else {
-                act.P.xm_cnt = (uint32_t)nrec;
-                act.P.cam_ctl_local[0] = 1;
-                if (!blob.empty()) {             // the tables ride behind the pass's records, padded to whole records
-                    blob.resize((blob.size() + sizeof(FuseOp) - 1) / sizeof(FuseOp) * sizeof(FuseOp), 0);
-                    act.P.cam_ctl_local[1] = (int32_t)blob.size();
-                    act.P.cam_ctl_local[2] = (int32_t)(all_ops.size() - act.op_off);
-                    const size_t at = all_ops.size();
-                    all_ops.resize(at + blob.size() / sizeof(FuseOp));
-                    memcpy(&all_ops[at], blob.data(), blob.size());
-                }
-                if (keep_diags) {                // the diagonals' table area rides behind everything else of the pass
-                    std::vector<double> area;
-                    diag_tables(n, c, hbits, specs, pass_diags, area);
-                    act.P.dg_cnt = (uint32_t)pass_diags.size();
-                    act.P.dg_rec_off = (uint32_t)(all_ops.size() - act.op_off);
-                    const size_t at = all_ops.size();
-                    all_ops.resize(at + area.size() * sizeof(double) / sizeof(FuseOp));
-                    memcpy(&all_ops[at], area.data(), area.size() * sizeof(double));
-                }
-                act.P.nops = (uint32_t)nrec;
+                any = true;
             }
         }
-        if (!rounds) { all_ops.insert(all_ops.end(), legacy.begin(), legacy.end()); act.P.nops = (uint32_t)legacy.size(); }
-        act.op_cnt = all_ops.size() - act.op_off;
-        static const bool dump = getenv("QCX_FUSE_DUMP") != nullptr;      // planner diagnostics (tools/probe_fuse3.py)
-        if (dump) {
-            unsigned nround = 0, nh = 0, nrun = 0, nsingle = 0, ncam = 0, run_gates[16] = {0}, ext = 0, loc = 0;
-            for (size_t q = act.op_off; q < act.op_off + act.P.nops; q++) {
-                const FuseOp &o = all_ops[q];
-                switch (o.type & 0xffu) {
-                case FUSE_ROUND: nround++; break;
-                case FUSE_H: nh++; break;
-                case FUSE_PRUN: nrun++; run_gates[o.a & 15u] += (unsigned)o.mask; break;
-                case FUSE_PHASE: nsingle++; if (o.mask) ext++; if (o.a) loc++; break;
-                default: ncam++; break;
-                }
-            }
-            fprintf(stderr, "[qcx fuse] pass T=%u c=%u hot=", act.P.T, act.P.c);
-            for (unsigned j = 0; j < act.P.nh; j++) fprintf(stderr, "%u,", act.P.hbit[j]);
-            fprintf(stderr, " gates=%zu records=%u rounds=%u H=%u runs=%u phases=%u (ext-ctl %u, lane-ctl %u) other=%u run gates by rsel:",
-                    act.ngates, act.P.nops, nround, nh, nrun, nsingle, ext, loc, ncam);
-            for (unsigned q = 1; q < 16; q++) if (run_gates[q]) fprintf(stderr, " %x:%u", q, run_gates[q]);
-            fprintf(stderr, "\n");
+        a0 = a1;
+    }
+    if (!any) return;
+    // re-emit every pass's records: a chained pass numbers its tile-local bits differently
+    std::vector<FuseAction> old;
+    old.swap(acts);
+    all_ops.clear();
+    for (size_t a = 0; a < old.size(); a++) {
+        if (!old[a].fused) { acts.push_back(old[a]); continue; }
+        FuseAction act;
+        memset(&act, 0, sizeof act);
+        if (emit(shapes[shape_of[a]], act)) {                      // (cannot happen: the same gates were emitted once already)
+            acts.clear(); all_ops.clear();
+            fuse_plan(r, tn, gates_in, acts, all_ops, tol, false);
+            return;
         }
+        const FusePass &O = old[a].P;                             // the addressing tables were computed above
+        act.P.chained = O.chained;
+        act.P.nseg_in = O.nseg_in; act.P.nseg_out = O.nseg_out; act.P.nseg_lg = O.nseg_lg;
+        memcpy(act.P.in_pos, O.in_pos, sizeof act.P.in_pos);
+        memcpy(act.P.st_loc, O.st_loc, sizeof act.P.st_loc);
+        memcpy(act.P.st_pos, O.st_pos, sizeof act.P.st_pos);
+        memcpy(act.P.seg_in, O.seg_in, sizeof act.P.seg_in);
+        memcpy(act.P.seg_out, O.seg_out, sizeof act.P.seg_out);
+        memcpy(act.P.seg_lg, O.seg_lg, sizeof act.P.seg_lg);
         acts.push_back(act);
     }
 }
@@ -822,8 +1011,20 @@ static int fuse_flush(qcx_register *r)
     std::vector<FuseAction> acts;
     std::vector<FuseOp> all_ops;
     const Tune tn = tune_now();
-    fuse_plan(r, tn, gates, acts, all_ops, r->fusion == 2);
-
+    // chains of passes go through the register's second buffer (allocated on first use; a register whose buffer pointer has
+    // been handed out, a shard view and a register too large for a second buffer work in place)
+    bool chain = tn.fuse_chain && r->own_stream && !r->no_chain && r->n >= (unsigned)std::max<long>(tn.fuse_chain_min_n, 13);
+    fuse_plan(r, tn, gates, acts, all_ops, r->fusion == 2, chain);
+    bool chained_any = false;
+    for (const FuseAction &a : acts) chained_any |= a.fused && a.P.chained;
+    if (chained_any && !r->scratch) {
+        if (hipMalloc(&r->scratch, r->dim * sizeof(amp_t)) != hipSuccess) {
+            (void)hipGetLastError();
+            r->scratch = nullptr; r->no_chain = 1;                 // no room (n = 34 fills the card): in place from now on
+            acts.clear(); all_ops.clear();
+            fuse_plan(r, tn, gates, acts, all_ops, r->fusion == 2, false);
+        }
+    }
     if (!all_ops.empty()) {
         if (gq->ev_valid) HIP_TRY(hipEventSynchronize(gq->ev));       // the previous flush may still read the buffers
         const size_t need_ops = all_ops.size() + 1;                  // + 1: the walk prefetches one header past the last item
@@ -845,7 +1046,14 @@ static int fuse_flush(qcx_register *r)
     }
     for (const FuseAction &act : acts) {
         if (!act.fused) { QCX_TRY(launch_standalone(r, gates[act.gate])); continue; }
-        QCX_TRY(launch_pass(r, tn, act.P, gq->d_ops + act.op_off, act.nopipe != 0));
+        if (act.P.chained) {
+            // out of place into the other buffer, which then IS the register's state (a chain ends on the identity layout, and
+            // nothing between its passes looks at the buffers)
+            QCX_TRY(launch_pass(r, tn, act.P, gq->d_ops + act.op_off, act.nopipe != 0, r->amp, r->scratch));
+            std::swap(r->amp, r->scratch);
+            gq->chained_passes++;
+        } else
+            QCX_TRY(launch_pass(r, tn, act.P, gq->d_ops + act.op_off, act.nopipe != 0, r->amp, r->amp));
         gq->passes_launched++;
         gq->gates_fused += act.ngates;
     }

@@ -1099,6 +1099,8 @@ struct FuseOp {                 // 32 bytes
 struct FuseCamExtra {           // overlays c, s of a CAMODC op (16 bytes)
     uint32_t C, d, Cd, inv;
 };
+struct FuseSeg { uint8_t src, dst, len, pad; };
+#define QCX_MAX_SEG 16
 struct FusePass {
     uint32_t nops, T, c, nh;
     int32_t  cam_ctl_local[4];  // [0]: 1 = ROUNDS form; [1]: bytes of folded-multiply tables, [2]: their record offset in ops,
@@ -1110,7 +1112,34 @@ struct FusePass {
     uint32_t dg_cnt, dg_rec_off;// tolerance mode: merged diagonals of the pass (0 = none), record offset of their table area in ops
     uint32_t dg_lds_off, dg_slim;// byte offset of their LDS area behind the lut; 1: every round of the pass is a fast round; 2: radix-8 fast rounds
     double   tol_scale;         // radix-8 passes: M_SQRT1_2 ^ (Hadamards of the pass), applied once when a tile is stored
+    // General tile addressing (round 4).  A pass reads the tile whose local bit j is PHYSICAL index bit in_pos[j] of the input
+    // buffer (ascending in j: in_pos[j] = j for the first c) and stores it where the pass's output layout puts those bits --
+    // in place on the identity layout (the default: out = in), or OUT OF PLACE into the second buffer under another
+    // logical -> physical map (a CHAINED pass: the host chooses the map so that the next pass reads whole contiguous tiles and
+    // only this pass's stores are gathered; the last pass of a chain stores the identity layout again).  The tile NUMBER's
+    // bits are spread over the free positions of the three index spaces by run-length segments: input, output, and LOGICAL
+    // (the gate records test control qubits outside the tile against the logical base index).
+    uint8_t  chained, nseg_in, nseg_out, nseg_lg;
+    uint8_t  in_pos[16];        // physical (input) index bit of tile-local bit j
+    uint8_t  st_loc[16];        // store order: the j-th lowest OUTPUT position of the tile's bits belongs to tile-local bit st_loc[j] ...
+    uint8_t  st_pos[16];        // ... and is output index bit st_pos[j] (ascending in j)
+    FuseSeg  seg_in[QCX_MAX_SEG], seg_out[QCX_MAX_SEG], seg_lg[QCX_MAX_SEG];
 };
+
+// index with the tile number's bits deposited by segments: bits [src, src + len) of t go to [dst, dst + len)
+__device__ __forceinline__ uint64_t fuse_deposit(uint64_t t, const FuseSeg *seg, unsigned nseg)
+{
+    uint64_t x = 0;
+    for (unsigned k = 0; k < nseg; k++) x |= ((t >> seg[k].src) & (((uint64_t)1 << seg[k].len) - 1)) << seg[k].dst;
+    return x;
+}
+// offset of a tile-local element index under a bit -> position table (linear in its bits)
+__device__ __forceinline__ uint64_t fuse_spread(unsigned e, const uint8_t *pos, unsigned T)
+{
+    uint64_t off = 0;
+    for (unsigned j = 0; j < T; j++) off |= (uint64_t)((e >> j) & 1u) << pos[j];
+    return off;
+}
 
 // One controlled modular multiply on an LDS-resident tile whose low M local bits are the M register.
 //   op.a    = M | (ctl_local + 1) << 8      (0 in the high part: the control is outside the tile)
@@ -1695,22 +1724,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void
     __syncthreads();
     constexpr unsigned EPT = TT ? ((1u << TT) + BLOCK - 1) / BLOCK : 16;      // elements per thread (<= 16)
     const unsigned ept = TT ? EPT : (tsize + BLOCK - 1) / BLOCK;
-    const unsigned lowmask = (1u << c) - 1u;
-
-    // global offset of a tile-local element index: linear in its bits, so split thread part / k part
-    auto scatter = [&](unsigned e) -> uint64_t {
-        uint64_t off = e & lowmask;
-        for (unsigned j = 0; j < nh; j++) off |= (uint64_t)((e >> (c + j)) & 1u) << P.hbit[j];
-        return off;
-    };
+    (void)c; (void)nh;
+    // global offset of a tile-local element index: linear in its bits, so split thread part / k part (this kernel works in
+    // place on the identity layout: the output tables of FusePass equal the input ones)
+    auto scatter = [&](unsigned e) -> uint64_t { return fuse_spread(e, P.in_pos, T); };
     const uint64_t off_t = scatter(threadIdx.x);
     uint64_t off_k[EPT];
 #pragma unroll
     for (unsigned k = 0; k < EPT; k++) off_k[k] = scatter(k * BLOCK);
 
     for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        uint64_t base = t << c;
-        for (unsigned j = 0; j < nh; j++) base = insert_zero(base, P.hbit[j]);
+        const uint64_t base = fuse_deposit(t, P.seg_in, P.nseg_in);
         amp_t *g = amp + (base | off_t);
 
         if constexpr (TT != 0 && LDSDMA) {
@@ -1761,7 +1785,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void
 // the rounds interpreter and is held to OCC waves per SIMD.
 template <int BLOCK, int TT, int OCC, bool CAM, int TOL = 0>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) void k_fused_rounds(
-    amp_t *__restrict__ amp, unsigned n, FusePass P, const FuseOp *__restrict__ ops, uint64_t ntiles, const FuseOp *ops_asm)
+    const amp_t *amp, amp_t *amp_out, unsigned n, FusePass P, const FuseOp *__restrict__ ops, uint64_t ntiles, const FuseOp *ops_asm)
 {
     static_assert((1u << TT) == 4u * BLOCK, "rounds form: 4 amplitudes per thread");
     extern __shared__ __attribute__((aligned(16))) unsigned char qcx_lds_raw[];
@@ -1780,17 +1804,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
     if constexpr (TOL)
         for (unsigned b = threadIdx.x; b < P.dg_cnt * 48u; b += BLOCK) dg[P.dg_cnt + b] = dg_area[3u * P.dg_cnt + b];
     __syncthreads();
-    const unsigned c = P.c, nh = P.nh;
-    const unsigned lowmask = (1u << c) - 1u;
-    auto scatter = [&](unsigned e) -> uint64_t {
-        uint64_t off = e & lowmask;
-        for (unsigned j = 0; j < nh; j++) off |= (uint64_t)((e >> (c + j)) & 1u) << P.hbit[j];
-        return off;
-    };
-    const uint64_t off_t = scatter(threadIdx.x);
-    uint64_t off_k[4];
+    const uint64_t off_t = fuse_spread(threadIdx.x, P.in_pos, TT);
+    uint64_t off_k[4], st_k[4];
+    unsigned ld_k[4];
 #pragma unroll
-    for (unsigned k = 0; k < 4; k++) off_k[k] = scatter(k * BLOCK);
+    for (unsigned k = 0; k < 4; k++) {
+        off_k[k] = fuse_spread(k * BLOCK, P.in_pos, TT);
+        st_k[k] = fuse_spread(k * BLOCK, P.st_pos, TT);
+        ld_k[k] = (unsigned)fuse_spread(k * BLOCK, P.st_loc, TT);
+    }
+    const uint64_t st_t = fuse_spread(threadIdx.x, P.st_pos, TT);
+    const unsigned ld_t = (unsigned)fuse_spread(threadIdx.x, P.st_loc, TT);
     const unsigned wbase = (threadIdx.x >> 6) * 64;
     // swz = s > 0: workgroups that share an XCD (blockIdx mod 8 under round-robin placement) take 2^s NEIGHBOURING tiles
     // instead of every eighth one -- their runs are then adjacent in memory (speed only; any order is correct)
@@ -1801,9 +1825,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
             const uint64_t xcd = t0 & 7u, slot = t0 >> 3, in = slot & ((1u << swz) - 1u), grp = slot >> swz;
             t = (((grp << 3) | xcd) << swz) | in;
         }
-        uint64_t base = t << c;
-        for (unsigned j = 0; j < nh; j++) base = insert_zero(base, P.hbit[j]);
-        amp_t *g = amp + (base | off_t);
+        const uint64_t base_in = fuse_deposit(t, P.seg_in, P.nseg_in);
+        uint64_t base = base_in, base_out = base_in;               // logical base (gate records), output base
+        if (P.chained) { base = fuse_deposit(t, P.seg_lg, P.nseg_lg); base_out = fuse_deposit(t, P.seg_out, P.nseg_out); }
+        const amp_t *g = amp + (base_in | off_t);
+        amp_t *go = amp_out + (base_out | st_t);
         if (!(P.dbg & 4u)) {
 #pragma unroll
             for (unsigned k = 0; k < 4; k++)
@@ -1827,10 +1853,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
         if (!(P.dbg & 1u)) fuse_apply_rounds<BLOCK, TT, CAM, TOL>(tile, lut, camtab, xm, P, ops, ops_asm, base, dg);
         amp_t v[4];
 #pragma unroll
-        for (unsigned k = 0; k < 4; k++) v[k] = tile[k * BLOCK + threadIdx.x];
+        for (unsigned k = 0; k < 4; k++) v[k] = tile[ld_k[k] | ld_t];          // (store order: ascending OUTPUT positions)
         if (!(P.dbg & 2u)) {
 #pragma unroll
-            for (unsigned k = 0; k < 4; k++) __builtin_nontemporal_store(v[k], g + off_k[k]);
+            for (unsigned k = 0; k < 4; k++) __builtin_nontemporal_store(v[k], go + st_k[k]);
         }
         __syncthreads();
     }
@@ -1917,7 +1943,7 @@ __device__ __forceinline__ void q3_run(amp_t *tile, unsigned p, const unsigned (
 // sweep): exact butterflies (separate roundings, no FMA), canonical zeros once at the store; no tables, no diagonals.
 template <int BLOCK, int TT, int OCC, bool EXACT = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) void k_fused_q3(
-    amp_t *__restrict__ amp, unsigned n, FusePass P, const FuseOp *__restrict__ ops, uint64_t ntiles)
+    const amp_t *amp, amp_t *amp_out, unsigned n, FusePass P, const FuseOp *__restrict__ ops, uint64_t ntiles)
 {
     static_assert((1u << TT) == 8u * BLOCK, "radix-8 rounds: 8 amplitudes per thread");
     extern __shared__ __attribute__((aligned(16))) unsigned char qcx_lds_raw[];
@@ -1929,22 +1955,24 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
         for (unsigned b = threadIdx.x; b < P.dg_cnt * 48u; b += BLOCK) dg[P.dg_cnt + b] = dg_area[3u * P.dg_cnt + b];
     __syncthreads();
     const amp_t *gtab = dg + P.dg_cnt;
-    const unsigned c = P.c, nh = P.nh;
-    const unsigned lowmask = (1u << c) - 1u;
-    auto scatter = [&](unsigned e) -> uint64_t {
-        uint64_t off = e & lowmask;
-        for (unsigned j = 0; j < nh; j++) off |= (uint64_t)((e >> (c + j)) & 1u) << P.hbit[j];
-        return off;
-    };
-    const uint64_t off_t = scatter(threadIdx.x);
-    uint64_t off_k[8];
+    const uint64_t off_t = fuse_spread(threadIdx.x, P.in_pos, TT);
+    uint64_t off_k[8], st_k[8];
+    unsigned ld_k[8];
 #pragma unroll
-    for (unsigned k = 0; k < 8; k++) off_k[k] = scatter(k * BLOCK);
+    for (unsigned k = 0; k < 8; k++) {
+        off_k[k] = fuse_spread(k * BLOCK, P.in_pos, TT);
+        st_k[k] = fuse_spread(k * BLOCK, P.st_pos, TT);
+        ld_k[k] = (unsigned)fuse_spread(k * BLOCK, P.st_loc, TT);
+    }
+    const uint64_t st_t = fuse_spread(threadIdx.x, P.st_pos, TT);
+    const unsigned ld_t = (unsigned)fuse_spread(threadIdx.x, P.st_loc, TT);
     const unsigned wbase = (threadIdx.x >> 6) * 64;
     for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        uint64_t base = t << c;
-        for (unsigned j = 0; j < nh; j++) base = insert_zero(base, P.hbit[j]);
-        amp_t *g = amp + (base | off_t);
+        const uint64_t base_in = fuse_deposit(t, P.seg_in, P.nseg_in);
+        uint64_t base = base_in, base_out = base_in;               // logical base (gate records), output base
+        if (P.chained) { base = fuse_deposit(t, P.seg_lg, P.nseg_lg); base_out = fuse_deposit(t, P.seg_out, P.nseg_out); }
+        const amp_t *g = amp + (base_in | off_t);
+        amp_t *go = amp_out + (base_out | st_t);
         if (!(P.dbg & 4u)) {
 #pragma unroll
             for (unsigned k = 0; k < 8; k++)
@@ -1986,13 +2014,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
         const double sc = (P.dbg & 1u) ? 1.0 : P.tol_scale;
 #pragma unroll
         for (unsigned k = 0; k < 8; k++) {
-            v[k] = tile[k * BLOCK + threadIdx.x];
+            v[k] = tile[ld_k[k] | ld_t];                                    // (store order: ascending OUTPUT positions)
             if constexpr (EXACT) { v[k].x += 0.0; v[k].y += 0.0; }          // the reference's canonical zeros, once per pass
             else { v[k].x *= sc; v[k].y *= sc; }
         }
         if (!(P.dbg & 2u)) {
 #pragma unroll
-            for (unsigned k = 0; k < 8; k++) __builtin_nontemporal_store(v[k], g + off_k[k]);
+            for (unsigned k = 0; k < 8; k++) __builtin_nontemporal_store(v[k], go + st_k[k]);
         }
         __syncthreads();
     }

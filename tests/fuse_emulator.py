@@ -5,8 +5,9 @@ passes / stand-alone gates) and the 32-byte records of every pass.  This module 
 vector with the arithmetic the kernels in csrc/qcx_kernels.h use -- same products and sums in the same order, the
 "+ 0.0" canonicalisation where the kernels put it (per gate in the plain form; once per round / run in the ROUNDS
 form) -- so that the CPU-only test suite can check planner + record format + kernel semantics against the oracle
-without a GPU.  Everything is expressed on GLOBAL amplitude indices: tile-local bit j is global bit j for j < c and
-global bit hbit[j - c] above.
+without a GPU.  Everything is expressed on LOGICAL amplitude indices: tile-local bit j is qubit act.tl[j] (in place on the
+identity layout: j for j < c, hbit[j - c] above).  Where a chained pass reads and writes its tiles in memory is checked
+separately (check_chain_addressing): it never changes what the records mean.
 """
 import struct
 
@@ -23,14 +24,20 @@ class Pass:
         self.hbit = [int(act.hbit[j]) for j in range(act.nh)]
         self.T = act.T
         assert self.T == self.c + len(self.hbit)
+        # the qubit that is tile-local bit j: act.tl (a chained pass orders its tile by the layout it reads; in place on the
+        # identity layout this is the low c bits followed by the hot bits)
+        self.tl = [int(act.tl[j]) for j in range(self.T)]
+        assert sorted(self.tl) == sorted(list(range(self.c)) + self.hbit)
+        if not getattr(act, "chained", 0):
+            assert self.tl == list(range(self.c)) + self.hbit
         self.idx = np.arange(1 << n, dtype=np.uint64)
-        tile_mask = (1 << self.c) - 1
-        for b in self.hbit:
+        tile_mask = 0
+        for b in self.tl:
             tile_mask |= 1 << b
         self.base = self.idx & np.uint64(~tile_mask & ((1 << 64) - 1))
 
     def gbit(self, j):
-        return j if j < self.c else self.hbit[j - self.c]
+        return self.tl[j]
 
     def bit(self, j_local):
         return ((self.idx >> np.uint64(self.gbit(j_local))) & np.uint64(1)).astype(bool)
@@ -343,3 +350,68 @@ def _rotate_oracle_pair(state, n, bits, c, s):
     sel = (((idx >> bits[0]) & 1) == 1) & (((idx >> bits[1]) & 1) == 1)
     _rotate(re, im, sel, c, s, True)
     state[0::2], state[1::2] = re, im
+
+
+def _deposit(t, segs, nseg):
+    x = 0
+    for k in range(nseg):
+        src, dst, ln = segs[4 * k], segs[4 * k + 1], segs[4 * k + 2]
+        x |= ((t >> src) & ((1 << ln) - 1)) << dst
+    return x
+
+
+def _spread(e, pos, T):
+    off = 0
+    for j in range(T):
+        off |= ((e >> j) & 1) << int(pos[j])
+    return off
+
+
+def check_chain_addressing(n, actions):
+    """Follow the ADDRESSES of a plan's fused passes exactly as the kernels compute them (FusePass tables): a buffer that
+    holds, at every physical index, the LOGICAL index of the amplitude stored there.  Every pass must (a) find in each tile
+    exactly the amplitudes of one logical tile, element e at the local index the records assume (act.tl), (b) see the logical
+    base index it tests controls against, (c) store a permutation; and after the last pass of every chain the layout must be
+    the identity again.  Returns the number of chained passes."""
+    cur = np.arange(1 << n, dtype=np.int64)          # identity layout
+    chained = 0
+    for act in actions:
+        if not act.fused:
+            assert np.array_equal(cur, np.arange(1 << n)), "a stand-alone gate needs the identity layout"
+            continue
+        T = act.T
+        tl = [int(act.tl[j]) for j in range(T)]
+        e = np.arange(1 << T, dtype=np.int64)
+        in_off = np.zeros(1 << T, dtype=np.int64)
+        lg_off = np.zeros(1 << T, dtype=np.int64)
+        for j in range(T):
+            in_off |= ((e >> j) & 1) << int(act.in_pos[j])
+            lg_off |= ((e >> j) & 1) << tl[j]
+        # store order: position j of the store index eo belongs to local bit st_loc[j], lands at output bit st_pos[j]
+        ld = np.zeros(1 << T, dtype=np.int64)
+        st = np.zeros(1 << T, dtype=np.int64)
+        for j in range(T):
+            ld |= ((e >> j) & 1) << int(act.st_loc[j])
+            st |= ((e >> j) & 1) << int(act.st_pos[j])
+        assert sorted(int(x) for x in act.st_loc[:T]) == list(range(T))
+        out = np.full(1 << n, -1, dtype=np.int64) if act.chained else None
+        ntiles = 1 << (n - T)
+        for t in range(ntiles):
+            b_in = _deposit(t, bytes(act.seg_in), act.nseg_in)
+            b_lg, b_out = b_in, b_in
+            if act.chained:
+                b_lg = _deposit(t, bytes(act.seg_lg), act.nseg_lg)
+                b_out = _deposit(t, bytes(act.seg_out), act.nseg_out)
+            tile = cur[b_in | in_off]                 # what the fill brings to local index e
+            assert np.array_equal(tile, b_lg | lg_off), f"tile {t}: the fill does not deliver the logical tile the records assume"
+            if act.chained:
+                assert np.all(out[b_out | st] == -1)
+                out[b_out | st] = tile[ld]
+            else:
+                assert act.nseg_out == 0 and np.array_equal(np.asarray(act.st_pos[:T]), np.asarray(act.in_pos[:T]))
+        if act.chained:
+            assert np.all(out >= 0), "the stores of a chained pass cover the buffer exactly once"
+            cur = out
+            chained += 1
+    assert np.array_equal(cur, np.arange(1 << n)), "a plan must leave the identity layout behind"
+    return chained

@@ -356,3 +356,80 @@ def test_tolerance_mode_shard_level_lists(qc, ob, tune_guard, seed):
     got = state[0::2] + 1j * state[1::2]
     assert float(np.max(np.abs(got - z))) <= 1e-12
     assert tot["diags"] >= 6
+
+
+# ---- chained passes (round 4): the same records under another numbering, other addresses -----------------------------------
+CHAIN_KEYS = TUNE_KEYS + ("fuse_chain", "fuse_chain_min_n", "fuse_hsweep_T", "fuse_hsweep_c")
+
+
+@pytest.fixture()
+def chain_guard(qc):
+    old = {k: qc.lib().qcx_tune_get(k.encode()) for k in CHAIN_KEYS}
+    qc.tune(fuse_chain=1, fuse_chain_min_n=13)
+    yield
+    qc.tune(**old)
+
+
+def sweep_descs(n, reps=1, order=None):
+    return [(0, q, 0, 0.0, 0.0, 0, 0) for _ in range(reps) for q in (order or range(n))]
+
+
+@pytest.mark.parametrize("mode", [1, 2], ids=["exact", "tolerance"])
+@pytest.mark.parametrize("n,M,Cn", [(14, 0, 1), (16, 0, 1), (15, 4, 15), (16, 5, 21)])
+def test_chained_plans_reproduce_the_oracle(qc, ob, chain_guard, n, M, Cn, mode):
+    """plans of a register with a second buffer (mode | 4): sweeps, the inverse-QFT schedule, Shor circuits and random
+    programs.  The emulator applies the records on logical indices (bit-exact vs the oracle in mode 1, 1e-12 in mode 2);
+    check_chain_addressing follows the kernels' address arithmetic through every pass."""
+    rs = np.random.RandomState(1000 + n + mode)
+    programs = []
+    programs.append(("sweep", sweep_descs(n, 2), [("h", q) for _ in range(2) for q in range(n)]))
+    d = iqft_descs(qc, n, M)
+    st = []
+    for l in range(n - 1, M - 1, -1):
+        st.append(("h", l))
+        for k in range(l - 1, M - 1, -1):
+            st.append(("p", l, k, math.pi / float(1 << (l - k))))
+    programs.append(("iqft", d, st))
+    for trial in range(2):
+        dd, ss = random_program(rs, n, M, Cn, 120)
+        programs.append((f"random{trial}", fill_polar(qc, dd, ss), ss))
+    total_chained = 0
+    for name, descs, steps in programs:
+        for tune in (dict(), dict(fuse_T=10, fuse_c=4), dict(fuse_T=12, fuse_c=3)):
+            qc.tune(fuse_T=11, fuse_c=4)
+            qc.tune(**tune)
+            actions, recs, nrec = qc.fusion_plan(n, M, descs, mode | 4)
+            total_chained += emu.check_chain_addressing(n, actions)
+            state = ob.random_state(n, 3)
+            want = state.copy()
+            oracle_run(ob, want, n, M, Cn, steps)
+            emu.run_plan(state, n, M, descs, actions, recs, ob)
+            if mode == 1:
+                assert np.array_equal(bits(state), bits(want)), (name, tune)
+            else:
+                assert float(np.max(np.abs(state - want))) <= 1e-12, (name, tune)
+    assert total_chained >= 6, "the planner never chained anything"
+
+
+def test_chain_of_the_n30_sweep_and_the_n28_iqft(qc, chain_guard):
+    """what the chained plans look like at full size (addresses only: no state): n = 30 sweep = 3 passes, every one reads
+    whole tiles (the first from the identity layout: its tile is the 12 low bits), stores runs of 2^3 amplitudes, and the last
+    one stores the identity layout; n = 28 inverse QFT, tolerance mode: 3 radix-8 passes"""
+    qc.tune(fuse_chain_min_n=20)
+    n = 30
+    actions, recs, nrec = qc.fusion_plan(n, 0, sweep_descs(n), 1 | 4)
+    assert [a.fused for a in actions] == [1, 1, 1] and [a.chained for a in actions] == [1, 1, 1]
+    for k, a in enumerate(actions):
+        assert a.T == 12
+        assert [int(x) for x in a.in_pos[:12]] == list(range(12)), "every pass of the chain reads contiguous tiles"
+        run = 0
+        while run < 12 and a.st_pos[run] == run:
+            run += 1
+        assert run == (3 if k < 2 else 3), (k, run)            # stores: 128-byte runs
+    last = actions[-1]
+    out_of = {int(last.tl[int(last.st_loc[j])]): int(last.st_pos[j]) for j in range(12)}
+    assert all(q == p for q, p in out_of.items()), "the last pass of a chain stores the identity layout"
+    n = 28
+    actions, recs, nrec = qc.fusion_plan(n, 0, iqft_descs(qc, n, 0), 2 | 4)
+    assert [a.fused for a in actions] == [1, 1, 1] and [a.chained for a in actions] == [1, 1, 1]
+    assert [int(x) for x in actions[1].in_pos[:12]] == list(range(12)) and [int(x) for x in actions[2].in_pos[:12]] == list(range(12))

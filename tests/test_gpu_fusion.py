@@ -315,3 +315,70 @@ def test_pure_hadamard_sweep_takes_the_three_pass_geometry_and_keeps_the_bits(qc
         r2.flush()
         assert r2.fusion_stats()[0] - p0 == 4
         assert np.array_equal(bits(r1.read(0, 1 << 13)), bits(r2.read(0, 1 << 13)))
+
+
+# ---- chained passes (round 4): runs of passes through the register's second buffer -------------------------------------------
+@pytest.fixture()
+def chain_guard(qc):
+    keys = ("fuse_chain", "fuse_chain_min_n", "fuse_T", "fuse_c", "fuse_T_phase", "fuse_phase_ratio")
+    old = {k: qc.lib().qcx_tune_get(k.encode()) for k in keys}
+    yield
+    qc.tune(**old)
+
+
+def chained_passes(qc, reg):
+    import ctypes as C
+    out = C.c_ulong(0)
+    qc.lib().qcx_chain_stats(reg._h, C.byref(out))
+    return out.value
+
+
+@pytest.mark.parametrize("mode", [1, 2], ids=["exact", "tolerance"])
+@pytest.mark.parametrize("L,M,Cn", [(14, 0, 1), (17, 0, 1), (11, 4, 15), (13, 5, 21), (21, 0, 1)])
+def test_chained_passes_give_the_same_bits(qc, ob, chain_guard, L, M, Cn, mode):
+    """every chained pass reads one buffer under one layout and writes the other under another one; sweeps, the
+    inverse-QFT schedule, Shor circuits and random programs against the oracle (bit for bit in the exact mode, 1e-12 in the
+    tolerance mode), every observer in between (reads, norm, measurement) sees the identity layout"""
+    n = L + M
+    qc.tune(fuse_chain=1, fuse_chain_min_n=13)
+    rs = np.random.RandomState(n * 7 + mode)
+    threads = 8
+    with qc.Register(L, M) as reg:
+        reg.set_fusion(mode)
+        for geom in (dict(fuse_T=11, fuse_c=4), dict(fuse_T=10, fuse_c=4), dict(fuse_T=12, fuse_c=3)):
+            qc.tune(**geom)
+            want = ob.fill_random(n, 21)
+            reg.fill_random(21)
+            for _ in range(2):
+                for q in range(n):
+                    qc.hadamard_gate(q, reg); ob.hadamard(want, n, q, threads)
+            assert abs(reg.norm2() - ob.norm2(want, n)) < 1e-12
+            qc.inverse_QFT(reg); ob.iqft(want, n, M, threads)
+            prog = random_program(rs, n, M, Cn, 80)
+            for g in prog:
+                if g[0] == "h":
+                    qc.hadamard_gate(g[1], reg); ob.hadamard(want, n, g[1], threads)
+                elif g[0] == "p":
+                    qc.c_phase_shift_gate(g[1], g[2], g[3], reg); ob.cphase(want, n, g[1], g[2], g[3], threads)
+                else:
+                    qc.c_amodc_gate(Cn, g[1], g[2], reg); ob.camodc(want, n, M, Cn, g[1], g[2], threads)
+            got = reg.read()
+            if mode == 1:
+                assert np.array_equal(bits(got), bits(want)), geom
+            else:
+                assert float(np.max(np.abs(got - want))) <= 1e-12, geom
+        assert chained_passes(qc, reg) >= 4
+        if M:
+            qc.reset_register(reg); qc.quantum_computation(Cn, 2 if Cn == 21 else 7, reg)
+            w2 = np.zeros(2 << n); ob.reset(w2, n); ob.quantum_computation(w2, n, M, Cn, 2 if Cn == 21 else 7, threads=threads)
+            r = 0.37
+            assert qc.measure_state(reg, r) == ob.measure(w2, n, r)
+        # a register whose buffer pointer has been handed out works in place from then on (the pointer stays valid)
+        before = chained_passes(qc, reg)
+        p0 = reg.device_pointer()
+        reg.fill_random(5); w3 = ob.fill_random(n, 5)
+        for q in range(n):
+            qc.hadamard_gate(q, reg); ob.hadamard(w3, n, q, threads)
+        got = reg.read()
+        assert reg.device_pointer() == p0 and chained_passes(qc, reg) == before
+        assert np.array_equal(bits(got), bits(w3)) if mode == 1 else float(np.max(np.abs(got - w3))) <= 1e-12

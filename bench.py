@@ -24,7 +24,9 @@ Extra objects on the JSON line:
                 workload: tier T3 = pairwise in place, OpenMP over the host cores (the headline `value`),
                 T2 = the reference's COO mat-vec alone, T1 = the literal reference algorithm.
   fused_sweep   (N = 1) the same 30 gate calls with qcx_set_fusion(1): passes, GB/s per pass, roofline fraction.
-  configs       (N = 1) the other BASELINE.json configurations that fit one GPU, driver-timed: config 2 (n=26 H sweep),
+  configs       (N = 1) the other BASELINE.json configurations that fit one GPU, driver-timed (plus kernels_n30: the per-gate
+                kernels next to the headline one -- modular multiply, controlled phase, measurement scan, circuit front -- against
+                their algorithmic bytes): config 2 (n=26 H sweep),
                 config 3 (n=28 qcx_inverse_QFT: fused passes = the default, one launch per gate, and -- when the build
                 has it -- the opt-in tolerance mode), config 5 on one GPU (n=30 qcx_quantum_computation(21, 2) +
                 measure_state).  Each with ms, passes, GB/s per pass, FP64-op/s and the fraction of each roof.
@@ -297,8 +299,10 @@ def main():
                      "hbm_passes_per_sweep": passes, "hbm_gbs_per_pass": gbs_pass, "roofline_frac": gbs_pass / HBM_PEAK_GBS,
                      "note": "qcx_set_fusion(1): same 30 hadamard_gate calls, executed as fused passes over LDS tiles; "
                              "32 B per amplitude are counted once per pass.  An all-Hadamard queue is planned on 2^12-amplitude "
-                             "tiles with 128-B runs: 3 passes per 30-qubit sweep instead of 4, each slower (about 4.2 vs 5.1 TB/s), "
-                             "the sweep faster.  With the gates skipped the three passes take 21.3 ms (profiles/r03_tune_sweep.txt)"}
+                             "tiles (radix-8 rounds): 3 passes per 30-qubit sweep, CHAINED through the register's second buffer "
+                             "(round 4): every pass reads whole 64-KiB tiles and stores 128-B runs under the layout the next pass "
+                             "reads contiguously; the last one stores the identity layout.  In place (round 3) the same passes took "
+                             "22.7 ms; with the gates skipped the chained passes take 19.9-20.7 ms (DESIGN.md s4)"}
             reg.set_fusion(False)
         reg.close()
         exchanges = 0
@@ -593,13 +597,52 @@ def single_gpu_configs(qc, reps=3):
         reg.set_fusion(0)
         circuit()
         c5["total_probability"] = reg.norm2()
+        reg.synchronize()
         t0 = time.perf_counter()
         idx = qc.measure_state(reg, rng)
-        c5["measure_ms"] = (time.perf_counter() - t0) * 1e3
+        c5["measure_ms"] = (time.perf_counter() - t0) * 1e3           # wall clock of the call: the scan + its read-back; the collapse is lazy
+        c5["measure_hbm_roof_frac"] = 16.0 * 2.0 ** n / (c5["measure_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS   # algorithmic: one read of the state
         c5["measured_index"] = idx
         c5["omega"] = qc.read_omega(idx, reg)
         c5["nearest_multiple_of_one_sixth"] = min((abs(c5["omega"] - k / 6.0), k) for k in range(7))[1]
     out["config5_one_gpu"] = c5
+
+    # the per-gate kernels next to the headline one, at n = 30 (HIP events on the register's stream, best of 4), against the
+    # algorithmic bytes of SURVEY s8(d)
+    kern = {}
+    with qc.Register(L, M) as reg:
+        reg.set_fusion(-1)
+        reg.fill_random(3)
+
+        def best(fn, reps=4):
+            fn(); reg.synchronize()
+            b = 1e30
+            for _ in range(reps):
+                reg.timer_start(); fn(); b = min(b, reg.timer_stop())
+            return b
+
+        def row(name, ms, nbytes, what):
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            kern[name] = {"ms": ms, "algorithmic_bytes": nbytes, "algorithmic_gbs": gbs, "hbm_roof_frac": gbs / HBM_PEAK_GBS, "bytes": what}
+        row("c_amodc_gate(C=21, ctl=17), M=5 [k_camodc]", best(lambda: qc.c_amodc_gate(21, 4, 17, reg)), 32.0 * 2.0 ** (n - 1),
+            "32 B x the control-set half (rows >= C are neither read nor written: the kernel moves less)")
+        row("c_phase_shift_gate(29, 12) [k_phase]", best(lambda: qc.c_phase_shift_gate(29, 12, 0.3, reg)), 32.0 * 2.0 ** (n - 2),
+            "32 B x the quarter with both bits set")
+        row("c_phase_shift_gate(20, 1) [k_phase_lines]", best(lambda: qc.c_phase_shift_gate(20, 1, 0.3, reg)), 32.0 * 2.0 ** (n - 1),
+            "32 B x the touched 128-B lines (bit 1 lies inside a line: half the state's lines)")
+        row("hadamard_gate(1) [k_h_wave]", best(lambda: qc.hadamard_gate(1, reg)), 32.0 * 2.0 ** n, "32 B per amplitude")
+        row("measure_state scan to the end [k_meas_onepass + walk]", best(lambda: reg.total_probability()), 16.0 * 2.0 ** n,
+            "one read of the state (qcx_total_probability: the exact scan without a collapse)")
+        reg.set_fusion(0)
+
+        def front():
+            qc.reset_register(reg)
+            for l in range(M, n):
+                qc.hadamard_gate(l, reg)
+            reg.flush()
+        reg.set_fusion(1)
+        row("reset_register + Hadamard layer [k_basis_front]", best(front), 16.0 * 2.0 ** n, "one write of the state, nothing read")
+    out["kernels_n30"] = kern
     return out
 
 

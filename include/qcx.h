@@ -262,6 +262,9 @@ int  qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_t first_gl
                             int *found, uint64_t *index, double *cum_out, void *stream);
 /* zero the shard; if 0 <= local_index < 2^n_local set that amplitude to (1,0) */
 int  qcx_shard_collapse(void *amp, unsigned n_local, int64_t local_index, void *stream);
+/* -0 components of the shard become +0: for amplitudes the caller wrote, before the first gate runs on them (the
+ * reference's mat-vec canonicalises every amplitude at every gate, Q:393-413; the gate kernels only those they act on) */
+int  qcx_shard_canon_zeros(void *amp, unsigned n_local, void *stream);
 
 #ifdef __cplusplus
 }

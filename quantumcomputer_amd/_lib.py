@@ -93,6 +93,7 @@ SIGNATURES = {
     "qcx_fusion_plan_mode": (_i, [_i, _u, _u, _u, _p, _p, _u, C.POINTER(_u), _p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "qcx_shard_measure_scan": (_i, [_p, _u, _u64, _u64, _d, _d, C.POINTER(_i), C.POINTER(_u64), C.POINTER(_d), _p]),
     "qcx_shard_collapse": (_i, [_p, _u, _i64, _p]),
+    "qcx_shard_canon_zeros": (_i, [_p, _u, _p]),
 }
 # not in the public header: diagnostics / tuning hooks
 _EXTRA = {

@@ -98,6 +98,9 @@ struct Tune {
     long cam_grid_cap = 0;     // (round 3: one tile per workgroup, 2.80-2.89 ms per gate at n = 30 against 2.85-3.0 with 4096 workgroups)
     long cam_full    = 0;      // modular multiply: 1 = whole-tile nontemporal write-back, 0 = partial (moved residues only), -1 = by C / 2^M
                                // (measured n = 30, C = 21, M = 5: whole tiles 2.9-3.4 ms = 17.2 GB at 5.0-5.9 TB/s, partial 2.8-2.9 ms = 14.5 GB at 5.0-5.2)
+    long cam_logT    = 8;      // modular multiply: tile = 2^this amplitudes, at least the 2^M block (n = 30, C = 21, M = 5: 2^11 2.65 ms, 2^10 2.50, 2^9 2.3-2.6, 2^8 2.3; 2^12 4.2)
+    long cam_skip    = 1;      // modular multiply: the 128-B lines of a 2^M block above row C are neither sources nor destinations: not read
+    long cam_nt_lines = 0;     // modular multiply: completely rewritten lines leave as nontemporal stores (the partly rewritten one through L2)
     long fuse_T      = 11;     // fused passes: tile = 2^T amplitudes in LDS (8..12)
     long fuse_c      = 4;      // fused passes: contiguous low bits of a tile (runs of 16 * 2^c bytes)
     long fuse_grid_cap = 24576; // workgroups of the one-tile-per-workgroup form (each walks several tiles: the table fill at kernel start is amortised)
@@ -139,7 +142,7 @@ static Tune tune_now() { std::lock_guard<std::mutex> lock(g_tune_mutex); return 
 extern "C" int qcx_tune_set(const char *key, long value)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); g_tune.name = value; return QCX_NO_ERROR; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_full) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_onepass) K(meas_spin_limit) K(meas_dbg) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_min_n) K(fuse_q3_c3)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_full) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_onepass) K(meas_spin_limit) K(meas_dbg) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_min_n) K(fuse_q3_c3)
 #undef K
     return QCX_BAD_ARGUMENTS;
 }
@@ -147,7 +150,7 @@ extern "C" int qcx_tune_set(const char *key, long value)
 extern "C" long qcx_tune_get(const char *key)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); return g_tune.name; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_full) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_onepass) K(meas_spin_limit) K(meas_dbg) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_min_n) K(fuse_q3_c3)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_full) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_onepass) K(meas_spin_limit) K(meas_dbg) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_min_n) K(fuse_q3_c3)
 #undef K
     return -1;
 }
@@ -232,6 +235,17 @@ extern "C" int qcx_shard_collapse(void *amp, unsigned n_local, int64_t local_ind
         hipLaunchKernelGGL(k_set_one, dim3(1), dim3(64), 0, st, (amp_t *)amp, (uint64_t)local_index);
         HIP_TRY(hipGetLastError());
     }
+    return QCX_NO_ERROR;
+}
+
+// -0 components become +0 (what the reference's mat-vec does to every amplitude at every gate, Q:393-413): for a state the
+// caller wrote, before the first gate runs on it (k_canon_zeros)
+extern "C" int qcx_shard_canon_zeros(void *amp, unsigned n_local, void *stream)
+{
+    if (!amp || n_local > 40) return QCX_BAD_ARGUMENTS;
+    const uint64_t count = (uint64_t)1 << n_local;
+    hipLaunchKernelGGL(k_canon_zeros, dim3(grid_for(count, 256 * 4, 0, 256)), dim3(256), 0, (hipStream_t)stream, (amp_t *)amp, count);
+    HIP_TRY(hipGetLastError());
     return QCX_NO_ERROR;
 }
 
@@ -491,8 +505,9 @@ extern "C" int qcx_shard_camodc(void *amp, unsigned n_local, unsigned M, unsigne
     const Tune tn = tune_now();
 
     CamodcParams P;
+    memset(&P, 0, sizeof P);
     P.M = M;
-    P.logT = (M < 11) ? 11 : M;                      // >= 2048 amplitudes (32 KiB) per tile
+    { const unsigned want = (unsigned)std::min<long>(12, std::max<long>(8, tn.cam_logT)); P.logT = (M < want) ? want : M; }     // tile: >= the 2^M block
     if (P.logT > n_local) P.logT = n_local;
     // a control at or above the M register is squeezed out of the tile numbering (tiles hold control-set amplitudes
     // only: half the vector is never read); that needs at least two tiles' worth of index space
@@ -500,10 +515,11 @@ extern "C" int qcx_shard_camodc(void *amp, unsigned n_local, unsigned M, unsigne
     if (P.logT < M) return QCX_BAD_ARGUMENTS;
     P.ctl = ctl;
     P.C = C;
+    P.skip = tn.cam_skip != 0; P.ntl = tn.cam_nt_lines != 0;
     const uint64_t blk = (uint64_t)1 << M;
     const uint64_t all_tiles = (uint64_t)1 << (n_local - P.logT);
     const uint64_t ctl_tiles = (ctl >= (int)M) ? all_tiles >> 1 : all_tiles;
-    const size_t lds = (size_t)16 << P.logT;
+    const size_t lds = ((size_t)16 << P.logT) + (((size_t)2 << M) + 15) / 16 * 16;       // tile + the source table of the permutation case
 
     // closed form is valid when the control is outside the M register, every residue fits the
     // register (C <= 2^M) and the reference's 32-bit product A*f cannot wrap (Q:598-600, Q:639)
@@ -718,6 +734,8 @@ struct qcx_register {
     unsigned   n_events;
     amp_t     *scratch;         // second buffer, allocated on first use (chained passes; M > 12 modular multiply)
     int        no_chain;        // the buffer pointer was handed out (qcx_device_pointer) or no second buffer fits: passes work in place
+    int        zeros_dirty;     // the caller wrote amplitudes (qcx_state_write / _load): they may hold -0, which the reference's gates would
+                                // canonicalise (Q:393-413); one k_canon_zeros pass runs before the next gate
     int        fusion;          // 1: every gate call is queued (fused passes, qcx_fuse.inc.h); 0: only the whole-circuit entry points; -1: nothing
     int        composite;       // > 0 while a whole-circuit entry point is queueing its gates
     struct GateQueue *queue;
@@ -728,6 +746,15 @@ struct qcx_register {
 };
 
 static int reg_camodc(qcx_register *r, unsigned C, unsigned A, unsigned ctl);
+
+// a state the caller wrote may hold -0 components; the reference's next gate would turn them into +0 wherever they sit
+// (Q:393-413), the gate kernels only where they act: one pass over the state before the first gate after such a write
+static int canon_if_dirty(qcx_register *r)
+{
+    if (!r->zeros_dirty) return QCX_NO_ERROR;
+    r->zeros_dirty = 0;
+    return qcx_shard_canon_zeros(r->amp, r->n, r->stream);
+}
 
 #include "qcx_fuse.inc.h"
 #include "qcx_sharded.inc.h"
@@ -745,7 +772,7 @@ static int reg_camodc_large(qcx_register *r, unsigned C, unsigned A, unsigned ct
     }
     CamodcParams P;
     memset(&P, 0, sizeof P);
-    P.M = M; P.logT = M; P.ctl = (int)ctl; P.C = C; P.ntiles = 0;
+    P.M = M; P.logT = M; P.ctl = (int)ctl; P.C = C; P.ntiles = 0; P.skip = 0; P.ntl = 0;
     const uint64_t blk = (uint64_t)1 << M;
     const unsigned grid = grid_for(r->dim, 256, 65536);
     if (camodc_closed_form(r->n, M, C, A, ctl)) {
@@ -1231,6 +1258,7 @@ extern "C" int qcx_reset_register(qcx_register *r)
     if (!r) return QCX_BAD_ARGUMENTS;
     if (r->sh) return sh_reset(r->sh);
     if (r->queue) r->queue->gates.clear();         // pending gates act on a state that is being overwritten
+    r->zeros_dirty = 0;
     if (r->fusion >= 0 && r->n >= 1) {             // lazily: the write happens at the next flush, fused with the circuit front (K0b)
         r->basis_pending = 1; r->basis_index = 1;
         return QCX_NO_ERROR;
@@ -1246,6 +1274,7 @@ extern "C" int qcx_hadamard_gate(unsigned q, qcx_register *r)
     if (r->sh) { SGate g; memset(&g, 0, sizeof g); g.type = FUSE_H; g.q = q; return sh_push(r->sh, g); }
     if (r->fusion > 0 || r->composite) { QGate g; memset(&g, 0, sizeof g); g.type = FUSE_H; g.q = q; return fuse_push(r, g); }
     FLUSH(r);                                         // (a lazily pending reset / collapse is written first)
+    QCX_TRY(canon_if_dirty(r));
     return qcx_shard_hadamard(r->amp, r->n, q, r->stream);
 }
 
@@ -1274,6 +1303,7 @@ extern "C" int qcx_c_phase_shift_gate(unsigned c, unsigned t, double theta, qcx_
         return fuse_push(r, g);
     }
     FLUSH(r);
+    QCX_TRY(canon_if_dirty(r));
     return qcx_shard_phase(r->amp, r->n, ((uint64_t)1 << c) | ((uint64_t)1 << t), er, ei, r->stream);
 }
 
@@ -1289,6 +1319,7 @@ extern "C" int qcx_c_amodc_gate(unsigned C, unsigned long long atox, unsigned c,
         return fuse_push(r, g);
     }
     FLUSH(r);
+    QCX_TRY(canon_if_dirty(r));
     return reg_camodc(r, C, (unsigned)(atox % C), c);
 }
 
@@ -1371,6 +1402,7 @@ extern "C" int qcx_measure_state_r(qcx_register *r, double rnd, unsigned long *s
     int found = 0; uint64_t idx = 0; double cum = 0.0;
     QCX_TRY(qcx_shard_measure_scan(r->amp, r->n, 0, r->dim - 1, 0.0, rnd, &found, &idx, &cum, r->stream));
     if (!found) idx = r->dim - 1;                                           // Q:283 fall-through
+    r->zeros_dirty = 0;                                                     // (the collapse replaces the whole state)
     if (r->fusion >= 0) { r->basis_pending = 1; r->basis_index = idx; }     // Q:302-303, written at the next flush (or never: a reset may follow)
     else QCX_TRY(qcx_shard_collapse(r->amp, r->n, (int64_t)idx, r->stream));
     *state_num = (unsigned long)idx;
@@ -1401,7 +1433,7 @@ extern "C" int qcx_state_write(qcx_register *r, unsigned long first, unsigned lo
     if (r->sh) return sh_copy(r->sh, first, count, const_cast<double *>(in), false);
     FLUSH(r);
     HIP_TRY(hipStreamSynchronize(r->stream));
-    if (count) HIP_TRY(hipMemcpy(r->amp + first, in, (size_t)count * sizeof(amp_t), hipMemcpyHostToDevice));
+    if (count) { HIP_TRY(hipMemcpy(r->amp + first, in, (size_t)count * sizeof(amp_t), hipMemcpyHostToDevice)); r->zeros_dirty = 1; }
     return QCX_NO_ERROR;
 }
 
@@ -1464,6 +1496,7 @@ extern "C" int qcx_state_load(qcx_register *r, const char *path)
 {
     if (!r || !path) return QCX_BAD_ARGUMENTS;
     if (r->sh) QCX_TRY(sh_identity(r->sh)); else { FLUSH(r); HIP_TRY(hipStreamSynchronize(r->stream)); }
+    r->zeros_dirty = 1;                              // (a sharded register: sh_copy notes it per set)
     FILE *f = fopen(path, "rb");
     if (!f) { set_error("qcx_state_load: cannot open %s", path); return QCX_BAD_ARGUMENTS; }
     StateFileHeader h;
@@ -1535,6 +1568,7 @@ extern "C" int qcx_state_fill_random(qcx_register *r, uint64_t seed)
     if (r->sh) return sh_fill_random(r->sh, seed);
     if (r->queue) r->queue->gates.clear();
     r->basis_pending = 0;                           // everything is overwritten
+    r->zeros_dirty = 0;
     // U(-0.5, 0.5) components have variance 1/12: this scale makes the expected norm 1
     return qcx_shard_fill_random(r->amp, r->n, 0, seed, sqrt(6.0 / (double)r->dim), r->stream);
 }

@@ -1006,6 +1006,7 @@ static int fuse_flush(qcx_register *r)
         if (used) { gq->gates.erase(gq->gates.begin(), gq->gates.begin() + used); gq->gates_fused += used; }
     }
     if (!gq || gq->gates.empty()) return QCX_NO_ERROR;
+    if (r->own_stream) QCX_TRY(canon_if_dirty(r));      // gates are about to run on a state the caller wrote (a shard view: its host's business)
     std::vector<QGate> gates;
     gates.swap(gq->gates);                       // the queue is empty from here on (re-entrancy safe)
     std::vector<FuseAction> acts;

@@ -238,6 +238,7 @@ struct CamodcParams {
     int      ctl;        // local bit index, or -1: control lives in the rank id and is 1
     unsigned C, d, Cd, inv;
     uint64_t ntiles;     // tiles to process (tiles hold control-set amplitudes only when ctl >= M)
+    unsigned skip, ntl;  // k_camodc: do not read the lines above row C; store completely rewritten lines nontemporally
 };
 
 // base of tile tt.  A tile is 2^logT amplitudes that all have the control bit SET: a control at or
@@ -270,6 +271,12 @@ __global__ __launch_bounds__(BLOCK) void k_camodc(amp_t *__restrict__ amp, Camod
     amp_t *tile = reinterpret_cast<amp_t *>(qcx_lds_raw);
     const unsigned T = 1u << P.logT, blkmask = (1u << P.M) - 1u;
     const bool squeeze = P.ctl >= (int)P.M && P.ctl < (int)P.logT;
+    // the permutation case (gcd(A, C) = 1): the source row of every destination row, tabulated once per workgroup -- one
+    // 32-bit modulo per residue instead of two divisions and a modulo per amplitude (round 4: 2.85 -> 2.4 ms at n = 30 together
+    // with the skipped lines)
+    unsigned short *lut = reinterpret_cast<unsigned short *>(tile + T);
+    const bool perm = !FULL && P.d == 1u && P.M <= 12u;
+    if (perm) for (unsigned f = threadIdx.x; f <= blkmask; f += BLOCK) lut[f] = (unsigned short)(f < P.C ? (f * P.inv) % P.C : f);
     for (uint64_t tt = blockIdx.x; tt < P.ntiles; tt += gridDim.x) {
         amp_t *g = camodc_tile(amp, P, tt);
         if constexpr (FULL) {
@@ -296,20 +303,28 @@ __global__ __launch_bounds__(BLOCK) void k_camodc(amp_t *__restrict__ amp, Camod
         // (fill through registers with the DEFAULT cache policy, measured at n = 30: 2.9 ms per gate; an LDS-DMA fill 3.0-3.2 ms;
         // nontemporal loads 4.1-4.5 ms -- the moved elements are rewritten as PARTIAL lines a moment later and those
         // writes must still find their lines in L2)
-        for (unsigned e = threadIdx.x; e < T; e += BLOCK) tile[e] = g[camodc_elem(squeeze, (unsigned)P.ctl, e)];
+        // Rows f >= C of a 2^M block are neither sources nor destinations (Q:631-634): the 128-B lines that hold nothing
+        // else are not even read (round 4; C = 21, M = 5: one line in four).  lineC = C rounded up to whole lines.
+        const unsigned lineC = P.skip ? ((P.C + 7u) & ~7u) : (1u << P.M);
+        for (unsigned e = threadIdx.x; e < T; e += BLOCK)
+            if ((e & blkmask) < lineC) tile[e] = g[camodc_elem(squeeze, (unsigned)P.ctl, e)];
         __syncthreads();
+        const unsigned fullC = P.ntl ? (P.C & ~7u) : 0u;                 // rows below this sit in lines that are rewritten completely
         for (unsigned e = threadIdx.x; e < T; e += BLOCK) {
             const unsigned f = e & blkmask;
             bool on = true;
             if (P.ctl >= 0 && P.ctl < (int)P.M) on = (e >> P.ctl) & 1u;
             if (!on || f >= P.C) continue;                     // identity rows (Q:611-613, Q:631-634)
             amp_t acc; acc.x = 0.0; acc.y = 0.0;
-            if (f % P.d == 0) {
+            if (perm) { const amp_t sv = tile[(e - f) + lut[f]]; acc.x += sv.x; acc.y += sv.y; }
+            else if (f % P.d == 0) {
                 unsigned src = ((f / P.d) * P.inv) % P.Cd;            // < C^2 <= 2^32: 32-bit arithmetic is exact (host checks)
                 const amp_t *blk = tile + (e - f);
                 for (unsigned t = 0; t < P.d; t++, src += P.Cd) { acc.x += blk[src].x; acc.y += blk[src].y; }
             }
-            g[camodc_elem(squeeze, (unsigned)P.ctl, e)] = acc;
+            // whole rewritten lines leave as nontemporal stores, the partly rewritten last line of a block through L2
+            if (f < fullC && P.ctl >= (int)P.M) __builtin_nontemporal_store(acc, g + camodc_elem(squeeze, (unsigned)P.ctl, e));
+            else g[camodc_elem(squeeze, (unsigned)P.ctl, e)] = acc;
         }
         __syncthreads();
     }
@@ -371,6 +386,23 @@ __global__ __launch_bounds__(256) void k_fill_random(amp_t *__restrict__ amp, ui
         v.x = ((double)(splitmix64(seed + k) >> 11) * 0x1p-53 - 0.5) * scale;
         v.y = ((double)(splitmix64(seed + k + 1) >> 11) * 0x1p-53 - 0.5) * scale;
         amp[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K0c  canonical zeros.  The reference's mat-vec rewrites EVERY amplitude at every gate as 0 + 1.0 * x (+ ...) (Q:393-413),
+// which turns a -0 component into +0 even where the gate is the identity.  The gate kernels only touch the amplitudes a
+// gate acts on, so they rely on an invariant instead: the state holds no -0 whenever a gate runs.  Reset, collapse, the
+// synthetic fill and every gate kernel keep it (each result ends in "+ 0.0"); a state WRITTEN by the caller
+// (qcx_state_write / qcx_state_load) may break it, and is passed through this kernel once before the next gate.
+// Reads everything, stores only the amplitudes that change.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_canon_zeros(amp_t *__restrict__ amp, uint64_t count)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256) {
+        amp_t v = __builtin_nontemporal_load(amp + i);
+        const bool neg0 = (uint64_t)__double_as_longlong(v.x) == 0x8000000000000000ULL || (uint64_t)__double_as_longlong(v.y) == 0x8000000000000000ULL;
+        if (neg0) { v.x += 0.0; v.y += 0.0; amp[i] = v; }
     }
 }
 
@@ -1297,31 +1329,38 @@ __device__ __forceinline__ void rotate_amp(amp_t &v, double cc, double ss)
 //    their bits.  Same values, bit for bit, as rotate_amp per gate.
 enum : uint32_t { FUSE_PRUN = 4 };
 
-#define QCX_LOADREC(M, C, S)                                         \
+// one record = one s_load_dwordx8 into a fixed block of scalar registers (A: s[72:79], B: s[80:87]; listed as clobbers):
+// dword 1 = tile-local mask, dwords 4-5 = cos, 6-7 = sin.  (Three separate loads of m, c, s cost two more instructions of the
+// scalar port per gate, and this walk is bound by that port as much as by the vector one: DESIGN.md s4.)
+#define QCX_RECA_M "s73"
+#define QCX_RECA_C "s[76:77]"
+#define QCX_RECA_S "s[78:79]"
+#define QCX_RECB_M "s81"
+#define QCX_RECB_C "s[84:85]"
+#define QCX_RECB_S "s[86:87]"
+#define QCX_LOADREC(BLK)                                             \
     "s_ff1_i32_b64 %[b], %[live]\n\t"                                \
     "s_bitset0_b64 %[live], %[b]\n\t"                                \
     "s_lshl_b32 %[b], %[b], 5\n\t"                                   \
-    "s_load_dword %[" M "], %[base], %[b] offset:0x24\n\t"           \
-    "s_load_dwordx2 %[" C "], %[base], %[b] offset:0x30\n\t"         \
-    "s_load_dwordx2 %[" S "], %[base], %[b] offset:0x38\n\t"
+    "s_load_dwordx8 " BLK ", %[base], %[b] offset:0x20\n\t"
 #define QCX_ROT1(C, S, X, Y)                                         \
-    "v_mul_f64 %[t0], %[" C "], %[" X "]\n\t"                        \
-    "v_mul_f64 %[t1], %[" S "], %[" Y "]\n\t"                        \
-    "v_mul_f64 %[t2], %[" C "], %[" Y "]\n\t"                        \
-    "v_mul_f64 %[t3], %[" S "], %[" X "]\n\t"                        \
+    "v_mul_f64 %[t0], " C ", %[" X "]\n\t"                          \
+    "v_mul_f64 %[t1], " S ", %[" Y "]\n\t"                          \
+    "v_mul_f64 %[t2], " C ", %[" Y "]\n\t"                          \
+    "v_mul_f64 %[t3], " S ", %[" X "]\n\t"                          \
     "v_add_f64 %[" X "], %[t0], -%[t1]\n\t"                          \
     "v_add_f64 %[" Y "], %[t2], %[t3]\n\t"
 #define QCX_ROT2(C, S, X0, Y0, X1, Y1)                               \
-    "v_mul_f64 %[t0], %[" C "], %[" X0 "]\n\t"                       \
-    "v_mul_f64 %[t1], %[" S "], %[" Y0 "]\n\t"                       \
-    "v_mul_f64 %[t2], %[" C "], %[" Y0 "]\n\t"                       \
-    "v_mul_f64 %[t3], %[" S "], %[" X0 "]\n\t"                       \
+    "v_mul_f64 %[t0], " C ", %[" X0 "]\n\t"                         \
+    "v_mul_f64 %[t1], " S ", %[" Y0 "]\n\t"                         \
+    "v_mul_f64 %[t2], " C ", %[" Y0 "]\n\t"                         \
+    "v_mul_f64 %[t3], " S ", %[" X0 "]\n\t"                         \
     "v_add_f64 %[" X0 "], %[t0], -%[t1]\n\t"                         \
-    "v_mul_f64 %[t0], %[" C "], %[" X1 "]\n\t"                       \
-    "v_mul_f64 %[t1], %[" S "], %[" Y1 "]\n\t"                       \
+    "v_mul_f64 %[t0], " C ", %[" X1 "]\n\t"                         \
+    "v_mul_f64 %[t1], " S ", %[" Y1 "]\n\t"                         \
     "v_add_f64 %[" Y0 "], %[t2], %[t3]\n\t"                          \
-    "v_mul_f64 %[t2], %[" C "], %[" Y1 "]\n\t"                       \
-    "v_mul_f64 %[t3], %[" S "], %[" X1 "]\n\t"                       \
+    "v_mul_f64 %[t2], " C ", %[" Y1 "]\n\t"                         \
+    "v_mul_f64 %[t3], " S ", %[" X1 "]\n\t"                         \
     "v_add_f64 %[" X1 "], %[t0], -%[t1]\n\t"                         \
     "v_add_f64 %[" Y1 "], %[t2], %[t3]\n\t"
 #define QCX_R1(C, S, i) QCX_ROT1(C, S, "x" #i, "y" #i)
@@ -1362,18 +1401,16 @@ enum : uint32_t { FUSE_PRUN = 4 };
 // case, a phase whose target lies outside the tile) skips the two vector instructions of the lane mask and the EXEC
 // round trip: the pass is bound by vector issue, the scalar compare + branch ride the other port.
 #define QCX_GATE(M, ROTS)                                            \
-    "s_cmp_eq_u32 %[" M "], 0\n\t"                                   \
+    "s_cmp_eq_u32 " M ", 0\n\t"                                      \
     "s_cbranch_scc1 6f\n\t"                                         \
-    "v_and_b32 %[t], %[" M "], %[p]\n\t"                             \
-    "v_cmpx_eq_u32_e32 vcc, %[" M "], %[t]\n\t"                      \
-    "s_or_b64 %[tch], %[tch], exec\n\t"                              \
+    "v_and_b32 %[t], " M ", %[p]\n\t"                                \
+    "v_cmpx_eq_u32_e32 vcc, " M ", %[t]\n\t"                         \
     "s_cbranch_execz 1f\n\t"                                        \
     ROTS                                                             \
     "1:\n\t"                                                        \
     "s_mov_b64 exec, %[ex]\n\t"                                     \
     "s_branch 7f\n\t"                                               \
     "6:\n\t"                                                        \
-    "s_or_b64 %[tch], %[tch], exec\n\t"                              \
     ROTS                                                             \
     "7:\n\t"
 // H on one of the round's two register bits, in place and without the final "+ 0.0" (the round canonicalises once at
@@ -1388,32 +1425,32 @@ enum : uint32_t { FUSE_PRUN = 4 };
     "v_add_f64 %[" BX "], %[t0], -%[t2]\n\t"                         \
     "v_add_f64 %[" BY "], %[t1], -%[t3]\n\t"
 // all live gates of one run for register selection R (live != 0 on entry, 0 on exit); records ping-pong between
-// sets A and B; then the canonical zeros for the rotated lanes if bit 4 of rsel asks for them
+// blocks A and B; then the canonical zeros if bit 4 of rsel asks for them -- on ALL lanes of the run's registers: a gate
+// kernel never meets a -0 it has not made itself (the state is canonical whenever gates run: a state written by the caller
+// is canonicalised first, qcx_api.hip), so "+ 0.0" on an amplitude no gate of the run rotated changes nothing
 #define QCX_RUN_BODY(R)                                              \
-    QCX_LOADREC("mA", "cA", "sA")                                    \
+    QCX_LOADREC("s[72:79]")                                          \
     "2:\n\t"                                                         \
     "s_waitcnt lgkmcnt(0)\n\t"                                       \
     "s_cmp_eq_u64 %[live], 0\n\t"                                    \
     "s_cbranch_scc1 3f\n\t"                                          \
-    QCX_LOADREC("mB", "cB", "sB")                                    \
-    QCX_GATE("mA", QCX_ROTS_##R("cA", "sA"))                         \
+    QCX_LOADREC("s[80:87]")                                          \
+    QCX_GATE(QCX_RECA_M, QCX_ROTS_##R(QCX_RECA_C, QCX_RECA_S))       \
     "s_waitcnt lgkmcnt(0)\n\t"                                       \
     "s_cmp_eq_u64 %[live], 0\n\t"                                    \
     "s_cbranch_scc1 4f\n\t"                                          \
-    QCX_LOADREC("mA", "cA", "sA")                                    \
-    QCX_GATE("mB", QCX_ROTS_##R("cB", "sB"))                         \
+    QCX_LOADREC("s[72:79]")                                          \
+    QCX_GATE(QCX_RECB_M, QCX_ROTS_##R(QCX_RECB_C, QCX_RECB_S))       \
     "s_branch 2b\n\t"                                                \
     "3:\n\t"                                                         \
-    QCX_GATE("mA", QCX_ROTS_##R("cA", "sA"))                         \
+    QCX_GATE(QCX_RECA_M, QCX_ROTS_##R(QCX_RECA_C, QCX_RECA_S))       \
     "s_branch 5f\n\t"                                                \
     "4:\n\t"                                                         \
-    QCX_GATE("mB", QCX_ROTS_##R("cB", "sB"))                         \
+    QCX_GATE(QCX_RECB_M, QCX_ROTS_##R(QCX_RECB_C, QCX_RECB_S))       \
     "5:\n\t"                                                         \
     "s_bitcmp1_b32 %[rsel], 12\n\t"                                  \
     "s_cbranch_scc0 99f\n\t"                                         \
-    "s_mov_b64 exec, %[tch]\n\t"                                     \
     QCX_ZERO_##R                                                     \
-    "s_mov_b64 exec, %[ex]\n\t"                                      \
     "s_branch 99f\n\t"
 // ONE asm statement for every register selection (entry 20 + R, binary dispatch on rsel & 15): with one statement
 // per selection behind a C++ switch the compiler copied all four amplitudes into fresh VGPRs at every run
@@ -1428,7 +1465,6 @@ enum : uint32_t { FUSE_PRUN = 4 };
     "s_bitcmp1_b32 %[rsel], 13\n\t"                                  \
     "s_cbranch_scc1 50f\n\t"                                         \
     "s_mov_b64 %[ex], exec\n\t"                                      \
-    "s_mov_b64 %[tch], 0\n\t"                                        \
     "s_cmp_eq_u64 %[live], 0\n\t"                                    \
     "s_cbranch_scc1 99f\n\t"                                         \
     "s_bfe_u32 %[b], %[rsel], 0x40008\n\t"                           \
@@ -1475,16 +1511,16 @@ struct Quad { double x0, y0, x1, y1, x2, y2, x3, y3; };
 __device__ __forceinline__ void fuse_round_item(Quad &q, const FuseOp *item, uint64_t live, unsigned p, uint32_t hdr,
                                                 uint32_t &xaddr, uint32_t &hdr_next, uint64_t &mask_next)
 {
-    uint64_t ex, tch; uint32_t bidx, mA, mB, tv; double cA, sA, cB, sB;
+    uint64_t ex; uint32_t bidx, tv;
     double t0, t1, t2, t3;
     const double hs = QCX_SQRT1_2;
     asm(QCX_ITEM_ALL
-        : [live] "+s"(live), [tch] "=&s"(tch), [ex] "=&s"(ex), [b] "=&s"(bidx), [mA] "=&s"(mA), [cA] "=&s"(cA), [sA] "=&s"(sA),
-          [mB] "=&s"(mB), [cB] "=&s"(cB), [sB] "=&s"(sB), [t] "=&v"(tv),
+        : [live] "+s"(live), [ex] "=&s"(ex), [b] "=&s"(bidx), [t] "=&v"(tv),
           [x0] "+v"(q.x0), [y0] "+v"(q.y0), [x1] "+v"(q.x1), [y1] "+v"(q.y1), [x2] "+v"(q.x2), [y2] "+v"(q.y2), [x3] "+v"(q.x3), [y3] "+v"(q.y3),
           [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),
           [tn] "=&s"(hdr_next), [mn] "=&v"(mask_next), [xa] "+v"(xaddr)
-        : [base] "s"(item), [p] "v"(p), [rsel] "s"(hdr), [hs] "s"(hs) : "vcc", "scc");
+        : [base] "s"(item), [p] "v"(p), [rsel] "s"(hdr), [hs] "s"(hs)
+        : "vcc", "scc", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87");
 }
 
 

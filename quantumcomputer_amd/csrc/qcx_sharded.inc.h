@@ -68,6 +68,9 @@ struct ShardSet {
     unsigned long fronts = 0;
     bool     in_selfcheck = false;                // this set IS the small register of a self-check (no nested checks)
     unsigned long selfchecks = 0;                 // pre-flight checks this register has passed (qcx_sharded_selfchecks)
+    bool     staged = false;                      // no peer access between some of the devices (or QCX_SHARD_FORCE_STAGED=1): a trade packs into the
+                                                  // shard's OWN spare buffer and the chunks travel by hipMemcpyPeerAsync (no peer stores, no relays)
+    bool     zeros_dirty = false;                 // the caller wrote amplitudes: one k_canon_zeros pass per shard before the next gate (Q:393-413)
     int      fusion = 1;                          // 1: each shard's gate list goes through the fused-pass scheduler; -1/0: one launch per gate
     size_t   max_queue = 8192;
     std::string trace;
@@ -190,6 +193,7 @@ static int sh_create(int L, int M, unsigned nshards, const int *devices, ShardSe
     // exchange windows pay when a trade crosses xGMI (tens of ms at n_local = 30); with every shard on ONE device a trade
     // is a local pass as fast as a gate and the windows only fragment the gate lists (measured at n = 30, 8 shards on one
     // GPU: fused sweep 31.8 -> 39.6 ms, Shor circuit 86 -> 97 ms).  QCX_SHARD_OVERLAP=0|1 overrides.
+    if (const char *e = getenv("QCX_SHARD_FORCE_STAGED")) sh->staged = atoi(e) != 0;
     sh->overlap = false;
     for (unsigned r = 1; r < nshards; r++) sh->overlap |= sh->dev[r] != sh->dev[0];
     if (const char *e = getenv("QCX_SHARD_OVERLAP")) sh->overlap = atoi(e) != 0;
@@ -207,9 +211,9 @@ static int sh_create(int L, int M, unsigned nshards, const int *devices, ShardSe
             if (sh->dev[c] == sh->dev[r]) continue;
             int can = 0;
             (void)hipDeviceCanAccessPeer(&can, sh->dev[r], sh->dev[c]);
-            if (!can) { set_error("no peer access between devices %d and %d", sh->dev[r], sh->dev[c]); status = QCX_HIP_ERROR; break; }
+            if (!can) { sh->staged = true; continue; }               // no peer stores between these two: the staged exchange (sh_exchange)
             const hipError_t pe = hipDeviceEnablePeerAccess(sh->dev[c], 0);
-            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) e = pe;
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) sh->staged = true;
             (void)hipGetLastError();
         }
         if (status != QCX_NO_ERROR) break;
@@ -404,10 +408,14 @@ static int sh_exchange(ShardSet *sh, const SwapList &swaps, const std::vector<PO
         if (!post.empty()) sh_trace_ops(sh, post);
     } else {
         const unsigned W = sh->W;
-        const unsigned R = (sh->zone_lo >= 8) ? (unsigned)sh->relay_dev.size() : 0u;
+        const bool staged = sh->staged;
+        const unsigned R = (sh->zone_lo >= 8 && !staged) ? (unsigned)sh->relay_dev.size() : 0u;
         const unsigned S = 1u << sh->sigma;                 // (relays are only set up with sigma = 0: sh_set_relays)
         const unsigned vbits = sh->slice_bits;              // bits of one view (a slice, or the whole shard when sigma = 0)
         const unsigned zlo = sh->zone_lo;                   // its trade zone = its top k bits
+        // the buffer a slice arrives in: the OTHER buffer of its new owner (peer stores), or -- staged -- the current one again:
+        // every shard packs into its own spare buffer first, then the chunks are copied over the data that has been packed
+        const int land = staged ? sh->cur : (sh->cur ^ 1);
         // (1) every shard's earlier work is done before anyone writes into its spare buffer
         for (unsigned r = 0; r < W; r++) { SH_DEV(sh, r); HIP_TRY(hipEventRecord(sh->ev_a[r], sh->st[r])); }
         for (unsigned r = 0; r < W; r++) {
@@ -428,7 +436,7 @@ static int sh_exchange(ShardSet *sh, const SwapList &swaps, const std::vector<PO
                 SH_DEV(sh, r);
                 for (unsigned c = 0; c < W; c++) HIP_TRY(hipStreamWaitEvent(sh->st[r], sh->ev_push[8 * c + sidx], 0));
                 for (unsigned i = 0; i < R; i++) HIP_TRY(hipStreamWaitEvent(sh->st[r], sh->relay_ev[i], 0));
-                if (!post.empty()) QCX_TRY(sh_run_view(sh, post, r, sh->buf[sh->cur ^ 1][r] + ((uint64_t)sidx << vbits), vbits, sidx));
+                if (!post.empty()) QCX_TRY(sh_run_view(sh, post, r, sh->buf[land][r] + ((uint64_t)sidx << vbits), vbits, sidx));
             }
             return QCX_NO_ERROR;
         };
@@ -442,14 +450,40 @@ static int sh_exchange(ShardSet *sh, const SwapList &swaps, const std::vector<PO
                 if (!pre.empty()) QCX_TRY(sh_run_view(sh, pre, r, src, vbits, sidx));
                 HIP_TRY(hipEventRecord(sh->ev_pre[8 * r + sidx], sh->st[r]));
                 HIP_TRY(hipStreamWaitEvent(sh->xs[r], sh->ev_pre[8 * r + sidx], 0));
+                PushDst Dr = D;
+                if (staged) {
+                    // pack only: chunk c of this shard's slice lands in its OWN spare buffer at [c << zlo, (c + 1) << zlo)
+                    // (k_pack_push stores chunk c at dst[c] + (me << zlo) + low)
+                    amp_t *spare = sh->buf[sh->cur ^ 1][r] + ((uint64_t)sidx << vbits);
+                    for (unsigned c = 0; c < W; c++) Dr.dst[c] = spare + ((uint64_t)c << zlo) - ((uint64_t)r << zlo);
+                }
                 if (zlo >= 8)
                     hipLaunchKernelGGL((k_pack_push<256, true>), dim3(grid_for(count, 256, 0, 256)), dim3(256), 0, sh->xs[r],
-                                       (const amp_t *)src, D, Rl, count, Sb, zlo, sh->k, r);
+                                       (const amp_t *)src, Dr, Rl, count, Sb, zlo, sh->k, r);
                 else
                     hipLaunchKernelGGL((k_pack_push<64, false>), dim3(grid_for(count, 64, 0, 64)), dim3(64), 0, sh->xs[r],
-                                       (const amp_t *)src, D, Rl, count, Sb, zlo, sh->k, r);
+                                       (const amp_t *)src, Dr, Rl, count, Sb, zlo, sh->k, r);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipEventRecord(sh->ev_push[8 * r + sidx], sh->xs[r]));
+            }
+            if (staged) {
+                // (1a) every shard has packed this slice (its current buffer is free to be overwritten): the chunks travel as
+                // copies, shard r's chunk c -> slot r of shard c's slice; the arrival event replaces the pack event
+                for (unsigned r = 0; r < W; r++) {
+                    SH_DEV(sh, r);
+                    for (unsigned c = 0; c < W; c++) HIP_TRY(hipStreamWaitEvent(sh->xs[r], sh->ev_push[8 * c + sidx], 0));
+                }
+                for (unsigned r = 0; r < W; r++) {
+                    SH_DEV(sh, r);
+                    const amp_t *spare = sh->buf[sh->cur ^ 1][r] + ((uint64_t)sidx << vbits);
+                    for (unsigned c = 0; c < W; c++) {
+                        amp_t *to = sh->buf[sh->cur][c] + ((uint64_t)sidx << vbits) + ((uint64_t)r << zlo);
+                        const size_t bytes = ((size_t)1 << zlo) * sizeof(amp_t);
+                        if (sh->dev[c] == sh->dev[r]) HIP_TRY(hipMemcpyAsync(to, spare + ((uint64_t)c << zlo), bytes, hipMemcpyDeviceToDevice, sh->xs[r]));
+                        else HIP_TRY(hipMemcpyPeerAsync(to, sh->dev[c], spare + ((uint64_t)c << zlo), sh->dev[r], bytes, sh->xs[r]));
+                    }
+                }
+                for (unsigned r = 0; r < W; r++) { SH_DEV(sh, r); HIP_TRY(hipEventRecord(sh->ev_push[8 * r + sidx], sh->xs[r])); }
             }
             // (1b) the relays forward their staged stripes to the owners once every shard has pushed (unsliced only)
             if (R) {
@@ -474,7 +508,7 @@ static int sh_exchange(ShardSet *sh, const SwapList &swaps, const std::vector<PO
             if (sidx >= 1) QCX_TRY(post_on(sidx - 1));       // ... while slice sidx is in flight
         }
         QCX_TRY(post_on(S - 1));
-        sh->cur ^= 1;
+        if (!staged) sh->cur ^= 1;
     }
     sh_book(sh, swaps, true);
     sh->exchanges++;
@@ -564,6 +598,10 @@ static int sh_flush(ShardSet *sh)
 {
     if (sh->basis_pending) QCX_TRY(sh_materialize_basis(sh));
     if (sh->queue.empty()) return QCX_NO_ERROR;
+    if (sh->zeros_dirty) {
+        sh->zeros_dirty = false;
+        if (!sh->dry) for (unsigned r = 0; r < sh->W; r++) { SH_DEV(sh, r); QCX_TRY(qcx_shard_canon_zeros(sh->buf[sh->cur][r], sh->n_local, sh->st[r])); }
+    }
     std::vector<SGate> q;
     q.swap(sh->queue);
     const bool windows = sh->overlap && sh->sigma > 0 && sh->relay_dev.empty();
@@ -733,6 +771,7 @@ static int sh_set_relays(ShardSet *sh, unsigned nrelays, const int *devices)
 static int sh_reset(ShardSet *sh)
 {
     sh->queue.clear();                              // pending gates act on a state that is being overwritten
+    sh->zeros_dirty = false;
     sh_identity_perm(sh);
     if (sh->dry) { sh->trace += "reset\n"; return QCX_NO_ERROR; }
     if (sh->fusion > 0) { sh->basis_pending = true; return QCX_NO_ERROR; }      // lazily: see sh_materialize_basis
@@ -745,6 +784,7 @@ static int sh_fill_random(ShardSet *sh, uint64_t seed)
 {
     sh->queue.clear();
     sh->basis_pending = false;
+    sh->zeros_dirty = false;
     sh_identity_perm(sh);
     if (sh->dry) return QCX_UNSUPPORTED;
     const double scale = sqrt(6.0 / (double)((uint64_t)1 << sh->n));
@@ -811,7 +851,7 @@ static int sh_copy(ShardSet *sh, uint64_t first, uint64_t count, double *host, b
         amp_t *d = sh->buf[sh->cur][r] + off;
         double *h = host + 2 * (at - first);
         if (to_host) HIP_TRY(hipMemcpy(h, d, (size_t)cnt * sizeof(amp_t), hipMemcpyDeviceToHost));
-        else HIP_TRY(hipMemcpy(d, h, (size_t)cnt * sizeof(amp_t), hipMemcpyHostToDevice));
+        else { HIP_TRY(hipMemcpy(d, h, (size_t)cnt * sizeof(amp_t), hipMemcpyHostToDevice)); sh->zeros_dirty = true; }
         at += cnt; left -= cnt;
     }
     return QCX_NO_ERROR;

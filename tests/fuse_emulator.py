@@ -235,7 +235,10 @@ def apply_pass(state, n, act, recs):
                             _rotate(re, im, sel, gr.c, gr.s, False)
                             touched |= sel
                         if canon:
-                            re[touched] += 0.0; im[touched] += 0.0
+                            # on ALL amplitudes held in the run's registers (round 4: the state is canonical whenever gates
+                            # run, so "+ 0.0" changes nothing where no gate of the run rotated)
+                            whole = ((rsel >> qreg) & 1) == 1
+                            re[whole] += 0.0; im[whole] += 0.0
                         stats["runs"] += 1; stats["run_gates"] += rc
                         o += 1 + rc
                     elif kind == FUSE_DIAG and nd:

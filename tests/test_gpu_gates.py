@@ -202,3 +202,24 @@ def test_bad_arguments(qc):
             qc.c_amodc_gate(15, 7, 9, reg)
     with pytest.raises(QcxError):
         qc.Register(40, 40)
+
+
+@pytest.mark.parametrize("skip,ntl", [(0, 0), (1, 0), (1, 1), (0, 1)])
+def test_camodc_store_and_fill_variants(qc, ob, skip, ntl):
+    """k_camodc with and without reading the lines above row C, with default and nontemporal stores of the completely
+    rewritten lines: the same bits (C just above / below line boundaries, non-coprime multipliers, controls inside and
+    above the tile)"""
+    old = {k: qc.lib().qcx_tune_get(k.encode()) for k in ("cam_skip", "cam_nt_lines")}
+    qc.tune(cam_skip=skip, cam_nt_lines=ntl)
+    try:
+        for (L, M, C, atox, ctl) in [(11, 5, 21, 2, 9), (11, 5, 24, 5, 15), (10, 6, 33, 7, 6), (9, 5, 7, 3, 13), (12, 4, 15, 10, 5),
+                                     (8, 7, 100, 30, 14), (14, 5, 32, 3, 18), (14, 5, 17, 4, 12)]:
+            n = L + M
+            a = ob.random_state(n, 600 + ctl)
+            want = a.copy(); ob.camodc(want, n, M, C, atox, ctl)
+            with qc.Register(L, M) as reg:
+                reg.write(a); reg.set_fusion(-1)
+                qc.c_amodc_gate(C, atox, ctl, reg)
+                assert_bits_equal(reg.read(), want, f"C_AMODC skip={skip} ntl={ntl} L={L} M={M} C={C} atox={atox} ctl={ctl}")
+    finally:
+        qc.tune(**old)

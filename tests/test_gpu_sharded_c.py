@@ -296,3 +296,41 @@ def test_tolerance_mode_on_a_sharded_register(qc, ob, shards, L, M):
                     out.append(qc.measure_state(reg, r))
                 picks.append(out)
             assert picks[0] == picks[1]
+
+
+@pytest.mark.parametrize("shards,n,M,slices,overlap", [(2, 12, 0, 0, 0), (4, 16, 4, 2, 1), (8, 18, 5, 3, 1), (4, 14, 0, 0, 0)])
+def test_staged_exchange_without_peer_access(qc, ob, monkeypatch, shards, n, M, slices, overlap):
+    """no peer access between two devices (forced here: QCX_SHARD_FORCE_STAGED=1): a trade packs every shard into its OWN
+    spare buffer and the chunks travel as hipMemcpyPeerAsync copies instead of peer stores -- creation no longer fails, the
+    bits are the same, with and without sliced exchange windows, and the pre-flight self-check runs through the same path"""
+    monkeypatch.setenv("QCX_SHARD_FORCE_STAGED", "1")
+    monkeypatch.setenv("QCX_SHARD_SLICES_LOG2", str(slices))
+    monkeypatch.setenv("QCX_SHARD_OVERLAP", str(overlap))
+    monkeypatch.setenv("QCX_SHARD_SELFCHECK", "1")
+    rnd = random.Random(shards * 100 + n)
+    Cn = 21 if M >= 5 else 15
+    with qc.Register(n - M, M, shards=shards, devices=qc.spread_devices(shards)) as reg:
+        assert reg.selfchecks == 1
+        for trial in range(3):
+            reg.set_fusion(1 if trial != 1 else -1)
+            reg.fill_random(60 + trial)
+            want = ob.fill_random(n, 60 + trial)
+            for _ in range(100):
+                t = rnd.random()
+                if t < 0.45:
+                    q = rnd.choice([n - 1, n - 2, rnd.randrange(n), rnd.randrange(M, n)])
+                    qc.hadamard_gate(q, reg); ob.hadamard(want, n, q)
+                elif t < 0.85 or M == 0:
+                    c, tq = rnd.sample(range(n), 2)
+                    th = rnd.uniform(-3.0, 3.0)
+                    qc.c_phase_shift_gate(c, tq, th, reg); ob.cphase(want, n, c, tq, th)
+                else:
+                    A, ctl = rnd.randrange(1, 99), rnd.randrange(M, n)
+                    qc.c_amodc_gate(Cn, A, ctl, reg); ob.camodc(want, n, M, Cn, A, ctl)
+            assert np.array_equal(bits(reg.read()), bits(want)), (shards, n, trial)
+        ex, _ = reg.sharded_stats()
+        assert ex >= 3
+        if M:
+            qc.reset_register(reg); qc.quantum_computation(Cn, 2 if Cn == 21 else 7, reg)
+            w2 = np.zeros(2 << n); ob.reset(w2, n); ob.quantum_computation(w2, n, M, Cn, 2 if Cn == 21 else 7)
+            assert qc.measure_state(reg, 0.61) == ob.measure(w2, n, 0.61)

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""profiles/<tag>_hbm_traffic.json from the two rocprofv3 counter passes of bench.py (--pmc FETCH_SIZE, --pmc WRITE_SIZE, each
+with --kernel-trace): HBM bytes per launch of the headline kernel at n = 30 and of the other kernels of the run, next to
+their algorithmic bytes.  FETCH_SIZE is doubled (MI355X_MICROARCH.md: on gfx950 it counts half the bytes of 16 B/lane
+coalesced streams) and the doubling is checked in the same run on two kernels of known traffic: k_norm_partial reads
+16 * 2^n bytes, k_fill_random writes 16 * 2^n.
+usage: make_traffic.py <dir of the fetch pass> <dir of the write pass> <tag>"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def rows(d, counter):
+    out = defaultdict(list)          # (kernel short name, grid threads) -> values
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            name = r["Kernel_Name"]
+            short = name[name.find("k_"):].split("(")[0] if "k_" in name else name.split("(")[0][-50:]
+            grid = int(r.get("Grid_Size", 0) or 0)
+            out[(short, grid)].append(float(r["Counter_Value"]))
+    return out
+
+
+def main():
+    dfetch, dwrite, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    F, W = rows(dfetch, "FETCH_SIZE"), rows(dwrite, "WRITE_SIZE")
+    mean = lambda v: sum(v) / len(v) if v else None
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline` "
+                     "(tools/prof_r04.sh), summarised by tools/make_traffic.py; KiB units; FETCH_SIZE doubled per the guide's gfx950 correction",
+           "kernels": []}
+    keys = sorted(set(F) | set(W), key=lambda k: -(len(F.get(k, [])) + len(W.get(k, []))))
+    for k in keys:
+        f, w = mean(F.get(k, [])), mean(W.get(k, []))
+        row = {"kernel": k[0], "grid_threads": k[1], "launches": max(len(F.get(k, [])), len(W.get(k, []))),
+               "FETCH_SIZE_KiB_raw_mean": f, "WRITE_SIZE_KiB_mean": w,
+               "hbm_bytes_per_launch": ((2.0 * f if f else 0.0) + (w or 0.0)) * 1024.0}
+        out["kernels"].append(row)
+        if k[0].startswith("k_h_pair") and k[1] == (1 << 29):          # one thread per pair: n = 30
+            alg = 32.0 * 2.0 ** 30
+            out["k_h_pair_launches_n30"] = row["launches"]
+            out["k_h_pair_bytes_per_launch_n30"] = row["hbm_bytes_per_launch"]
+            out["algorithmic_bytes_per_launch"] = alg
+            out["ratio"] = row["hbm_bytes_per_launch"] / alg
+    # calibration of the FETCH_SIZE doubling in the same run
+    for k in keys:
+        if k[0].startswith("k_norm_partial") and F.get(k):
+            out.setdefault("calibration", {})["k_norm_partial FETCH_SIZE_KiB_raw (reads 16 * 2^n B)"] = mean(F[k])
+        if k[0].startswith("k_fill_random") and W.get(k) and k[1] >= (1 << 26):
+            out.setdefault("calibration", {})[f"k_fill_random grid {k[1]} WRITE_SIZE_KiB (writes 16 * 2^n B)"] = mean(W[k])
+    os.makedirs("profiles", exist_ok=True)
+    json.dump(out, open(os.path.join("profiles", f"{tag}_hbm_traffic.json"), "w"), indent=1)
+    print(json.dumps({k: v for k, v in out.items() if k != "kernels"}, indent=1))
+    for r in out["kernels"][:30]:
+        print(r)
+
+
+if __name__ == "__main__":
+    main()

@@ -44,7 +44,7 @@ def main():
                 ms = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
                 dur[short(r["Kernel_Name"])].append(ms)
                 rows.append((int(r["Start_Timestamp"]), short(r["Kernel_Name"]), ms, r.get("VGPR_Count"), r.get("SGPR_Count"),
-                             r.get("LDS_Block_Size"), r.get("Grid_Size"), r.get("Workgroup_Size")))
+                             r.get("LDS_Block_Size"), r.get("Grid_Size") or r.get("Grid_Size_X"), r.get("Workgroup_Size") or r.get("Workgroup_Size_X")))
         tot = sum(sum(v) for v in dur.values())
         out["kernel_stats"] = {k: dict(calls=len(v), total_ms=round(sum(v), 3), avg_ms=round(sum(v) / len(v), 4),
                                        min_ms=round(min(v), 4), max_ms=round(max(v), 4), pct=round(100 * sum(v) / tot, 2))

@@ -445,6 +445,14 @@ static bool launch_rounds_kernel(int occ, int tol_occ, unsigned grid, size_t lds
 {
     if constexpr ((1u << TT) == 4u * B) {
         const bool cam = P.has_cam != 0;
+        if (P.gen) {          // the tiles are generated (circuit front on an unwritten basis state): passes without multiplies only
+#define QCX_GEN_LAUNCH(O, S) hipLaunchKernelGGL((k_fused_rounds<B, TT, O, false, S, true>), dim3(grid), dim3(B), lds, st, amp, amp_out, n, P, d_ops, ntiles, d_ops)
+            if (P.dg_cnt) { if (P.dg_slim) { if (tol_occ >= 8) QCX_GEN_LAUNCH(8, 2); else QCX_GEN_LAUNCH(6, 2); } else QCX_GEN_LAUNCH(6, 1); }
+            else if (occ >= 8) QCX_GEN_LAUNCH(8, 0);
+            else QCX_GEN_LAUNCH(6, 0);
+#undef QCX_GEN_LAUNCH
+            return true;
+        }
         if (P.dg_cnt) {       // tolerance mode: the pass holds merged diagonals (K6t); 2 = every round is a fast round (slim kernel)
 #define QCX_TOL_LAUNCH(O, C, S) hipLaunchKernelGGL((k_fused_rounds<B, TT, O, C, S>), dim3(grid), dim3(B), lds, st, amp, amp_out, n, P, d_ops, ntiles, d_ops)
             if (P.dg_slim) {
@@ -490,6 +498,11 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
         P.dg_lds_off = (uint32_t)((lut_bytes + 15) & ~(size_t)15);
         lut_bytes = P.dg_lds_off + 16 * (size_t)P.dg_cnt * 49;
     }
+    P.gen_lds_off = 0;
+    if (P.gen) {                                                                   // + the generated fill's slot tables (2 x 1024 entries of 2 B; 2 x 512 for the radix-8 kernel, whose two workgroups per CU have no room for more)
+        P.gen_lds_off = (uint32_t)((lut_bytes + 15) & ~(size_t)15);
+        lut_bytes = P.gen_lds_off + 2 * (P.dg_slim == 2 ? 512 : 1024) * sizeof(unsigned short);
+    }
     const size_t lds = ((size_t)16 << P.T) + lut_bytes;
     // 4 amplitudes per thread (all loads of a tile in flight at once, few registers): block = 2^T / 4
 #define QCX_FUSE_LAUNCH(B, TTv) do { \
@@ -502,7 +515,11 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
         // (a few workgroups per CU that walk the tiles: 2048 workgroups 6.3 ms, 24576 7.0 ms, one per tile 8.3 ms at n = 28)
         // (the Hadamard-only exact form likes more of them: n = 30 sweep 23.5 ms with 8192, 23.9 with 3072)
         const unsigned grid3 = grid_for(ntiles, 1, P.dg_cnt ? tn.fuse_q3_cap : tn.fuse_q3_cap_exact);
-        if (P.dg_cnt) hipLaunchKernelGGL((k_fused_q3<512, 12, 4, false>), dim3(grid3), dim3(512), lds, r->stream, amp_in, amp_out, n, P, d_ops, ntiles);
+        if (P.gen) {
+            if (P.dg_cnt) hipLaunchKernelGGL((k_fused_q3<512, 12, 4, false, true>), dim3(grid3), dim3(512), lds, r->stream, amp_in, amp_out, n, P, d_ops, ntiles);
+            else hipLaunchKernelGGL((k_fused_q3<512, 12, 4, true, true>), dim3(grid3), dim3(512), lds, r->stream, amp_in, amp_out, n, P, d_ops, ntiles);
+        }
+        else if (P.dg_cnt) hipLaunchKernelGGL((k_fused_q3<512, 12, 4, false>), dim3(grid3), dim3(512), lds, r->stream, amp_in, amp_out, n, P, d_ops, ntiles);
         else hipLaunchKernelGGL((k_fused_q3<512, 12, 4, true>), dim3(grid3), dim3(512), lds, r->stream, amp_in, amp_out, n, P, d_ops, ntiles);
         HIP_TRY(hipGetLastError());
         return QCX_NO_ERROR;
@@ -827,6 +844,20 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         }
         if (i == first) { standalone(i++); continue; }             // does not fit a tile at all
         if (i - first == 1) { standalone(first); continue; }       // alone: its tuned kernel
+        // A pass whose hot bits all lie below bit 12 takes the WHOLE low end of the index as its tile (up to 2^12 amplitudes): the
+        // tile is then one contiguous block -- e.g. the last pass of the n = 30 Shor circuit's inverse QFT, Hadamards on qubits
+        // 5 .. 11 with c = 4: bit 4 (an M-register bit no gate of the pass needs) would otherwise stay outside and cut the tile
+        // into 256-B runs (7.4 -> 5.9 ms for that pass)
+        if (!want_q3 && tn.fuse_rounds && tn.fuse_lowtile && !hbits.empty()) {
+            const unsigned top = *std::max_element(hbits.begin(), hbits.end()) + 1;
+            // (bit-exact passes only up to 2^11: the 1024-thread form of the exact rounds kernel loses more than the contiguous
+            // tile gains -- n = 30 Shor circuit 36.9 -> 40.2 ms when its last pass went to 2^12; the tolerance mode's passes gain: 24.6 -> 23.7)
+            if (top <= (tol ? 12u : 11u) && top <= n && top >= 10 && top > c + hbits.size()) {
+                hbits.clear();
+                for (unsigned b = c; b < top; b++) hbits.push_back(b);
+                budget = top - c;
+            }
+        }
         // pad the tile with the lowest free bits (longer contiguous runs) up to T bits
         for (unsigned b = c; hbits.size() < budget && b < n; b++)
             if (std::find(hbits.begin(), hbits.end(), b) == hbits.end()) hbits.push_back(b);
@@ -974,12 +1005,10 @@ static int launch_basis_front(amp_t *amp, unsigned n_local, const BasisFront &B,
 // The register is the basis state r->basis_index but nothing has been written yet (lazy reset / collapse).  Write it now --
 // together with the longest prefix of the queue that has a closed form on a basis state: Hadamards on distinct qubits, then
 // controlled modular multiplies (K0b, k_basis_front; the front of Q:712-737 is exactly that).  *used = gates consumed.
-static int basis_front(qcx_register *r, const std::vector<QGate> &gates, size_t *used)
+// the separate write of the basis state + the closed-form front B (k gates of the queue)
+static int launch_front(qcx_register *r, const BasisFront &B, size_t k)
 {
-    *used = 0;
-    const unsigned n = r->n, M = (unsigned)r->M;
-    BasisFront B;
-    const size_t k = front_plan(n, M, r->basis_index, tune_now(), gates, &B);
+    const unsigned n = r->n;
     // (basis_pending is the only record of the logical state: it is cleared once the write has been launched, not before)
     if (k == 0) {                                                       // nothing to fuse: the plain write
         if (r->basis_index == 1) QCX_TRY(qcx_shard_reset(r->amp, n, 1, r->stream));
@@ -990,8 +1019,70 @@ static int basis_front(qcx_register *r, const std::vector<QGate> &gates, size_t 
     QCX_TRY(launch_basis_front(r->amp, n, B, r->stream));
     r->basis_pending = 0;
     r->fronts++;
+    return QCX_NO_ERROR;
+}
+
+static int basis_front(qcx_register *r, const std::vector<QGate> &gates, size_t *used)
+{
+    BasisFront B;
+    const size_t k = front_plan(r->n, (unsigned)r->M, r->basis_index, tune_now(), gates, &B);
+    QCX_TRY(launch_front(r, B, k));
     *used = k;
     return QCX_NO_ERROR;
+}
+
+// Can the front B be generated tile by tile inside the pass `act` -- the first pass behind it, which reads the identity
+// layout: its tile-local bit j IS qubit in_pos[j] -- instead of being written by a pass of its own?  (GenFront, qcx_kernels.h:
+// one modulus for the whole ladder, the basis residue below it; a rounds-form pass without multiplies.)  Fills G.
+static bool gen_front_build(unsigned n, unsigned M, const BasisFront &B, const FuseAction &act, GenFront *G)
+{
+    const FusePass &P = act.P;
+    if (!act.fused || P.has_cam || P.cam_ctl_local[0] != 1 || P.T < 10 || P.T > 12 || M > 12 || B.first != 0 || n > 40) return false;
+    memset(G, 0, sizeof *G);
+    const uint32_t lowmask = (1u << M) - 1u;
+    const uint32_t f0 = (uint32_t)(B.basis & lowmask);
+    uint32_t C = 0;
+    for (unsigned g = 0; g < B.ncam; g++) {
+        if (g == 0) C = B.C[0]; else if (B.C[g] != C) return false;
+    }
+    if (B.ncam && (C == 0 || f0 >= C || C > 4096u || B.ncam > 64)) return false;
+    uint64_t tilemask = 0;
+    unsigned h = 0;
+    int slot_of[64];
+    for (unsigned q = 0; q < 64; q++) slot_of[q] = -1;
+    for (unsigned j = 0; j < P.T; j++) {
+        const unsigned q = P.in_pos[j];
+        tilemask |= (uint64_t)1 << q;
+        G->slotbit[j] = G->lowbit[j] = 0xff;
+        G->signbit[j] = (uint8_t)((B.sign_mask >> q) & 1u);
+        if (q < M) G->lowbit[j] = (uint8_t)q;
+        else { slot_of[q] = (int)h; G->slotbit[j] = (uint8_t)h; h++; }
+    }
+    if (h > (P.dg_slim == 2 ? 9u : 10u)) return false;              // the slot tables' room in LDS
+    G->h = h;
+    for (unsigned q = M; q < n; q++)
+        if (slot_of[q] >= 0 && ((B.fixed_mask >> q) & 1u)) { G->sfm |= 1u << slot_of[q]; G->sbv |= (uint32_t)((B.basis >> q) & 1u) << slot_of[q]; }
+    G->basis = B.basis;
+    G->fixed_out = B.fixed_mask & ~tilemask;
+    G->sign_out = B.sign_mask & ~tilemask;
+    G->v = B.v;
+    G->M = M; G->ncam = B.ncam; G->C = B.ncam ? C : 0u; G->f0 = f0;
+    G->cmpmask = ~(uint32_t)(B.hmask & lowmask) & lowmask;
+    G->lowout_mask = lowmask & ~(uint32_t)tilemask;
+    for (unsigned f = 0; f < 5; f++) for (unsigned b = 0; b < 256; b++) G->tabP[f][b] = 1;
+    for (unsigned g = 0; g < B.ncam; g++) {
+        const unsigned ctl = B.ctl[g];
+        G->camA[g] = B.A[g] % C;
+        if (ctl >= 40) return false;
+        if (slot_of[ctl] >= 0) { G->camloc[g] = (uint8_t)slot_of[ctl]; continue; }
+        if ((tilemask >> ctl) & 1u) return false;                   // (a control below M inside the tile: front_plan never produces it)
+        G->camloc[g] = 0xff;
+        const unsigned f = ctl >> 3, bit = ctl & 7u;
+        G->present |= 1u << f;
+        for (unsigned b = 0; b < 256; b++)
+            if ((b >> bit) & 1u) G->tabP[f][b] = (uint16_t)(((uint32_t)G->tabP[f][b] * G->camA[g]) % C);
+    }
+    return true;
 }
 
 // plan -> upload every pass's records in one copy -> launch in order.  No host synchronisation except waiting for
@@ -999,19 +1090,32 @@ static int basis_front(qcx_register *r, const std::vector<QGate> &gates, size_t 
 static int fuse_flush(qcx_register *r)
 {
     GateQueue *gq = r->queue;
+    const Tune tn = tune_now();
+    // A lazily pending reset / collapse: the register IS a basis state that has not been written.  The closed-form front of
+    // the queue (Hadamards, then the multiply ladder) is either written by a pass of its own (K0b) or -- when a fused pass
+    // follows it -- generated tile by tile inside that pass (GenFront): no write pass, and that pass reads nothing.
+    bool gen_try = false;
+    BasisFront Bf;
+    size_t kfront = 0;
     if (r->basis_pending) {
-        static const std::vector<QGate> none;
-        size_t used = 0;
-        QCX_TRY(basis_front(r, gq ? gq->gates : none, &used));
-        if (used) { gq->gates.erase(gq->gates.begin(), gq->gates.begin() + used); gq->gates_fused += used; }
+        if (gq && !gq->gates.empty() && tn.fuse_gen && r->own_stream && r->n >= 12) {
+            kfront = front_plan(r->n, (unsigned)r->M, r->basis_index, tn, gq->gates, &Bf);
+            gen_try = gq->gates.size() > kfront;
+        }
+        if (!gen_try) {
+            static const std::vector<QGate> none;
+            size_t used = 0;
+            QCX_TRY(basis_front(r, gq ? gq->gates : none, &used));
+            if (used) { gq->gates.erase(gq->gates.begin(), gq->gates.begin() + used); gq->gates_fused += used; }
+        }
     }
     if (!gq || gq->gates.empty()) return QCX_NO_ERROR;
-    if (r->own_stream) QCX_TRY(canon_if_dirty(r));      // gates are about to run on a state the caller wrote (a shard view: its host's business)
+    if (r->own_stream && !gen_try) QCX_TRY(canon_if_dirty(r));      // gates are about to run on a state the caller wrote (a shard view: its host's business)
     std::vector<QGate> gates;
     gates.swap(gq->gates);                       // the queue is empty from here on (re-entrancy safe)
+    if (gen_try) gates.erase(gates.begin(), gates.begin() + kfront);
     std::vector<FuseAction> acts;
     std::vector<FuseOp> all_ops;
-    const Tune tn = tune_now();
     // chains of passes go through the register's second buffer (allocated on first use; a register whose buffer pointer has
     // been handed out, a shard view and a register too large for a second buffer work in place)
     bool chain = tn.fuse_chain && r->own_stream && !r->no_chain && r->n >= (unsigned)std::max<long>(tn.fuse_chain_min_n, 13);
@@ -1025,6 +1129,24 @@ static int fuse_flush(qcx_register *r)
             acts.clear(); all_ops.clear();
             fuse_plan(r, tn, gates, acts, all_ops, r->fusion == 2, false);
         }
+    }
+    if (gen_try) {
+        GenFront G;
+        if (!acts.empty() && gen_front_build(r->n, (unsigned)r->M, Bf, acts[0], &G)) {
+            const size_t at = all_ops.size(), nrec = (sizeof(GenFront) + sizeof(FuseOp) - 1) / sizeof(FuseOp);
+            all_ops.resize(at + nrec);
+            memset(&all_ops[at], 0, nrec * sizeof(FuseOp));
+            memcpy(&all_ops[at], &G, sizeof G);
+            acts[0].P.gen = 1;
+            acts[0].P.gen_rec_off = (uint32_t)(at - acts[0].op_off);
+            r->basis_pending = 0;                                 // (the pass that generates it is launched below; a failed launch returns its error)
+            r->fronts++;
+            r->zeros_dirty = 0;
+        } else {
+            QCX_TRY(launch_front(r, Bf, kfront));                 // the separate write pass after all
+            r->zeros_dirty = 0;
+        }
+        gq->gates_fused += kfront;
     }
     if (!all_ops.empty()) {
         if (gq->ev_valid) HIP_TRY(hipEventSynchronize(gq->ev));       // the previous flush may still read the buffers

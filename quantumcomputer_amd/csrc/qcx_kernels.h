@@ -947,13 +947,15 @@ __global__ __launch_bounds__(64) void k_meas_groups(const MeasBlock *__restrict_
     if (lane == 0) outg[blockIdx.x] = g;
 }
 
-// exact scan of one block.  Batches of 1024 amplitudes (16 per lane, the next batch's loads in flight meanwhile): when a
+// exact scan of one record.  Batches of 1024 amplitudes (16 per lane, the next batch's loads in flight meanwhile): when a
 // whole batch has no tie / oversized element and stays inside the binade and below r, it is ONE integer addition (one
-// wave reduction); otherwise its 16 groups of 64 are tried the same way, and only the group in which something happens
-// runs the strictly sequential chain.
-__device__ __forceinline__ bool meas_try_int(double &cum, double r, unsigned long long inc, uint32_t fl)
+// wave reduction).  Otherwise the longest prefix of its 16 groups of 64 for which that holds is found by bisection (the sums
+// are monotone), the one group in which something happens runs the strictly sequential chain, and the rest of the batch
+// starts over under the binade the chain ended in.
+__device__ __forceinline__ bool meas_int_value(double cum, double r, unsigned long long inc, uint32_t fl, double &cn)
 {
-    // all lanes: inc = this lane's integer increments under the binade of cum, fl = its flags.  true: cum advanced exactly
+    // all lanes: inc = this lane's integer increments under the binade of cum, fl = its flags.  true: cn = the exact running
+    // sum after them (every addition stayed inside the binade and below r)
     const uint64_t cb = (uint64_t)__double_as_longlong(cum);
     const int ec = (int)((cb >> 52) & 0x7ff);
     if (ec == 0 || ec == 0x7ff) return false;
@@ -963,10 +965,8 @@ __device__ __forceinline__ bool meas_try_int(double &cum, double r, unsigned lon
     const uint64_t tot = readlane_u64(inc, 0);                                  // <= 1024 increments < 2^53 each: no overflow
     const uint64_t Kn = ((cb & 0xfffffffffffffULL) | ((uint64_t)1 << 52)) + tot;
     if (Kn >= ((uint64_t)1 << 53)) return false;
-    const double cn = __longlong_as_double((long long)(((uint64_t)ec << 52) | (Kn & 0xfffffffffffffULL)));
-    if (cn >= r) return false;
-    cum = cn;
-    return true;
+    cn = __longlong_as_double((long long)(((uint64_t)ec << 52) | (Kn & 0xfffffffffffffULL)));
+    return !(cn >= r);
 }
 
 __device__ __forceinline__ bool wave_exact_block(const amp_t *__restrict__ amp, uint64_t first, uint64_t len,
@@ -987,32 +987,47 @@ __device__ __forceinline__ bool wave_exact_block(const amp_t *__restrict__ amp, 
             nx[g] = 0.0;
             if (o < len) nx[g] = prob_of(amp[first + o]);
         }
-        if (!(cum >= r)) {                                  // the whole batch as one integer addition
+        int a = 0;                                          // groups [0, a) of the batch are done
+        const int gmax = (int)min((uint64_t)G, (len - base0 + 63) / 64);
+        while (a < gmax) {
+            // this lane's increments of the groups still to do, under the binade the running sum is in now
             const int ec = (int)(((uint64_t)__double_as_longlong(cum) >> 52) & 0x7ff);
-            unsigned long long inc = 0; uint32_t fl = 0;
+            uint64_t inc[G]; uint32_t fl[G];
 #pragma unroll
             for (int g = 0; g < G; g++) {
                 const uint64_t pb = (uint64_t)__double_as_longlong(pv[g]);
                 uint32_t f1 = 0;
                 const uint64_t i1 = meas_inc(pb, ec, f1);
-                inc += pb ? i1 : 0; fl |= pb ? f1 : 0u;
+                inc[g] = pb ? i1 : 0; fl[g] = pb ? f1 : 0u;
             }
-            if (meas_try_int(cum, r, inc, fl)) continue;
-        }
-#pragma unroll 1
-        for (int g = 0; g < G; g++) {
-            const uint64_t base = base0 + (uint64_t)g * 64;
-            if (base >= len) break;
-            double p = pv[0];                               // pv[g] without a run-time register index
+            auto value = [&](int lo, int hi, double &cn) {  // the groups [lo, hi) as one integer addition
+                unsigned long long sI = 0; uint32_t sF = 0;
 #pragma unroll
-            for (int q = 1; q < G; q++) p = (q == g) ? pv[q] : p;
+                for (int g = 0; g < G; g++) { const bool in = g >= lo && g < hi; sI += in ? inc[g] : 0; sF |= in ? fl[g] : 0u; }
+                return meas_int_value(cum, r, sI, sF, cn);
+            };
+            double cn = cum;
+            int take = a;                                   // groups [a, take) can be taken at once
             if (!(cum >= r)) {
-                const int ec = (int)(((uint64_t)__double_as_longlong(cum) >> 52) & 0x7ff);
-                const uint64_t pb = (uint64_t)__double_as_longlong(p);
-                uint32_t fl = 0;
-                const uint64_t i1 = meas_inc(pb, ec, fl);
-                if (meas_try_int(cum, r, pb ? i1 : 0, pb ? fl : 0u)) continue;
+                if (value(a, gmax, cn)) take = gmax;
+                else {
+                    int lo = a, hi = gmax - 1;              // the longest good prefix ends in [lo, hi]
+                    double cbest = cum;
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        double c2;
+                        if (value(a, mid, c2)) { lo = mid; cbest = c2; } else hi = mid - 1;
+                    }
+                    take = lo; cn = cbest;
+                }
             }
+            if (take > a) { cum = cn; a = take; }
+            if (a >= gmax) break;
+            // group a: the strictly sequential chain
+            double p = pv[0];                               // pv[a] without a run-time register index
+#pragma unroll
+            for (int q = 1; q < G; q++) p = (q == a) ? pv[q] : p;
+            const uint64_t base = base0 + (uint64_t)a * 64;
             double run = cum;
 #pragma unroll
             for (int jj = 0; jj < 64; jj++) {
@@ -1028,6 +1043,7 @@ __device__ __forceinline__ bool wave_exact_block(const amp_t *__restrict__ amp, 
                 return true;
             }
             cum = readlane_f64(run, 63);
+            a++;
         }
     }
     return false;
@@ -1156,7 +1172,92 @@ struct FusePass {
     uint8_t  st_loc[16];        // store order: the j-th lowest OUTPUT position of the tile's bits belongs to tile-local bit st_loc[j] ...
     uint8_t  st_pos[16];        // ... and is output index bit st_pos[j] (ascending in j)
     FuseSeg  seg_in[QCX_MAX_SEG], seg_out[QCX_MAX_SEG], seg_lg[QCX_MAX_SEG];
+    // gen = 1: the pass does not READ its tiles: the register is a basis state that has not been written yet (lazy reset /
+    // collapse), and the tile -- that state after the closed-form circuit front, see GenFront -- is generated in LDS
+    uint32_t gen, gen_rec_off, gen_lds_off, gen_pad;
 };
+
+// The circuit front on a basis state (K0b, BasisFront below) evaluated per TILE of the first pass behind it (round 4): the
+// front's separate write pass and the first pass's read disappear.  Same closed form, same bits: after the front, the
+// 2^M-block of an amplitude index i (its bits >= M) is populated iff its non-Hadamard bits equal the basis state's, and then
+// holds ONE amplitude +/- v, at the residue  f = f0 * prod over the set control bits of A_g  mod C  (one modulus for the whole
+// ladder, f0 < C: the products commute; anything else takes the separate write pass).  Per tile: the controls outside the
+// tile give a factor from <= 5 byte-indexed tables, the 2^h combinations of the tile-local bits >= M a table built once per
+// workgroup; an element then costs one LDS look-up and a compare.
+struct GenFront {
+    uint64_t basis;
+    uint64_t fixed_out, sign_out;           // outside-tile parts of BasisFront::fixed_mask / sign_mask
+    double   v;
+    uint32_t M, ncam, C, f0;                // C = 0: no multiplies (every populated block holds f0)
+    uint32_t cmpmask;                       // the low-M bits that must equal the residue (Hadamards on M-register bits free them)
+    uint32_t lowout_mask;                   // low-M bits that lie outside the tile (taken from the tile's base index)
+    uint32_t sfm, sbv;                      // slot space: which slot bits are fixed, and to what
+    uint32_t h, present;                    // slot bits; which of the five byte tables hold a control
+    uint8_t  slotbit[16], lowbit[16], signbit[16];      // per tile-local bit: slot bit index / low-M bit position (0xff: none) / in the sign mask
+    uint8_t  camloc[64];                    // per multiply: slot bit of its control, 0xff = outside the tile (in the byte tables)
+    uint32_t camA[64];
+    uint16_t tabP[5][256];                  // product of the A_g whose control is a set bit of byte f of the base index, mod C
+};
+
+// per-thread / per-k constant of the generated fill: slot bits | low bits << 12 | sign parity << 24 of a tile-local element index
+__device__ __forceinline__ uint32_t gen_pack(unsigned e, const GenFront *G, unsigned T)
+{
+    uint32_t w = 0;
+    for (unsigned j = 0; j < T; j++) {
+        if (!((e >> j) & 1u)) continue;
+        if (G->slotbit[j] != 0xff) w |= 1u << G->slotbit[j];
+        if (G->lowbit[j] != 0xff) w |= 1u << (12u + G->lowbit[j]);
+        if (G->signbit[j]) w ^= 1u << 24;
+    }
+    return w;
+}
+
+// once per workgroup: the slot table (residue factor of the tile-local controls, times f0; 0xffff = block not populated)
+template <int BLOCK>
+__device__ __forceinline__ void gen_setup(const GenFront *G, unsigned short *phot)
+{
+    const unsigned nslot = 1u << G->h;
+    for (unsigned s = threadIdx.x; s < nslot; s += BLOCK) {
+        unsigned x = G->f0;
+        if ((s & G->sfm) != G->sbv) x = 0xffffu;
+        else if (G->C)
+            for (unsigned g = 0; g < G->ncam; g++)
+                if (G->camloc[g] != 0xff && ((s >> G->camloc[g]) & 1u)) x = (x * G->camA[g]) % G->C;
+        phot[s] = (unsigned short)x;
+    }
+}
+
+// per tile: res[s] = the residue of slot s for this tile (0xffff: not populated), then the tile itself
+template <int BLOCK, unsigned EPT>
+__device__ __forceinline__ void gen_tile(const GenFront *G, amp_t *tile, const unsigned short *phot, unsigned short *res,
+                                         uint64_t base, uint32_t packT, const uint32_t (&packK)[EPT])
+{
+    const unsigned nslot = 1u << G->h;
+    const bool pop_out = (base & G->fixed_out) == (G->basis & G->fixed_out);
+    for (unsigned s = threadIdx.x; s < nslot; s += BLOCK) {
+        unsigned x = phot[s];
+        if (!pop_out) x = 0xffffu;
+        else if (x != 0xffffu && G->C) {
+#pragma unroll
+            for (unsigned f = 0; f < 5; f++)
+                if ((G->present >> f) & 1u) x = (x * (unsigned)G->tabP[f][(unsigned)((base >> (8u * f)) & 255u)]) % G->C;
+        }
+        res[s] = (unsigned short)x;
+    }
+    __syncthreads();
+    const uint32_t lowbase = (uint32_t)base & G->lowout_mask;
+    const uint32_t parbase = (uint32_t)__builtin_popcountll(base & G->sign_out) & 1u;
+    const double vp = G->v, vm = -G->v;
+#pragma unroll
+    for (unsigned k = 0; k < EPT; k++) {
+        const uint32_t w = packT ^ packK[k];
+        const unsigned f = res[w & 0xfffu];
+        const uint32_t low = ((w >> 12) & 0xfffu) | lowbase;
+        amp_t a; a.x = 0.0; a.y = 0.0;
+        if (f != 0xffffu && ((low ^ f) & G->cmpmask) == 0u) a.x = (((w >> 24) ^ parbase) & 1u) ? vm : vp;
+        tile[k * BLOCK + threadIdx.x] = a;
+    }
+}
 
 // index with the tile number's bits deposited by segments: bits [src, src + len) of t go to [dst, dst + len)
 __device__ __forceinline__ uint64_t fuse_deposit(uint64_t t, const FuseSeg *seg, unsigned nseg)
@@ -1819,7 +1920,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void
 // store phases of the resident workgroups overlap each other; measured, that beats the double-buffered pipeline
 // inside one workgroup (the round-1 pipelined form, removed) as soon as enough workgroups are resident, so this kernel carries nothing but
 // the rounds interpreter and is held to OCC waves per SIMD.
-template <int BLOCK, int TT, int OCC, bool CAM, int TOL = 0>
+template <int BLOCK, int TT, int OCC, bool CAM, int TOL = 0, bool GEN = false>      // GEN: the tiles are generated, not read (GenFront)
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) void k_fused_rounds(
     const amp_t *amp, amp_t *amp_out, unsigned n, FusePass P, const FuseOp *__restrict__ ops, uint64_t ntiles, const FuseOp *ops_asm)
 {
@@ -1852,6 +1953,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
     const uint64_t st_t = fuse_spread(threadIdx.x, P.st_pos, TT);
     const unsigned ld_t = (unsigned)fuse_spread(threadIdx.x, P.st_loc, TT);
     const unsigned wbase = (threadIdx.x >> 6) * 64;
+    // gen: the tiles are generated (the circuit front on a basis state that was never written), not read
+    const GenFront *GF = reinterpret_cast<const GenFront *>(ops + P.gen_rec_off);
+    unsigned short *gen_phot = reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(lut) + P.gen_lds_off);
+    unsigned short *gen_res = gen_phot + 1024;
+    uint32_t packT = 0, packK[4] = {0, 0, 0, 0};
+    if constexpr (GEN) {
+        gen_setup<BLOCK>(GF, gen_phot);
+        packT = gen_pack(threadIdx.x, GF, TT);
+#pragma unroll
+        for (unsigned k = 0; k < 4; k++) packK[k] = gen_pack(k * BLOCK, GF, TT);
+        __syncthreads();
+    }
     // swz = s > 0: workgroups that share an XCD (blockIdx mod 8 under round-robin placement) take 2^s NEIGHBOURING tiles
     // instead of every eighth one -- their runs are then adjacent in memory (speed only; any order is correct)
     const unsigned swz = (P.dbg >> 8) & 7u;
@@ -1866,7 +1979,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
         if (P.chained) { base = fuse_deposit(t, P.seg_lg, P.nseg_lg); base_out = fuse_deposit(t, P.seg_out, P.nseg_out); }
         const amp_t *g = amp + (base_in | off_t);
         amp_t *go = amp_out + (base_out | st_t);
-        if (!(P.dbg & 4u)) {
+        if constexpr (GEN) gen_tile<BLOCK, 4>(GF, tile, gen_phot, gen_res, base, packT, packK);
+        else if (!(P.dbg & 4u)) {
 #pragma unroll
             for (unsigned k = 0; k < 4; k++)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + off_k[k]),
@@ -1977,7 +2091,7 @@ __device__ __forceinline__ void q3_run(amp_t *tile, unsigned p, const unsigned (
 
 // EXACT = true: the same radix-8 structure for passes of nothing but Hadamards in the BIT-EXACT modes (the fused Hadamard
 // sweep): exact butterflies (separate roundings, no FMA), canonical zeros once at the store; no tables, no diagonals.
-template <int BLOCK, int TT, int OCC, bool EXACT = false>
+template <int BLOCK, int TT, int OCC, bool EXACT = false, bool GEN = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) void k_fused_q3(
     const amp_t *amp, amp_t *amp_out, unsigned n, FusePass P, const FuseOp *__restrict__ ops, uint64_t ntiles)
 {
@@ -2003,13 +2117,26 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
     const uint64_t st_t = fuse_spread(threadIdx.x, P.st_pos, TT);
     const unsigned ld_t = (unsigned)fuse_spread(threadIdx.x, P.st_loc, TT);
     const unsigned wbase = (threadIdx.x >> 6) * 64;
+    // gen: the tiles are generated (the circuit front on a basis state that was never written), not read
+    const GenFront *GF = reinterpret_cast<const GenFront *>(ops + P.gen_rec_off);
+    unsigned short *gen_phot = reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(tile + tsize) + P.gen_lds_off);
+    unsigned short *gen_res = gen_phot + 512;
+    uint32_t packT = 0, packK[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (GEN) {
+        gen_setup<BLOCK>(GF, gen_phot);
+        packT = gen_pack(threadIdx.x, GF, TT);
+#pragma unroll
+        for (unsigned k = 0; k < 8; k++) packK[k] = gen_pack(k * BLOCK, GF, TT);
+        __syncthreads();
+    }
     for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const uint64_t base_in = fuse_deposit(t, P.seg_in, P.nseg_in);
         uint64_t base = base_in, base_out = base_in;               // logical base (gate records), output base
         if (P.chained) { base = fuse_deposit(t, P.seg_lg, P.nseg_lg); base_out = fuse_deposit(t, P.seg_out, P.nseg_out); }
         const amp_t *g = amp + (base_in | off_t);
         amp_t *go = amp_out + (base_out | st_t);
-        if (!(P.dbg & 4u)) {
+        if constexpr (GEN) gen_tile<BLOCK, 8>(GF, tile, gen_phot, gen_res, base, packT, packK);
+        else if (!(P.dbg & 4u)) {
 #pragma unroll
             for (unsigned k = 0; k < 8; k++)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + off_k[k]),

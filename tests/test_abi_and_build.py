@@ -127,8 +127,8 @@ def test_gate_kernels_have_no_fma():
     # bit-exact kernel -- per-gate kernels, the exact fused passes, measurement, exchange -- is free of it
     funcs = {m.group(1): txt[m.start():txt.find(".Lfunc_end", m.start())] for m in re.finditer(r"^(_Z\w+):", txt, re.M)}
     with_fma = [name for name, body in funcs.items() if re.search(r"v_fma_f64|v_fmac_f64|v_pk_fma_f64", body)]
-    assert with_fma and all(re.match(r"_ZN3qcx14k_fused_roundsILi\d+ELi\d+ELi\d+ELb[01]ELi[12]EE|_ZN3qcx10k_fused_q3ILi\d+ELi\d+ELi\d+ELb0EE", name) for name in with_fma), with_fma
-    assert any(re.match(r"_ZN3qcx10k_fused_q3ILi\d+ELi\d+ELi\d+ELb1EE", name) for name in funcs), "the exact radix-8 Hadamard kernel"
+    assert with_fma and all(re.match(r"_ZN3qcx14k_fused_roundsILi\d+ELi\d+ELi\d+ELb[01]ELi[12]ELb[01]EE|_ZN3qcx10k_fused_q3ILi\d+ELi\d+ELi\d+ELb0ELb[01]EE", name) for name in with_fma), with_fma
+    assert any(re.match(r"_ZN3qcx10k_fused_q3ILi\d+ELi\d+ELi\d+ELb1ELb[01]EE", name) for name in funcs), "the exact radix-8 Hadamard kernel"
     assert txt.count("global_load_dwordx4") > 50            # 16-B amplitude accesses everywhere
     # the "+ 0.0" canonicalisation must survive optimisation in the Hadamard kernels
     body = txt[txt.index("k_h_pair"):]
@@ -144,7 +144,7 @@ def test_fused_rounds_kernel_keeps_its_scalar_record_loads():
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     txt = open(s_path).read()
-    bodies = [txt[m.start():txt.find(".Lfunc_end", m.start())] for m in re.finditer(r"^_ZN3qcx14k_fused_roundsILi512ELi11ELi8ELb[01]ELi0EE\w*:", txt, re.M)]
+    bodies = [txt[m.start():txt.find(".Lfunc_end", m.start())] for m in re.finditer(r"^_ZN3qcx14k_fused_roundsILi512ELi11ELi8ELb[01]ELi0ELb0EE\w*:", txt, re.M)]
     assert len(bodies) == 2
     for b in bodies:
         assert len(re.findall(r"global_load_dword ", b)) == 0 and len(re.findall(r"flat_load", b)) == 0

@@ -103,11 +103,13 @@ struct Tune {
     long cam_nt_lines = 0;     // modular multiply: completely rewritten lines leave as nontemporal stores (the partly rewritten one through L2)
     long fuse_T      = 11;     // fused passes: tile = 2^T amplitudes in LDS (8..12)
     long fuse_c      = 4;      // fused passes: contiguous low bits of a tile (runs of 16 * 2^c bytes)
-    long fuse_grid_cap = 24576; // workgroups of the one-tile-per-workgroup form (each walks several tiles: the table fill at kernel start is amortised)
+    long fuse_grid_cap = 65536; // (round 4, chained passes: 65536 beats 24576 by 1-2 %, one per tile loses 15 % on the n = 30 exact Shor circuit)
+                               // workgroups of the one-tile-per-workgroup form (each walks several tiles: the table fill at kernel start is amortised)
     long fuse_qround = 1;      // tolerance mode: rounds of the shape H D H D run as straight-line code (FUSE_QROUND)
     long fuse_swz = 0;         // rounds kernel: workgroups of one XCD take 2^this neighbouring tiles (0: tile = blockIdx)
-    long fuse_q3_cap = 3072;   // workgroups of k_fused_q3 (n = 28 inverse QFT: 3072 -> 6.17 ms, 2048 6.36, 24576 7.0, one per tile 8.3)
-    long fuse_q3_cap_exact = 8192;
+    long fuse_q3_cap = 65536;  // workgroups of k_fused_q3 with tables (round 3, in place: 3072 best; round 4, chained: n = 28 inverse QFT 6.12 ms with 3072, 5.85 with 65536;
+                               // n = 30 Shor circuit 18.7 with 65536, 20.5 with one per tile)
+    long fuse_q3_cap_exact = 0;  // all-Hadamard radix-8 passes (no tables to stage): one workgroup per tile (round 4, chained passes: n = 30 sweep 20.2 ms with 8192, 19.2 with one per tile)
     long fuse_q3 = 1;          // tolerance mode: radix-8 fast rounds on 2^12 tiles when they save a pass (k_fused_q3)
     long fuse_gen    = 1;      // a pending reset / collapse + circuit front is GENERATED inside the first fused pass behind it (no write pass, no read)
     long fuse_lowtile = 1;     // a pass whose hot bits lie below bit 12 takes the whole low end of the index as its (contiguous) tile

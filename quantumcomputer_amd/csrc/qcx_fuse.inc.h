@@ -84,7 +84,7 @@ struct GateQueue {
     size_t   d_cap = 0;
     FuseOp  *h_ops = nullptr;       // pinned staging
     size_t   h_cap = 0;
-    unsigned long passes_launched = 0, gates_fused = 0, chained_passes = 0;
+    unsigned long passes_launched = 0, gates_fused = 0, chained_passes = 0, gen_fronts = 0;
     hipEvent_t ev;                  // recorded after the last kernel of a flush: guards the record buffers
     bool     ev_valid = false;
 };
@@ -1095,6 +1095,7 @@ static int fuse_flush(qcx_register *r)
     // the queue (Hadamards, then the multiply ladder) is either written by a pass of its own (K0b) or -- when a fused pass
     // follows it -- generated tile by tile inside that pass (GenFront): no write pass, and that pass reads nothing.
     bool gen_try = false;
+    const bool front_flush = r->basis_pending != 0;
     BasisFront Bf;
     size_t kfront = 0;
     if (r->basis_pending) {
@@ -1130,6 +1131,43 @@ static int fuse_flush(qcx_register *r)
             fuse_plan(r, tn, gates, acts, all_ops, r->fusion == 2, false);
         }
     }
+    // Behind a circuit front only a few of the 2^M low index values are populated (the multiply ladder's orbit), and no gate of
+    // an inverse QFT touches the M register: whole waves of a tile hold nothing but +0.  Passes of such a flush map their wave
+    // number onto M-register bits of the tile and let all-zero waves skip the rounds (FusePass::zskip; found at run time, so
+    // any state is handled correctly)
+    if (front_flush && tn.fuse_zskip && r->M >= 2) {
+        bool h_on_m = false;
+        for (const QGate &g : gates) h_on_m |= (g.type == FUSE_H && g.q < (unsigned)r->M) || g.type == FUSE_CAMODC || g.type == 99;
+        for (FuseAction &a : acts) {
+            if (h_on_m || !a.fused || a.P.cam_ctl_local[0] != 1 || a.P.has_cam || a.P.dg_slim == 2 || a.P.T < 10 || a.P.T > 12) continue;
+            const unsigned W = a.P.T - 8;                          // waves per workgroup = 2^W (4 amplitudes per thread)
+            std::vector<unsigned> passive;                         // tile-local positions of M-register bits, by ascending qubit
+            for (unsigned q = 0; q < (unsigned)r->M; q++)
+                for (unsigned j = 0; j < a.P.T; j++) if (a.tl[j] == q) passive.push_back(j);
+            if (passive.size() < W || W > (unsigned)tn.fuse_zskip_maxw) continue;          // (W = 3: the lanes' LDS stride costs 8-way bank conflicts -- the 2^11 pass of the n = 30 Shor circuit 7.4 -> 8.7 ms)
+            std::vector<unsigned> z(passive.end() - W, passive.end());
+            std::sort(z.begin(), z.end());
+            a.P.zskip = (uint8_t)W;
+            a.P.zlist = 0;
+            for (unsigned j = 0; j < W; j++) { a.P.zb[j] = (uint8_t)z[j]; a.P.zlist |= (uint64_t)z[j] << (8 * j); }
+            // every round's header gets the sorted list of the positions its threads' lane numbers leave out: zb[] + its register bits
+            bool ok = true;
+            for (size_t o = a.op_off; o < a.op_off + a.P.nops && ok; ) {
+                FuseOp &h = all_ops[o];
+                const uint32_t ty = h.type & 0xffu;
+                if (ty != FUSE_ROUND && ty != FUSE_QROUND) { ok = false; break; }
+                std::vector<unsigned> e(z);
+                e.push_back(h.a & 0xffu); e.push_back((h.a >> 8) & 0xffu);
+                std::sort(e.begin(), e.end());
+                for (size_t k = 1; k < e.size(); k++) ok &= e[k] != e[k - 1];          // (a register bit among the zb[]: cannot happen -- no Hadamard on the M register)
+                uint64_t list = 0;
+                for (size_t k = 0; k < e.size(); k++) list |= (uint64_t)e[k] << (8 * k);
+                memcpy(&h.c, &list, sizeof list);
+                o += 1 + (size_t)h.mask;
+            }
+            if (!ok) a.P.zskip = 0;
+        }
+    }
     if (gen_try) {
         GenFront G;
         if (!acts.empty() && gen_front_build(r->n, (unsigned)r->M, Bf, acts[0], &G)) {
@@ -1141,6 +1179,7 @@ static int fuse_flush(qcx_register *r)
             acts[0].P.gen_rec_off = (uint32_t)(at - acts[0].op_off);
             r->basis_pending = 0;                                 // (the pass that generates it is launched below; a failed launch returns its error)
             r->fronts++;
+            gq->gen_fronts++;
             r->zeros_dirty = 0;
         } else {
             QCX_TRY(launch_front(r, Bf, kfront));                 // the separate write pass after all

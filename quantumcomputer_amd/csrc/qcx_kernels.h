@@ -1174,7 +1174,15 @@ struct FusePass {
     FuseSeg  seg_in[QCX_MAX_SEG], seg_out[QCX_MAX_SEG], seg_lg[QCX_MAX_SEG];
     // gen = 1: the pass does not READ its tiles: the register is a basis state that has not been written yet (lazy reset /
     // collapse), and the tile -- that state after the closed-form circuit front, see GenFront -- is generated in LDS
-    uint32_t gen, gen_rec_off, gen_lds_off, gen_pad;
+    uint32_t gen, gen_rec_off, gen_lds_off;
+    // zskip = W > 0 (W = log2 of the waves per workgroup): the wave number is mapped onto the tile-local bits zb[0..W) -- bits no
+    // Hadamard of the pass targets and no multiply moves -- instead of onto the highest thread bits, and a wave whose
+    // amplitudes are ALL +0 skips the rounds (gates map +0 to +0: same bits).  The host asks for it behind a circuit front:
+    // there only the residues of the multiply ladder's orbit are populated among the 2^M low index values (C = 21, a = 2:
+    // six of 32), so whole waves of a tile hold nothing.  Correct for any state: a wave that finds a non-zero bit works.
+    uint8_t  zskip, zb[3];
+    uint32_t zpad;
+    uint64_t zlist;             // the zb[] ascending, one per byte
 };
 
 // The circuit front on a basis state (K0b, BasisFront below) evaluated per TILE of the first pass behind it (round 4): the
@@ -1770,13 +1778,44 @@ __device__ __forceinline__ void qround_run(amp_t *tile, unsigned p, unsigned e1,
     tile[p] = v0; tile[e1] = v1; tile[e2] = v2; tile[e3] = v3;
 }
 
+// zero-wave skipping (FusePass::zskip): the element index of a thread when the wave number rides on the tile-local bits zb[]
+// and the lane number on the remaining positions, ascending.  `list` = the positions to leave out of the lane number (the zb[]
+// and, inside a round, its register bits), ascending, one per byte (the host sorts them: FusePass::zlist for the whole tile,
+// the c field of a round's header record for a round); `wavepart` = the wave number's bits already at their zb[] positions.
+__device__ __forceinline__ unsigned zskip_index(unsigned lanebits, unsigned wavepart, uint64_t list, unsigned cnt)
+{
+    unsigned x = lanebits;
+    for (unsigned k = 0; k < cnt; k++) x = (unsigned)insert_zero(x, (unsigned)(list >> (8u * k)) & 0xffu);
+    return x | wavepart;
+}
+// does this wave's share of the tile (the elements whose zb[] bits spell its number) hold nothing but +0 ?
+template <int TT>
+__device__ __forceinline__ bool zskip_wave_is_zero(const amp_t *tile, const FusePass &P, unsigned wavepart)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    constexpr unsigned per = (1u << TT) >> 6;                   // elements per lane over the whole tile
+    const unsigned share = per >> P.zskip;                        // ... of this wave's share
+    uint64_t any = 0;
+    for (unsigned k = 0; k < share; k++) {
+        const amp_t v = tile[zskip_index(lane | (k << 6), wavepart, P.zlist, P.zskip)];
+        any |= (uint64_t)__double_as_longlong(v.x) | (uint64_t)__double_as_longlong(v.y);
+    }
+    return __ballot(any != 0) == 0ULL;
+}
+
 template <int BLOCK, int TT, bool CAM = true, int TOL = 0>     // CAM = false: the pass holds no modular multiply (smaller kernel); TOL: 1 tolerance mode, 2 fast rounds only
 __device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, unsigned short *lut, const unsigned char *camtab,
                                                   const uint64_t *xm, const FusePass &P, const FuseOp *__restrict__ ops,
-                                                  const FuseOp *ops_asm, uint64_t base, const amp_t *dg = nullptr)
+                                                  const FuseOp *ops_asm, uint64_t base, const amp_t *dg = nullptr, unsigned zrot = 0)
 {
     static_assert((1u << TT) == 4u * BLOCK, "rounds form needs 4 amplitudes per thread");
     unsigned i = 0;
+    // zskip: which share of the tile this wave takes rotates with the tile number (zrot) -- the populated shares are the same in
+    // every tile, and a wave sits on one SIMD for good: without the rotation one SIMD would do all the work
+    const unsigned zwave = ((threadIdx.x >> 6) + zrot) & ((BLOCK >> 6) - 1u);
+    unsigned zpart = 0;
+    for (unsigned j = 0; j < P.zskip; j++) zpart |= ((zwave >> j) & 1u) << P.zb[j];
+    const bool idle = !CAM && P.zskip && zskip_wave_is_zero<TT>(tile, P, zpart);      // this wave holds nothing: it only keeps the barriers
     while (i < P.nops) {
         const uint32_t type = ops[i].type & 0xffu;
         if (TOL && type == FUSE_QROUND) {
@@ -1784,18 +1823,25 @@ __device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, unsigned short *l
             const amp_t *gtab = dg + P.dg_cnt;                      // behind the per-tile E_out slots
             const unsigned rb0 = ops[i].a & 0xffu, rb1 = (ops[i].a >> 8) & 0xffu;
             const uint32_t sA = ops[i + 1].type, sB = ops[i + 1].a;
-            const unsigned p = (unsigned)insert_zero(insert_zero(threadIdx.x, rb0), rb1);
+            if (!idle) {
+            uint64_t zl; memcpy(&zl, &ops[i].c, sizeof zl);           // (zskip: the positions the lane number leaves out, sorted by the host)
+            const unsigned p = P.zskip ? zskip_index(threadIdx.x & 63u, zpart, zl, P.zskip + 2u)
+                                       : (unsigned)insert_zero(insert_zero(threadIdx.x, rb0), rb1);
             const unsigned e1 = p | (1u << rb0), e2 = p | (1u << rb1), e3 = e1 | (1u << rb1);
             if (sA & 1u) { if (sB & 1u) qround_run<true, true>(tile, p, e1, e2, e3, rb0, rb1, sA, sB, dg, gtab);
                            else         qround_run<true, false>(tile, p, e1, e2, e3, rb0, rb1, sA, sB, dg, gtab); }
             else         { if (sB & 1u) qround_run<false, true>(tile, p, e1, e2, e3, rb0, rb1, sA, sB, dg, gtab);
                            else         qround_run<false, false>(tile, p, e1, e2, e3, rb0, rb1, sA, sB, dg, gtab); }
+            }
             __syncthreads();
             i += 2;
         } else if (TOL != 2 && type == FUSE_ROUND) {
             const unsigned rb0 = ops[i].a & 0xffu, rb1 = (ops[i].a >> 8) & 0xffu;
             const unsigned cnt = (unsigned)ops[i].mask;
-            const unsigned p = (unsigned)insert_zero(insert_zero(threadIdx.x, rb0), rb1);
+            if (!idle) {
+            uint64_t zl; memcpy(&zl, &ops[i].c, sizeof zl);           // (zskip: the positions the lane number leaves out, sorted by the host)
+            const unsigned p = P.zskip ? zskip_index(threadIdx.x & 63u, zpart, zl, P.zskip + 2u)
+                                       : (unsigned)insert_zero(insert_zero(threadIdx.x, rb0), rb1);
             const unsigned e1 = p | (1u << rb0), e2 = p | (1u << rb1), e3 = e1 | (1u << rb1);
             Quad q;
             { const amp_t v0 = tile[p], v1 = tile[e1], v2 = tile[e2], v3 = tile[e3];
@@ -1830,6 +1876,7 @@ __device__ __forceinline__ void fuse_apply_rounds(amp_t *tile, unsigned short *l
             { amp_t v0, v1, v2, v3;
               v0.x = q.x0; v0.y = q.y0; v1.x = q.x1; v1.y = q.y1; v2.x = q.x2; v2.y = q.y2; v3.x = q.x3; v3.y = q.y3;
               tile[p] = v0; tile[e1] = v1; tile[e2] = v2; tile[e3] = v3; }
+            }
             __syncthreads();
             i += 1 + cnt;
         } else if (CAM && type == FUSE_CAMRUN) {
@@ -2000,7 +2047,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (!(P.dbg & 1u)) fuse_apply_rounds<BLOCK, TT, CAM, TOL>(tile, lut, camtab, xm, P, ops, ops_asm, base, dg);
+        if (!(P.dbg & 1u)) fuse_apply_rounds<BLOCK, TT, CAM, TOL>(tile, lut, camtab, xm, P, ops, ops_asm, base, dg, (unsigned)t);
         amp_t v[4];
 #pragma unroll
         for (unsigned k = 0; k < 4; k++) v[k] = tile[ld_k[k] | ld_t];          // (store order: ascending OUTPUT positions)

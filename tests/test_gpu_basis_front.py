@@ -132,3 +132,53 @@ def test_config5_front_n30_is_one_pass(qc, ob):
         assert reg.fusion_stats()[0] - p0 == 1                  # the whole front: one write pass
         for s in sorted({0, (1 << n) - (1 << W)} | {int(v) << W for v in rs.randint(0, 1 << (n - W), 6)}):
             assert np.array_equal(bits(reg.read(s, 1 << W)), bits(ob.shor_front_window(n, M, Cn, a, s, 1 << W))), s
+
+
+def _gen_fronts(qc, reg):
+    import ctypes as C
+    out = C.c_ulong(0)
+    qc.lib().qcx_gen_stats(reg._h, C.byref(out))
+    return out.value
+
+
+@pytest.mark.parametrize("mode", [0, 2], ids=["exact", "tolerance"])
+@pytest.mark.parametrize("C,L,M,a", [(21, 9, 5, 2), (21, 14, 5, 2), (15, 12, 4, 11), (33, 10, 6, 7), (35, 17, 6, 2), (21, 16, 5, 16)])
+def test_front_generated_inside_the_first_pass(qc, ob, C, L, M, a, mode):
+    """round 4: when a fused pass follows the circuit front, the front is not written at all -- the pass generates its tiles
+    (GenFront) instead of reading them.  Same bits as with the separate write pass (fuse_gen = 0) and as the oracle; from
+    reset states and from measured basis states (minus signs); the tolerance mode's passes generate the same front."""
+    n = L + M
+    old = qc.lib().qcx_tune_get(b"fuse_gen")
+    oldz = qc.lib().qcx_tune_get(b"fuse_zskip")
+    try:
+        outs = []
+        for gen, zskip in ((1, 1), (0, 1), (1, 0)):                      # (zskip: waves whose share of a tile is all +0 skip the rounds)
+            qc.tune(fuse_gen=gen, fuse_zskip=zskip)
+            with qc.Register(L, M) as reg:
+                reg.set_fusion(mode)
+                g0 = _gen_fronts(qc, reg)
+                qc.reset_register(reg); qc.quantum_computation(C, a, reg)
+                first = reg.read()
+                idx = qc.measure_state(reg, 0.41)                       # collapse: a basis state with bits inside the Hadamard set
+                for l in range(M, n):
+                    qc.hadamard_gate(l, reg)
+                qc.inverse_QFT(reg)
+                second = reg.read()
+                outs.append((first, idx, second))
+                assert (_gen_fronts(qc, reg) - g0 >= 1) == bool(gen)
+        want = np.zeros(2 << n); ob.reset(want, n); ob.quantum_computation(want, n, M, C, a, threads=8)
+        if mode == 0:
+            assert all(np.array_equal(bits(o[0]), bits(want)) for o in outs)
+        else:
+            assert all(float(np.max(np.abs(o[0] - want))) <= 1e-12 for o in outs)
+        assert outs[0][1] == outs[1][1] == outs[2][1] == ob.measure(want, n, 0.41)
+        w2 = want                                                        # collapsed by ob.measure
+        for l in range(M, n):
+            ob.hadamard(w2, n, l, 8)
+        ob.iqft(w2, n, M, 8)
+        if mode == 0:
+            assert all(np.array_equal(bits(o[2]), bits(w2)) for o in outs)
+        else:
+            assert all(float(np.max(np.abs(o[2] - w2))) <= 1e-12 for o in outs)
+    finally:
+        qc.tune(fuse_gen=old, fuse_zskip=oldz)

@@ -133,6 +133,9 @@ unsigned qcx_ref_int_pow(double base, double power);
  *                canonicalised.  On a sharded register (qcx_register_create_sharded) every shard's passes run in this mode. */
 int  qcx_set_fusion(qcx_register *reg, int enable);
 int  qcx_flush(qcx_register *reg);
+/* passes_launched: fused passes plus circuit fronts executed (a front = the lazily pending basis state written together with
+ * the closed-form prefix of the queue; also one that was generated inside its first pass); gates_fused: gates that went into
+ * either.  Sharded register: passes_launched counts the fronts only (see qcx_sharded_stats), gates_fused is 0. */
 int  qcx_fusion_stats(qcx_register *reg, unsigned long *passes_launched, unsigned long *gates_fused);
 
 /* ---- measurement: Q:272-306 ----------------------------------------------- */
@@ -151,7 +154,12 @@ int  qcx_total_probability(qcx_register *reg, double *total_probability);
  * in 64 MiB pieces.  Load requires a register of the same L and M and verifies the checksum. */
 int  qcx_state_save(qcx_register *reg, const char *path);
 int  qcx_state_load(qcx_register *reg, const char *path);
-void *qcx_device_pointer(qcx_register *reg);      /* the amplitude buffer in HBM (for interop) */
+/* The amplitude buffer in HBM (for interop).  Flushes first.  Its contents are the register's state only after qcx_flush,
+ * qcx_synchronize or a fresh call of this function: reset_register and the collapse of measure_state are lazy, and fused
+ * passes may alternate between two buffers.  Calling it pins the state to the returned buffer from then on (the register
+ * stops chaining passes through its second buffer), so the pointer stays valid until the register is destroyed.  NULL for a
+ * sharded register. */
+void *qcx_device_pointer(qcx_register *reg);
 /* synthetic input for benches and full-size tests: component k (k = 2*index + {0 re, 1 im}) is
  * ((splitmix64(seed + k) >> 11) * 2^-53 - 0.5) * sqrt(6 / 2^n); generated on the device */
 int  qcx_state_fill_random(qcx_register *reg, uint64_t seed);

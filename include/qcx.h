@@ -78,8 +78,8 @@ int  qcx_M_size(const qcx_register *reg);
  * on the same devices and compares every amplitude, bit for bit, with what the layout says it must be; on a mismatch
  * creation fails with QCX_HIP_ERROR and qcx_last_error() names the shard (QCX_SHARD_SELFCHECK=0 skips, =1 forces the
  * check; qcx_sharded_set_relays runs it again through the relays).
- * Limits: M_size <= 12 (the modular multiply stages whole 2^M blocks in LDS; larger M registers are single-GPU only and
- * give QCX_UNSUPPORTED here).  Not available on a sharded register: qcx_register_set_stream, qcx_device_pointer (NULL),
+ * M_size > 12 works like on one GPU (the modular multiply then runs in place through a per-device staging buffer instead of
+ * LDS tiles; M_size <= 26).  Not available on a sharded register: qcx_register_set_stream, qcx_device_pointer (NULL),
  * the event pool. */
 int  qcx_register_create_sharded(int L_size, int M_size, unsigned nshards, const int *devices, qcx_register **out);
 int  qcx_spread_devices(unsigned nshards, int visible_devices /* <= 0: ask HIP */, int *devices_out /* [nshards] */);

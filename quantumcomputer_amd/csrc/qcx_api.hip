@@ -112,6 +112,8 @@ struct Tune {
     long fuse_q3_cap_exact = 0;  // all-Hadamard radix-8 passes (no tables to stage): one workgroup per tile (round 4, chained passes: n = 30 sweep 20.2 ms with 8192, 19.2 with one per tile)
     long fuse_q3 = 1;          // tolerance mode: radix-8 fast rounds on 2^12 tiles when they save a pass (k_fused_q3)
     long fuse_gen    = 1;      // a pending reset / collapse + circuit front is GENERATED inside the first fused pass behind it (no write pass, no read)
+    long cam_block   = 0;      // threads per workgroup of k_camodc (0: 256; 1024 for tiles of 2^12 amplitudes)
+    long cam_stage_mb = 1024;  // M > 12: staging buffer of the in-place modular multiply (MiB; at least one 2^M-block)
     long fuse_zskip  = 1;      // passes behind a circuit front: waves whose share of the tile is all +0 skip the rounds (FusePass::zskip)
     long fuse_zskip_maxw = 2;  // ... on tiles of at most 2^(8 + this) amplitudes
     long fuse_lowtile = 1;     // a pass whose hot bits lie below bit 12 takes the whole low end of the index as its (contiguous) tile
@@ -148,7 +150,7 @@ static Tune tune_now() { std::lock_guard<std::mutex> lock(g_tune_mutex); return 
 extern "C" int qcx_tune_set(const char *key, long value)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); g_tune.name = value; return QCX_NO_ERROR; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_full) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_onepass) K(meas_spin_limit) K(meas_dbg) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_zskip) K(fuse_zskip_maxw)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_full) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_onepass) K(meas_spin_limit) K(meas_dbg) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_zskip) K(fuse_zskip_maxw)
 #undef K
     return QCX_BAD_ARGUMENTS;
 }
@@ -156,7 +158,7 @@ extern "C" int qcx_tune_set(const char *key, long value)
 extern "C" long qcx_tune_get(const char *key)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); return g_tune.name; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_full) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_onepass) K(meas_spin_limit) K(meas_dbg) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_zskip) K(fuse_zskip_maxw)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_full) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_onepass) K(meas_spin_limit) K(meas_dbg) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_zskip) K(fuse_zskip_maxw)
 #undef K
     return -1;
 }
@@ -182,6 +184,8 @@ struct Workspace {
     double     *h_scalar = nullptr;     // pinned
     uint32_t   *tab = nullptr;          // camodc CSR table (off + srcs)
     size_t      tab_cap = 0;
+    amp_t      *cam_stage = nullptr;    // staging buffer of the M > 12 modular multiply (K3b)
+    size_t      cam_stage_cap = 0;
     double     *meas_sums = nullptr, *meas_prefix = nullptr;   // exact parallel measurement (K4b)
     MeasBlock  *meas_blocks = nullptr;
     unsigned    meas_cap = 0;
@@ -500,15 +504,98 @@ static unsigned modinv_u32(unsigned a, unsigned m)
     return (unsigned)t;
 }
 
+// M > 12: the 2^M-block does not fit an LDS tile -> in place through the device's staging buffer, a batch of blocks at a time
+// (K3b: k_cam_big_gather / k_cam_big_scatter).  Works on any view (a whole register, a shard, a slice of at least one block).
+static int shard_camodc_large(amp_t *a, unsigned n_local, unsigned M, unsigned C, unsigned A, int ctl, hipStream_t st, const Tune &tn)
+{
+    if (M > 26) return QCX_UNSUPPORTED;
+    const uint64_t blk = (uint64_t)1 << M;
+    const uint64_t fmax = (C < blk ? C : blk) - 1;
+    const bool wraps = (uint64_t)(C - 1) * fmax > 0xffffffffULL;
+    const bool closed = (ctl < 0 || ctl >= (int)M) && C <= blk && !wraps;        // as in qcx_shard_camodc
+    CamBig P;
+    memset(&P, 0, sizeof P);
+    P.M = M; P.C = C;
+    P.ctl = (ctl >= (int)M) ? ctl : -1;               // a control inside the M register is encoded in the table
+    P.R = closed ? C : (unsigned)blk;
+    P.chunks = (P.R + 1023u) / 1024u;
+    const uint64_t all_blocks = (uint64_t)1 << (n_local - M);
+    const uint64_t touched = (P.ctl >= 0) ? all_blocks >> 1 : all_blocks;
+    if (touched == 0) return QCX_NO_ERROR;
+
+    Workspace *w;
+    QCX_TRY(workspace(&w));
+    std::lock_guard<std::mutex> use(g_ws_use[w - g_ws]);     // table and staging buffer are per-device scratch: one user at a time
+    const size_t row_bytes = (size_t)P.R * sizeof(amp_t);
+    const size_t want = std::max<size_t>(row_bytes, std::min<size_t>((size_t)std::max<long>(tn.cam_stage_mb, 1) << 20, row_bytes * touched));
+    {
+        std::lock_guard<std::mutex> lock(g_ws_mutex);
+        if (w->cam_stage_cap < want) {
+            HIP_TRY(hipStreamSynchronize(st));
+            if (w->cam_stage) HIP_TRY(hipFree(w->cam_stage));
+            w->cam_stage = nullptr; w->cam_stage_cap = 0;
+            if (hipMalloc(&w->cam_stage, want) != hipSuccess) {
+                (void)hipGetLastError();
+                set_error("hipMalloc(%zu bytes) for the staging buffer of a modular multiply with M = %u", want, M);
+                return QCX_INSUFFICIENT_MEMORY;
+            }
+            w->cam_stage_cap = want;
+        }
+    }
+    const uint32_t *d_off = nullptr, *d_srcs = nullptr;
+    if (closed) {
+        P.d = gcd_u32(A, C); P.Cd = C / P.d; P.inv = modinv_u32(A / P.d, P.Cd);
+    } else {
+        // CSR of sources per destination built as Q:611-654 maps them
+        std::vector<uint32_t> cnt(blk + 1, 0), dst(blk);
+        for (uint64_t f = 0; f < blk; f++) {
+            uint32_t d = (uint32_t)f;
+            const bool on = (ctl >= 0 && ctl < (int)M) ? ((f >> ctl) & 1u) : true;
+            if (on && f < C) d = (uint32_t)(((uint32_t)(A * (uint32_t)f)) % C) & (uint32_t)(blk - 1);
+            dst[f] = d; cnt[d + 1]++;
+        }
+        for (uint64_t g = 0; g < blk; g++) cnt[g + 1] += cnt[g];
+        std::vector<uint32_t> tab(2 * blk + 1);
+        memcpy(tab.data(), cnt.data(), (blk + 1) * sizeof(uint32_t));
+        std::vector<uint32_t> fill(cnt.begin(), cnt.end() - 1);
+        for (uint64_t f = 0; f < blk; f++) tab[blk + 1 + fill[dst[f]]++] = (uint32_t)f;       // ascending f per destination
+        const size_t need = tab.size() * sizeof(uint32_t);
+        {
+            std::lock_guard<std::mutex> lock(g_ws_mutex);
+            if (w->tab_cap < need) {
+                if (w->tab) HIP_TRY(hipFree(w->tab));
+                w->tab = nullptr; w->tab_cap = 0;
+                HIP_TRY(hipMalloc(&w->tab, need));
+                w->tab_cap = need;
+            }
+        }
+        HIP_TRY(hipStreamSynchronize(st));                   // the previous table may still be in use
+        HIP_TRY(hipMemcpy(w->tab, tab.data(), need, hipMemcpyHostToDevice));
+        d_off = w->tab; d_srcs = w->tab + blk + 1;
+    }
+    const uint64_t per_batch = std::max<uint64_t>(1, w->cam_stage_cap / row_bytes);
+    for (uint64_t first = 0; first < touched; first += per_batch) {
+        P.first = first; P.nblk = std::min<uint64_t>(per_batch, touched - first);
+        const uint64_t items = ((P.nblk + 7) / 8) * P.chunks;                    // per XCD, at most
+        const unsigned grid = 8u * (unsigned)std::min<uint64_t>(items, 1024);
+        if (closed) hipLaunchKernelGGL((k_cam_big_gather<false>), dim3(grid), dim3(256), 0, st, (const amp_t *)a, w->cam_stage, P, d_off, d_srcs);
+        else hipLaunchKernelGGL((k_cam_big_gather<true>), dim3(grid), dim3(256), 0, st, (const amp_t *)a, w->cam_stage, P, d_off, d_srcs);
+        hipLaunchKernelGGL(k_cam_big_scatter, dim3(grid), dim3(256), 0, st, a, (const amp_t *)w->cam_stage, P);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));                       // rare path: table and staging buffer are free again when the lock is
+    return QCX_NO_ERROR;
+}
+
 extern "C" int qcx_shard_camodc(void *amp, unsigned n_local, unsigned M, unsigned C, unsigned A, int ctl, void *stream)
 {
     if (!amp || n_local > 40 || C == 0 || M > n_local) return QCX_BAD_ARGUMENTS;
     if (ctl >= (int)n_local) return QCX_BAD_QUBIT;
-    if (M > 12) return QCX_UNSUPPORTED;              // 2^M-block no longer fits the LDS tile
     A %= C;
     hipStream_t st = (hipStream_t)stream;
     amp_t *a = (amp_t *)amp;
     const Tune tn = tune_now();
+    if (M > 12) return shard_camodc_large(a, n_local, M, C, A, ctl, st, tn);     // 2^M-block no longer fits the LDS tile
 
     CamodcParams P;
     memset(&P, 0, sizeof P);
@@ -541,8 +628,13 @@ extern "C" int qcx_shard_camodc(void *amp, unsigned n_local, unsigned M, unsigne
         const unsigned grid = grid_for(P.ntiles, 1, tn.cam_grid_cap);
         // most of every line rewritten (C / 2^M >= 1/2): store whole nontemporal lines instead of partial ones
         const bool full = tn.cam_full > 0 || (tn.cam_full < 0 && 2 * (uint64_t)C >= blk);
-        if (full) hipLaunchKernelGGL((k_camodc<256, true>), dim3(grid), dim3(256), lds, st, a, P);
-        else hipLaunchKernelGGL((k_camodc<256, false>), dim3(grid), dim3(256), lds, st, a, P);
+        // tiles of 2^12 amplitudes (M = 12) get 1024 threads: with 256 the two workgroups a CU's LDS holds are 8 waves, too few to
+        // overlap their load -> barrier -> store chains (n = 30: 4.55 -> 3.25 ms; 2^11 tiles: 512 threads 3.27, 256 threads 3.14)
+        const unsigned blockT = (tn.cam_block > 0) ? (unsigned)tn.cam_block : (P.logT >= 12 ? 1024u : 256u);
+#define QCX_CAM_LAUNCH(B) do { if (full) hipLaunchKernelGGL((k_camodc<B, true>), dim3(grid), dim3(B), lds, st, a, P); \
+                               else hipLaunchKernelGGL((k_camodc<B, false>), dim3(grid), dim3(B), lds, st, a, P); } while (0)
+        if (blockT >= 1024) QCX_CAM_LAUNCH(1024); else if (blockT >= 512) QCX_CAM_LAUNCH(512); else QCX_CAM_LAUNCH(256);
+#undef QCX_CAM_LAUNCH
         HIP_TRY(hipGetLastError());
         return QCX_NO_ERROR;
     }
@@ -738,7 +830,7 @@ struct qcx_register {
     hipEvent_t ev0, ev1;
     hipEvent_t *events;
     unsigned   n_events;
-    amp_t     *scratch;         // second buffer, allocated on first use (chained passes; M > 12 modular multiply)
+    amp_t     *scratch;         // second buffer, allocated on first use (chained passes)
     int        no_chain;        // the buffer pointer was handed out (qcx_device_pointer) or no second buffer fits: passes work in place
     int        zeros_dirty;     // the caller wrote amplitudes (qcx_state_write / _load): they may hold -0, which the reference's gates would
                                 // canonicalise (Q:393-413); one k_canon_zeros pass runs before the next gate
@@ -767,64 +859,8 @@ static int canon_if_dirty(qcx_register *r)
 
 #define FLUSH(r) QCX_TRY(fuse_flush(r))
 
-// M > 12: the 2^M-block does not fit an LDS tile -> out of place into the scratch buffer, then swap
-static int reg_camodc_large(qcx_register *r, unsigned C, unsigned A, unsigned ctl)
-{
-    const unsigned M = (unsigned)r->M;
-    if (M > 26) return QCX_UNSUPPORTED;
-    if (!r->scratch) {
-        hipError_t e = hipMalloc(&r->scratch, r->dim * sizeof(amp_t));
-        if (e != hipSuccess) { snprintf(g_last_error, sizeof g_last_error, "hipMalloc(scratch): %s", hipGetErrorString(e)); return QCX_INSUFFICIENT_MEMORY; }
-    }
-    CamodcParams P;
-    memset(&P, 0, sizeof P);
-    P.M = M; P.logT = M; P.ctl = (int)ctl; P.C = C; P.ntiles = 0; P.skip = 0; P.ntl = 0;
-    const uint64_t blk = (uint64_t)1 << M;
-    const unsigned grid = grid_for(r->dim, 256, 65536);
-    if (camodc_closed_form(r->n, M, C, A, ctl)) {
-        P.d = gcd_u32(A, C); P.Cd = C / P.d; P.inv = modinv_u32(A / P.d, P.Cd);
-        hipLaunchKernelGGL((k_camodc_oop<false, 256>), dim3(grid), dim3(256), 0, r->stream, r->amp, r->scratch, r->dim, P, nullptr, nullptr);
-    } else {
-        std::vector<uint32_t> cnt(blk + 1, 0), dst(blk);
-        for (uint64_t f = 0; f < blk; f++) {
-            uint32_t d = (uint32_t)f;
-            const bool on = (ctl < M) ? ((f >> ctl) & 1u) : true;
-            if (on && f < C) d = (uint32_t)(((uint32_t)(A * (uint32_t)f)) % C) & (uint32_t)(blk - 1);
-            dst[f] = d; cnt[d + 1]++;
-        }
-        for (uint64_t g = 0; g < blk; g++) cnt[g + 1] += cnt[g];
-        std::vector<uint32_t> tab(2 * blk + 1);
-        memcpy(tab.data(), cnt.data(), (blk + 1) * sizeof(uint32_t));
-        std::vector<uint32_t> fill(cnt.begin(), cnt.end() - 1);
-        for (uint64_t f = 0; f < blk; f++) tab[blk + 1 + fill[dst[f]]++] = (uint32_t)f;
-        Workspace *w;
-        QCX_TRY(workspace(&w));
-        std::lock_guard<std::mutex> use(g_ws_use[w - g_ws]);
-        const size_t need = tab.size() * sizeof(uint32_t);
-        {
-            std::lock_guard<std::mutex> lock(g_ws_mutex);
-            if (w->tab_cap < need) {
-                if (w->tab) HIP_TRY(hipFree(w->tab));
-                w->tab = nullptr; w->tab_cap = 0;
-                HIP_TRY(hipMalloc(&w->tab, need));
-                w->tab_cap = need;
-            }
-        }
-        HIP_TRY(hipStreamSynchronize(r->stream));
-        HIP_TRY(hipMemcpy(w->tab, tab.data(), need, hipMemcpyHostToDevice));
-        if (ctl < M) P.ctl = -1;                     // the table already encodes a control inside the M register
-        hipLaunchKernelGGL((k_camodc_oop<true, 256>), dim3(grid), dim3(256), 0, r->stream, r->amp, r->scratch, r->dim, P,
-                           w->tab, w->tab + blk + 1);
-        HIP_TRY(hipStreamSynchronize(r->stream));            // rare path: finish before the table can be replaced
-    }
-    HIP_TRY(hipGetLastError());
-    amp_t *t = r->amp; r->amp = r->scratch; r->scratch = t;       // swap_states (Q:242-249)
-    return QCX_NO_ERROR;
-}
-
 static int reg_camodc(qcx_register *r, unsigned C, unsigned A, unsigned ctl)
 {
-    if ((unsigned)r->M > 12) return reg_camodc_large(r, C, A, ctl);
     return qcx_shard_camodc(r->amp, r->n, (unsigned)r->M, C, A, (int)ctl, r->stream);
 }
 
@@ -1057,7 +1093,7 @@ static int descs_to_gates(unsigned n_local, unsigned M, unsigned count, const qc
             g.q = d.q; g.C = d.C; g.A = d.A % d.C;
             const bool closed = (d.q == 0xffffffffu) ? camodc_closed_form(n_local, M, d.C, g.A, M)   // "control" outside M
                                                      : camodc_closed_form(n_local, M, d.C, g.A, d.q);
-            g.type = closed ? (uint32_t)FUSE_CAMODC : 99u;
+            g.type = (closed && M <= 12) ? (uint32_t)FUSE_CAMODC : 99u;          // (M > 12: never inside a tile pass -- K3b, stand-alone)
         } else return QCX_BAD_ARGUMENTS;
         out.push_back(g);
     }
@@ -1076,7 +1112,6 @@ extern "C" int qcx_shard_run_fused(void *amp, unsigned n_local, unsigned M, unsi
 extern "C" int qcx_shard_run_fused_mode(int mode, void *amp, unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates, void *stream)
 {
     if (!amp || n_local == 0 || n_local > 40 || M > n_local || (count && !gates)) return QCX_BAD_ARGUMENTS;
-    if (M > 12) return QCX_UNSUPPORTED;
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return QCX_HIP_ERROR;
@@ -1119,7 +1154,6 @@ extern "C" int qcx_fusion_plan_mode(int mode, unsigned n_local, unsigned M, unsi
 {
     if (n_local == 0 || n_local > 40 || M > n_local || (count && !gates) || !n_actions || !n_records) return QCX_BAD_ARGUMENTS;
     if ((mode & 3) != 1 && (mode & 3) != 2) return QCX_BAD_ARGUMENTS;
-    if (M > 12) return QCX_UNSUPPORTED;
     static_assert(sizeof(qcx_fuse_record) == sizeof(FuseOp), "record layout");
     qcx_register tmp;
     memset(&tmp, 0, sizeof tmp);

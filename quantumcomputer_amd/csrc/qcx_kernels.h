@@ -2397,36 +2397,83 @@ __global__ __launch_bounds__(BLOCK) void k_pack_push(const amp_t *__restrict__ s
 }
 
 // ---------------------------------------------------------------------------
-// K3b  controlled modular multiply for M registers too large for an LDS tile (M > 12): out of place,
-// dst = gate(src), the caller swaps the two buffers afterwards (the reference's swap_states, Q:242-249).
-// Sources are gathered straight from HBM/L2 (16-B reads inside a 2^M block), so this path is correct
-// but not fast; every M the reference can practically reach (M <= 12) takes the LDS kernels above.
-// TABLE = false: closed form (control >= M, C <= 2^M, no 32-bit wrap);  true: CSR source table.
+// K3b  controlled modular multiply for M registers too large for an LDS tile (M > 12): IN PLACE through a bounded staging
+// buffer, a batch of 2^M-blocks at a time.  k_cam_big_gather computes the new rows [0, R) of every control-set block of the
+// batch into the staging buffer (R = C in the closed form: rows >= C keep their values; R = 2^M with a source table), with the
+// reference's order of summation (ascending source row, starting from 0: Q:393, Q:409-412); k_cam_big_scatter copies them
+// back over the block.  No second state buffer and no buffer swap: the path works on a shard view and on a register that fills
+// the card.  Traffic: 64 B per rewritten amplitude (gathered read + staged write + staged read + write).
+// The 16-B source reads of one block scatter over its 2^M * 16 bytes, so all workgroups that work on a block sit on ONE XCD
+// (blockIdx mod 8 under the round-robin placement) and consecutive workgroups of that XCD take consecutive chunks of the same
+// block: the block's lines are fetched into that XCD's L2 once (256 KiB at M = 14 ... 2 MiB at M = 17 of the 4 MiB).
+// TABLE = false: closed form (control outside the M register, C <= 2^M, no 32-bit wrap);  true: CSR source table.
 // ---------------------------------------------------------------------------
-template <bool TABLE, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_camodc_oop(const amp_t *__restrict__ src, amp_t *__restrict__ dst, uint64_t count,
-                                                        CamodcParams P, const uint32_t *__restrict__ off,
-                                                        const uint32_t *__restrict__ srcs)
+struct CamBig {
+    unsigned M, R;           // rows staged per block
+    int      ctl;            // control bit (>= M), or -1: every block of the view takes part
+    unsigned C, d, Cd, inv;
+    uint64_t first, nblk;    // the batch: control-set blocks [first, first + nblk) of the view
+    unsigned chunks;         // ceil(R / 1024)
+};
+
+__device__ __forceinline__ uint64_t cam_big_block_base(const CamBig &P, uint64_t tb)
 {
-    const uint64_t blkmask = ((uint64_t)1 << P.M) - 1;
-    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < count; i += (uint64_t)gridDim.x * BLOCK) {
-        const uint64_t f = i & blkmask, b0 = i - f;
-        const bool on = (P.ctl < 0) ? true : ((i >> P.ctl) & 1u);
-        amp_t acc;
-        if (TABLE) {
-            if (!on) { dst[i] = src[i]; continue; }
-            acc.x = 0.0; acc.y = 0.0;
-            for (uint32_t k = off[f]; k < off[f + 1]; k++) { const amp_t v = src[b0 + srcs[k]]; acc.x += v.x; acc.y += v.y; }
-        } else {
-            if (!on || f >= P.C) { dst[i] = src[i]; continue; }
-            acc.x = 0.0; acc.y = 0.0;
-            const uint32_t g = (uint32_t)f;
-            if (g % P.d == 0) {
+    const uint64_t blockno = (P.ctl >= (int)P.M) ? (insert_zero(tb, (unsigned)P.ctl - P.M) | ((uint64_t)1 << ((unsigned)P.ctl - P.M))) : tb;
+    return blockno << P.M;
+}
+
+// (block of the batch, chunk of 1024 rows) of workgroup-iteration `it` under the XCD-aware order; false: past the end
+__device__ __forceinline__ bool cam_big_item(const CamBig &P, uint64_t it, uint64_t *j, unsigned *chunk)
+{
+    const unsigned xcd = blockIdx.x & 7u;
+    const uint64_t mine = (P.nblk + 7u - xcd) >> 3;               // blocks j of the batch with j mod 8 == xcd
+    if (it >= mine * P.chunks) return false;
+    *j = (it / P.chunks) * 8u + xcd;
+    *chunk = (unsigned)(it % P.chunks);
+    return true;
+}
+
+template <bool TABLE>
+__global__ __launch_bounds__(256) void k_cam_big_gather(const amp_t *__restrict__ amp, amp_t *__restrict__ stage, CamBig P,
+                                                        const uint32_t *__restrict__ off, const uint32_t *__restrict__ srcs)
+{
+    uint64_t j; unsigned chunk;
+    for (uint64_t it = blockIdx.x >> 3; cam_big_item(P, it, &j, &chunk); it += gridDim.x >> 3) {
+        const amp_t *blk = amp + cam_big_block_base(P, P.first + j);
+        amp_t *to = stage + j * P.R;
+#pragma unroll
+        for (unsigned k = 0; k < 4; k++) {
+            const unsigned g = chunk * 1024u + k * 256u + threadIdx.x;
+            if (g >= P.R) continue;
+            amp_t acc; acc.x = 0.0; acc.y = 0.0;
+            if (TABLE) {
+                for (uint32_t s = off[g]; s < off[g + 1]; s++) { const amp_t v = blk[srcs[s]]; acc.x += v.x; acc.y += v.y; }
+            } else if (g % P.d == 0) {
                 uint32_t s0 = (uint32_t)(((uint64_t)(g / P.d) * P.inv) % P.Cd);
-                for (uint32_t t = 0; t < P.d; t++, s0 += P.Cd) { const amp_t v = src[b0 + s0]; acc.x += v.x; acc.y += v.y; }
+                for (uint32_t q = 0; q < P.d; q++, s0 += P.Cd) { const amp_t v = blk[s0]; acc.x += v.x; acc.y += v.y; }
             }
+            __builtin_nontemporal_store(acc, to + g);
         }
-        dst[i] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cam_big_scatter(amp_t *__restrict__ amp, const amp_t *__restrict__ stage, CamBig P)
+{
+    uint64_t j; unsigned chunk;
+    for (uint64_t it = blockIdx.x >> 3; cam_big_item(P, it, &j, &chunk); it += gridDim.x >> 3) {
+        amp_t *blk = amp + cam_big_block_base(P, P.first + j);
+        const amp_t *from = stage + j * P.R;
+        amp_t v[4];
+#pragma unroll
+        for (unsigned k = 0; k < 4; k++) {
+            const unsigned g = chunk * 1024u + k * 256u + threadIdx.x;
+            if (g < P.R) v[k] = __builtin_nontemporal_load(from + g);
+        }
+#pragma unroll
+        for (unsigned k = 0; k < 4; k++) {
+            const unsigned g = chunk * 1024u + k * 256u + threadIdx.x;
+            if (g < P.R) blk[g] = v[k];
+        }
     }
 }
 

@@ -167,7 +167,6 @@ static int sh_create(int L, int M, unsigned nshards, const int *devices, ShardSe
         set_error("register too small for %u shards (need n_local - max(M, 6) >= 2 log2(shards))", nshards);
         delete sh; return QCX_BAD_ARGUMENTS;
     }
-    if ((unsigned)M > 12) { set_error("sharded register: M <= 12"); delete sh; return QCX_UNSUPPORTED; }
     sh->perm.resize(sh->n); sh->inv.resize(sh->n);
     sh_identity_perm(sh);
     sh->dry = devices && devices[0] < 0;

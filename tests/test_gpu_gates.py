@@ -92,7 +92,7 @@ CAMODC_CASES = [
     (4, 3, 15, 7, 4), (4, 3, 21, 2, 5),                                # C > 2^M: only bits < M of f' kept
     (3, 5, 21, 2, 2), (3, 5, 21, 10, 0), (3, 4, 15, 7, 3),             # control inside the M register
     (12, 4, 15, 7, 15), (13, 5, 21, 4, 17), (9, 5, 21, 2, 10),         # control above / inside the LDS tile
-    # M > 12: out-of-place path with buffer swap (closed form, many-to-one, control inside M, C > 2^M)
+    # M > 12: in place through the staging buffer, K3b (closed form, many-to-one, control inside M, C > 2^M)
     (2, 13, 8191, 1234, 14), (3, 13, 5000, 7, 13), (1, 14, 16000, 3, 14), (2, 13, 8190, 6, 13),
     (2, 13, 6000, 12, 5), (2, 13, 9000, 7, 14),
 ]
@@ -107,10 +107,43 @@ def test_camodc_bit_exact(qc, ob, L, M, C, atox, ctl):
         with qc.Register(L, M) as reg:
             reg.write(a); reg.set_fusion(fusion)
             qc.c_amodc_gate(C, atox, ctl, reg)
-            qc.hadamard_gate(n - 1, reg)                   # something after it (the M > 12 path swaps buffers)
+            qc.hadamard_gate(n - 1, reg)                   # something after it
             got = reg.read()
         w2 = want.copy(); ob.hadamard(w2, n, n - 1)
         assert_bits_equal(got, w2, f"C_AMODC L={L} M={M} C={C} atox={atox} ctl={ctl} fusion={fusion}")
+
+
+@pytest.mark.parametrize("L,M,C,atox,ctl", [(7, 13, 8191, 1234, 15), (6, 14, 16001, 3, 19), (7, 13, 5000, 10, 13), (6, 13, 8000, 7, 4),
+                                            (5, 15, 32749, 2, 17), (6, 13, 9000, 7, 16)])
+def test_camodc_large_m_in_batches(qc, ob, L, M, C, atox, ctl):
+    """M > 12 with more than one 2^M-block per control value: the staged in-place kernels (K3b) with a staging buffer of
+    one block, of a few blocks (uneven last batch) and of everything at once -- every amplitude vs the oracle"""
+    n = L + M
+    a = ob.random_state(n, 900 + ctl)
+    want = a.copy(); ob.camodc(want, n, M, C, atox, ctl)
+    old = qc.lib().qcx_tune_get(b"cam_stage_mb")
+    try:
+        for mb in (1, 3, 1024):            # 2^13 rows = 128 KiB: 1 MiB holds 8 blocks, 3 MiB 24, ...
+            qc.tune(cam_stage_mb=mb)
+            with qc.Register(L, M) as reg:
+                reg.write(a)
+                qc.c_amodc_gate(C, atox, ctl, reg)
+                assert_bits_equal(reg.read(), want, f"C_AMODC L={L} M={M} C={C} atox={atox} ctl={ctl} stage={mb} MiB")
+    finally:
+        qc.tune(cam_stage_mb=old)
+
+
+def test_shor_circuit_with_a_large_m_register(qc, ob):
+    """the whole circuit of Q:712-737 with M = 13 (C = 8191, L = 9): queued, the multiplies stand-alone between fused passes"""
+    L, M, Cn, a = 9, 13, 8191, 3
+    n = L + M
+    want = np.zeros(2 << n); ob.reset(want, n); ob.quantum_computation(want, n, M, Cn, a)
+    for mode in (1, -1):
+        with qc.Register(L, M) as reg:
+            reg.set_fusion(mode)
+            qc.reset_register(reg)
+            qc.quantum_computation(Cn, a, reg)
+            assert_bits_equal(reg.read(), want, f"Shor C={Cn} L={L} M={M} mode={mode}")
 
 
 def test_reset_register(qc):

@@ -72,13 +72,13 @@ def test_shard_entry_points_with_global_bits(pg, ob, qc):
     assert np.array_equal(bits(t.cpu().numpy()), bits(full[(rank << nl) * 2:((rank + 1) << nl) * 2]))
 
 
-def test_shard_run_fused_gate_list(pg, ob, qc):
+@pytest.mark.parametrize("nl,M,Cn", [(15, 5, 21), (17, 13, 8191)], ids=["M=5", "M=13 (multiplies stand-alone, staged in place)"])
+def test_shard_run_fused_gate_list(pg, ob, qc, nl, M, Cn):
     """qcx_shard_run_fused: a gate list on a shard (rank-bit controls folded in: always-on multiply, reduced phase
     masks) through the fusion scheduler equals the same gates applied one by one by the oracle"""
     import torch
     from quantumcomputer_amd.sharded import HipEngine
     rs = np.random.RandomState(77)
-    nl, M, Cn = 15, 5, 21
     eng = HipEngine("cuda:0")
     for trial in range(4):
         want = ob.random_state(nl, 90 + trial)

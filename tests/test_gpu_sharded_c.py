@@ -37,7 +37,8 @@ def test_hadamard_sweeps(qc, ob, shards, n, fusion):
         assert 2 <= ex <= 6                                  # one trade per sweep + restoring the identity layout
 
 
-@pytest.mark.parametrize("shards,C,L,M,a", [(2, 15, 3, 4, 7), (2, 21, 6, 5, 2), (4, 21, 8, 5, 2), (8, 21, 12, 5, 2), (4, 33, 9, 6, 7)])
+@pytest.mark.parametrize("shards,C,L,M,a", [(2, 15, 3, 4, 7), (2, 21, 6, 5, 2), (4, 21, 8, 5, 2), (8, 21, 12, 5, 2), (4, 33, 9, 6, 7),
+                                            (2, 8191, 9, 13, 3), (4, 8191, 10, 13, 3)])       # M > 12: the staged in-place multiply on every shard
 def test_shor_circuit_and_measurement(qc, ob, shards, C, L, M, a):
     n = L + M
     if n - (shards.bit_length() - 1) - max(M, 6) < 2 * (shards.bit_length() - 1):
@@ -56,7 +57,7 @@ def test_shor_circuit_and_measurement(qc, ob, shards, C, L, M, a):
             assert np.array_equal(bits(reg.read()), bits(want))          # collapsed the same way
         assert all(x == y for x, y in picks), picks
         k = shards.bit_length() - 1
-        if n - k >= M + 6:
+        if n - k >= M + 6 and M <= 12:
             # the circuit front (reset + Hadamard layer, shard-id qubits included + multiply ladder) went out as one write
             # pass per shard, without an exchange: one front per shot
             assert reg.fusion_stats()[0] == 4

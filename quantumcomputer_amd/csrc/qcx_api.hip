@@ -1093,7 +1093,7 @@ static int descs_to_gates(unsigned n_local, unsigned M, unsigned count, const qc
             g.q = d.q; g.C = d.C; g.A = d.A % d.C;
             const bool closed = (d.q == 0xffffffffu) ? camodc_closed_form(n_local, M, d.C, g.A, M)   // "control" outside M
                                                      : camodc_closed_form(n_local, M, d.C, g.A, d.q);
-            g.type = (closed && M <= 12) ? (uint32_t)FUSE_CAMODC : 99u;          // (M > 12: never inside a tile pass -- K3b, stand-alone)
+            g.type = closed ? (uint32_t)FUSE_CAMODC : 99u;          // (M > 12: the planner keeps it out of the tile passes -- K3b, stand-alone)
         } else return QCX_BAD_ARGUMENTS;
         out.push_back(g);
     }
@@ -1210,7 +1210,7 @@ extern "C" int qcx_shard_basis_front(void *amp, unsigned n_local, uint64_t first
     }
     BasisFront B;
     size_t k = 0;
-    if (M <= 12) k = front_plan(n, M, basis, tune_now(), q, &B);
+    if (M <= 26) k = front_plan(n, M, basis, tune_now(), q, &B);
     hipStream_t st = (hipStream_t)stream;
     if (k == 0) {
         const uint64_t per = (uint64_t)1 << n_local;
@@ -1362,7 +1362,7 @@ extern "C" int qcx_c_amodc_gate(unsigned C, unsigned long long atox, unsigned c,
     if (r->fusion > 0 || r->composite) {
         QGate g; memset(&g, 0, sizeof g);
         g.q = c; g.C = C; g.A = (unsigned)(atox % C);
-        g.type = ((unsigned)r->M <= 12 && camodc_closed_form(r->n, (unsigned)r->M, C, g.A, c)) ? (uint32_t)FUSE_CAMODC : 99u;
+        g.type = camodc_closed_form(r->n, (unsigned)r->M, C, g.A, c) ? (uint32_t)FUSE_CAMODC : 99u;
         return fuse_push(r, g);
     }
     FLUSH(r);

@@ -484,7 +484,7 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
     const unsigned n = r->n;
     const uint64_t ntiles = (uint64_t)1 << (n - P.T);
     const unsigned grid = grid_for(ntiles, 1, tn.fuse_grid_cap);
-    const size_t lut_only = cam_lut_bytes((unsigned)r->M);                         // scratch of the modular-multiply steps
+    const size_t lut_only = P.has_cam ? cam_lut_bytes((unsigned)r->M) : 16;        // scratch of the modular-multiply steps
     size_t lut_bytes = lut_only + (size_t)P.cam_ctl_local[1];                      // + tables of folded multiply runs
     P.xm_off = 0;
     P.dbg = (uint32_t)tn.fuse_dbg | (((uint32_t)tn.fuse_swz & 7u) << 8);
@@ -616,9 +616,13 @@ struct PassShape {
     int nopipe;
 };
 
-static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<QGate> &gates_in, std::vector<FuseAction> &acts, std::vector<FuseOp> &all_ops,
+static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<QGate> &gates_arg, std::vector<FuseAction> &acts, std::vector<FuseOp> &all_ops,
                       bool tol = false, bool chain = false)
 {
+    // an M register beyond the LDS tile (M > 12): its modular multiplies never join a tile pass -- stand-alone (K3b), like the table form
+    std::vector<QGate> big;
+    if ((unsigned)r->M > 12) { big = gates_arg; for (QGate &g : big) if (g.type == FUSE_CAMODC) g.type = 99; }
+    const std::vector<QGate> &gates_in = (unsigned)r->M > 12 ? big : gates_arg;
     std::vector<QGate> merged;
     std::vector<DiagSpec> specs;
     std::vector<size_t> ofirst, ocnt;                  // per (merged) gate: its run in the original list
@@ -647,7 +651,9 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         act.first_gate = ofirst[first]; act.ngates = ofirst[i - 1] + ocnt[i - 1] - ofirst[first];
         act.P.has_cam = sh.n_other ? 1u : 0u;
         act.P.c = sh.c; act.P.nh = (uint32_t)sh.hbits.size(); act.P.T = sh.c + act.P.nh;
-        act.P.cam_ctl_local[3] = (int32_t)cam_lut_bytes((unsigned)r->M);           // table area sits behind the lut
+        // (the table area sits behind the modular-multiply scratch; a pass without multiplies carries none: with M >= 12 its 8 KiB
+        //  pushed the 2^10-tile phase passes over the LDS budget of the rounds form and onto the general kernel: 24 ms against 7)
+        act.P.cam_ctl_local[3] = (int32_t)(sh.n_other ? cam_lut_bytes((unsigned)r->M) : 16);
         for (unsigned j = 0; j < act.P.nh; j++) act.P.hbit[j] = (uint8_t)sh.hbits[j];
         std::vector<FuseOp> legacy;
         bool rounds = tn.fuse_rounds && act.P.T >= 10 && act.P.T <= 12;
@@ -969,7 +975,7 @@ static size_t front_plan(unsigned n, unsigned M, uint64_t basis, const Tune &tn,
     unsigned nh = 0;
     const uint64_t lowmask = ((uint64_t)1 << M) - 1;
     BasisFront B; memset(&B, 0, sizeof B);
-    if (tn.fuse_front && M <= 12) {
+    if (tn.fuse_front && M <= 26) {
         while (k < gates.size() && gates[k].type == FUSE_H && !((hmask >> gates[k].q) & 1)) { hmask |= (uint64_t)1 << gates[k].q; nh++; k++; }
         if (!(hmask & lowmask))
             while (k < gates.size() && gates[k].type == FUSE_CAMODC && gates[k].q != 0xffffffffu && B.ncam < 64) {
@@ -990,7 +996,10 @@ static size_t front_plan(unsigned n, unsigned M, uint64_t basis, const Tune &tn,
 // one shard's (or the whole register's) front: the wave-tile kernel, or one thread per amplitude for tiny registers
 static int launch_basis_front(amp_t *amp, unsigned n_local, const BasisFront &B, hipStream_t st)
 {
-    if (n_local >= B.M + 6) {
+    if (B.M > 12) {                       // a workgroup per 2^M-block (the wave tile would be 64 blocks = 2^(M + 6) amplitudes)
+        const uint64_t nblocks = ((uint64_t)1 << n_local) >> B.M;
+        hipLaunchKernelGGL(k_basis_front_big, dim3(grid_for(nblocks, 1, 16384)), dim3(256), 0, st, amp, n_local, B);
+    } else if (n_local >= B.M + 6) {
         const uint64_t nwaves = ((uint64_t)1 << n_local) >> (6 + B.M);
         hipLaunchKernelGGL(k_basis_front, dim3(grid_for(nwaves, 4, 65536, 256)), dim3(256), 0, st, amp, n_local, B);
     } else

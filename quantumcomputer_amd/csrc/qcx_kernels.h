@@ -2331,6 +2331,42 @@ __global__ __launch_bounds__(256) void k_basis_front(amp_t *__restrict__ amp, un
     }
 }
 
+// the same rule for M registers beyond the wave tile (M > 12): a workgroup per 2^M-block -- its first wave walks the block's
+// residue chain (uniform over the lanes), the whole workgroup writes the block's 2^M amplitudes with coalesced stores
+__global__ __launch_bounds__(256) void k_basis_front_big(amp_t *__restrict__ amp, unsigned n, BasisFront B)
+{
+    __shared__ unsigned s_code[2];
+    const unsigned M = B.M;
+    const uint64_t nblocks = ((uint64_t)1 << n) >> M;              // host guarantees n >= M
+    const unsigned lowmask = (1u << M) - 1u;
+    const unsigned free_low = (unsigned)(B.hmask & lowmask), sign_low = (unsigned)(B.sign_mask & lowmask);
+    const double vp = B.v, vm = -B.v;
+    for (uint64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const uint64_t bi = B.first + (blk << M);                  // GLOBAL index of the block (controls, signs, populated test)
+        if (threadIdx.x < 64) {
+            unsigned f = (unsigned)(B.basis & lowmask);
+            for (unsigned g = 0; g < B.ncam; g++)
+                if (((bi >> B.ctl[g]) & 1u) && f < B.C[g]) f = (B.A[g] * f) % B.C[g];
+            if (threadIdx.x == 0) {
+                s_code[0] = f;
+                s_code[1] = ((bi & B.fixed_mask) == (B.basis & B.fixed_mask) ? 2u : 0u) | ((unsigned)__builtin_popcountll(bi & B.sign_mask) & 1u);
+            }
+        }
+        __syncthreads();
+        const unsigned f = s_code[0], fl = s_code[1];
+        amp_t *to = amp + (blk << M);
+        for (unsigned e = threadIdx.x; e <= lowmask; e += 256) {
+            amp_t v; v.x = 0.0; v.y = 0.0;
+            if ((fl & 2u) && ((e ^ f) & ~free_low & lowmask) == 0) {
+                const unsigned sg = (fl & 1u) ^ ((unsigned)__builtin_popcount(e & sign_low) & 1u);
+                v.x = sg ? vm : vp;
+            }
+            __builtin_nontemporal_store(v, to + e);
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------
 // X1  local index-bit permutation (pack pass of the sharded qubit remap): dst[j] = src[j with the bit
 // pairs (a_m, b_m) exchanged].  Out of place, coalesced stores, gathered loads (runs of 2^min(a, b)).

@@ -44,7 +44,7 @@ def basis_state(n, b):
     return s
 
 
-@pytest.mark.parametrize("C,L,M,a", [(15, 8, 4, 7), (21, 9, 5, 2), (35, 7, 6, 2), (21, 6, 5, 2), (15, 4, 4, 7)])
+@pytest.mark.parametrize("C,L,M,a", [(15, 8, 4, 7), (21, 9, 5, 2), (35, 7, 6, 2), (21, 6, 5, 2), (15, 4, 4, 7), (8191, 4, 13, 3), (16381, 3, 14, 2)])
 def test_shor_front_from_the_reset_state(qc, ob, C, L, M, a):
     n = L + M
     descs = [(0, l, 0, 0.0, 0.0, 0, 0) for l in range(M, n)]

@@ -19,7 +19,8 @@ def tune_guard(qc):
     qc.tune(**old)
 
 
-@pytest.mark.parametrize("C,L,M,a", [(15, 3, 4, 7), (15, 8, 4, 7), (21, 9, 5, 2), (21, 14, 5, 2), (35, 7, 6, 2), (15, 12, 4, 11), (33, 10, 6, 7), (21, 6, 5, 2), (21, 3, 5, 2)])
+@pytest.mark.parametrize("C,L,M,a", [(15, 3, 4, 7), (15, 8, 4, 7), (21, 9, 5, 2), (21, 14, 5, 2), (35, 7, 6, 2), (15, 12, 4, 11), (33, 10, 6, 7), (21, 6, 5, 2), (21, 3, 5, 2),
+                                     (8191, 9, 13, 3), (16381, 7, 14, 2)])       # M > 12: a workgroup per block (k_basis_front_big)
 @pytest.mark.parametrize("mode", [0, 1])
 def test_shor_circuit_front_is_one_write_pass(qc, ob, C, L, M, a, mode):
     n = L + M

@@ -903,6 +903,13 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
             // layouts: lay[0] = identity (what the first pass reads); pass k of the chain writes lay[k + 1]; the last one the identity
             std::vector<std::vector<unsigned>> lay(m + 1, std::vector<unsigned>(n));
             for (unsigned q = 0; q < n; q++) lay[0][q] = lay[m][q] = q;
+            // which side of a pass is the gathered one (fuse_chain_dir; -1: chosen here).  Memory-bound chains (radix-8 rounds:
+            // Hadamard sweeps, tolerance mode) run better when a pass READS whole tiles and stores gathered (n = 30 sweep 19.7 vs
+            // 21.6 ms, tolerance Shor 18.9 vs 20.3); chains of the exact phase walk when a pass STORES whole tiles and the next one
+            // gathers (n = 30 Shor circuit 30.9 -> 29.7 ms: its third pass 7.6 -> 6.7)
+            bool slim_any = false;
+            for (size_t k = 0; k < m; k++) slim_any |= acts[a0 + k].P.dg_slim != 0;
+            const bool store_whole = tn.fuse_chain_dir < 0 ? !slim_any : tn.fuse_chain_dir != 0;
             for (size_t k = 0; k + 1 < m; k++) {
                 const PassShape &cur = shapes[shape_of[a0 + k]], &nxt = shapes[shape_of[a0 + k + 1]];
                 std::vector<bool> in_cur(n, false), in_nxt(n, false), placed(n, false);
@@ -912,8 +919,11 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
                 // the next tile first (it will be read as one contiguous block): the qubits both tiles hold lowest -- they are
                 // what this pass's stores are contiguous in --, then the rest of the next tile
                 for (unsigned q = 0; q < n; q++) if (in_cur[q] && in_nxt[q]) { order.push_back(q); placed[q] = true; }
-                for (unsigned q = 0; q < n; q++) if (in_nxt[q] && !placed[q]) { order.push_back(q); placed[q] = true; }
+                if (!store_whole)
+                    for (unsigned q = 0; q < n; q++) if (in_nxt[q] && !placed[q]) { order.push_back(q); placed[q] = true; }
                 // then the rest of this pass's tile (short strides for its stores), then everything else
+                // (store_whole, the other way round: THIS pass's tile is the contiguous one -- whole-tile stores, and the next
+                //  pass gathers its tile in runs of the shared qubits)
                 for (unsigned q = 0; q < n; q++) if (in_cur[q] && !placed[q]) { order.push_back(q); placed[q] = true; }
                 for (unsigned q = 0; q < n; q++) if (!placed[q]) order.push_back(q);
                 for (unsigned pos = 0; pos < n; pos++) lay[k + 1][order[pos]] = pos;
@@ -931,7 +941,7 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
             if (ok) {
                 for (size_t k = 0; k < m; k++) {
                     shapes[shape_of[a0 + k]] = ns[k];
-                    (void)pass_tables_chained(acts[a0 + k].P, n, ns[k].tl, lay[k], lay[k + 1], acts[a0 + k].P.dg_slim != 0);
+                    (void)pass_tables_chained(acts[a0 + k].P, n, ns[k].tl, lay[k], lay[k + 1], acts[a0 + k].P.dg_slim != 0 && !store_whole);
                 }
                 any = true;
             }

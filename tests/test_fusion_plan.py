@@ -359,7 +359,7 @@ def test_tolerance_mode_shard_level_lists(qc, ob, tune_guard, seed):
 
 
 # ---- chained passes (round 4): the same records under another numbering, other addresses -----------------------------------
-CHAIN_KEYS = TUNE_KEYS + ("fuse_chain", "fuse_chain_min_n", "fuse_hsweep_T", "fuse_hsweep_c")
+CHAIN_KEYS = TUNE_KEYS + ("fuse_chain", "fuse_chain_min_n", "fuse_chain_dir", "fuse_hsweep_T", "fuse_hsweep_c")
 
 
 @pytest.fixture()
@@ -395,8 +395,10 @@ def test_chained_plans_reproduce_the_oracle(qc, ob, chain_guard, n, M, Cn, mode)
         programs.append((f"random{trial}", fill_polar(qc, dd, ss), ss))
     total_chained = 0
     for name, descs, steps in programs:
-        for tune in (dict(), dict(fuse_T=10, fuse_c=4), dict(fuse_T=12, fuse_c=3)):
-            qc.tune(fuse_T=11, fuse_c=4)
+        # (fuse_chain_dir: which side of a chained pass is the gathered one -- stores (0), reads (1), by the kind of chain (-1))
+        for tune in (dict(), dict(fuse_T=10, fuse_c=4, fuse_chain_dir=0), dict(fuse_T=12, fuse_c=3, fuse_chain_dir=1), dict(fuse_chain_dir=1),
+                     dict(fuse_chain_dir=0)):
+            qc.tune(fuse_T=11, fuse_c=4, fuse_chain_dir=-1)
             qc.tune(**tune)
             actions, recs, nrec = qc.fusion_plan(n, M, descs, mode | 4)
             total_chained += emu.check_chain_addressing(n, actions)

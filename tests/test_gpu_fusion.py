@@ -327,7 +327,7 @@ def test_pure_hadamard_sweep_takes_the_three_pass_geometry_and_keeps_the_bits(qc
 # ---- chained passes (round 4): runs of passes through the register's second buffer -------------------------------------------
 @pytest.fixture()
 def chain_guard(qc):
-    keys = ("fuse_chain", "fuse_chain_min_n", "fuse_T", "fuse_c", "fuse_T_phase", "fuse_phase_ratio")
+    keys = ("fuse_chain", "fuse_chain_min_n", "fuse_chain_dir", "fuse_T", "fuse_c", "fuse_T_phase", "fuse_phase_ratio")
     old = {k: qc.lib().qcx_tune_get(k.encode()) for k in keys}
     yield
     qc.tune(**old)
@@ -352,7 +352,9 @@ def test_chained_passes_give_the_same_bits(qc, ob, chain_guard, L, M, Cn, mode):
     threads = 8
     with qc.Register(L, M) as reg:
         reg.set_fusion(mode)
-        for geom in (dict(fuse_T=11, fuse_c=4), dict(fuse_T=10, fuse_c=4), dict(fuse_T=12, fuse_c=3)):
+        # (fuse_chain_dir: the gathered side of a chained pass -- its stores (0), its reads (1), chosen by the kind of chain (-1))
+        for geom in (dict(fuse_T=11, fuse_c=4, fuse_chain_dir=-1), dict(fuse_T=10, fuse_c=4, fuse_chain_dir=0), dict(fuse_T=12, fuse_c=3, fuse_chain_dir=1),
+                     dict(fuse_T=11, fuse_c=4, fuse_chain_dir=1), dict(fuse_T=11, fuse_c=4, fuse_chain_dir=0)):
             qc.tune(**geom)
             want = ob.fill_random(n, 21)
             reg.fill_random(21)

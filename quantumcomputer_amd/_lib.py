@@ -108,6 +108,7 @@ _EXTRA = {
     "qcx_front_plan": (_i, [_u, _u, _u64, _u, _p, C.POINTER(_u), _p, C.c_size_t]),
     "qcx_chain_stats": (_i, [_p, C.POINTER(_ul)]),
     "qcx_gen_stats": (_i, [_p, C.POINTER(_ul)]),
+    "qcx_gen_cols_stats": (_i, [_p, C.POINTER(_ul)]),
 }
 
 

@@ -84,7 +84,7 @@ struct GateQueue {
     size_t   d_cap = 0;
     FuseOp  *h_ops = nullptr;       // pinned staging
     size_t   h_cap = 0;
-    unsigned long passes_launched = 0, gates_fused = 0, chained_passes = 0, gen_fronts = 0;
+    unsigned long passes_launched = 0, gates_fused = 0, chained_passes = 0, gen_fronts = 0, gen_cols = 0;
     hipEvent_t ev;                  // recorded after the last kernel of a flush: guards the record buffers
     bool     ev_valid = false;
 };
@@ -503,6 +503,13 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
         P.gen_lds_off = (uint32_t)((lut_bytes + 15) & ~(size_t)15);
         lut_bytes = P.gen_lds_off + 2 * (P.dg_slim == 2 ? 512 : 1024) * sizeof(unsigned short);
     }
+    if (P.gen == 2) {                     // the generated first pass by columns (K6g): populated columns + the records' masks in LDS
+        P.xm_off = 0;
+        const size_t lds_cols = (size_t)P.zpad * QCX_COL_STRIDE * sizeof(amp_t) + 8 * ((size_t)P.xm_cnt + 66);
+        hipLaunchKernelGGL((k_gen_cols<6>), dim3(grid), dim3(256), lds_cols, r->stream, amp_out, n, P, d_ops, ntiles, d_ops);
+        HIP_TRY(hipGetLastError());
+        return QCX_NO_ERROR;
+    }
     const size_t lds = ((size_t)16 << P.T) + lut_bytes;
     // 4 amplitudes per thread (all loads of a tile in flight at once, few registers): block = 2^T / 4
 #define QCX_FUSE_LAUNCH(B, TTv) do { \
@@ -612,13 +619,16 @@ struct PassShape {
     std::vector<unsigned> hbits;        // the tile's qubits above the low c, ascending
     std::vector<unsigned> tl;           // the tile's qubits in local order
     bool want_q3;
+    bool cols;                          // the generated first pass by columns (K6g): exact radix-4 rounds, merged diagonals expanded
     size_t n_h, n_ph, n_other;
     int nopipe;
 };
 
 static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<QGate> &gates_arg, std::vector<FuseAction> &acts, std::vector<FuseOp> &all_ops,
-                      bool tol = false, bool chain = false)
+                      bool tol = false, bool chain = false, bool first_cols = false)
 {
+    // first_cols: the list sits behind a circuit front that the first pass generates by columns (K6g, k_gen_cols): that pass takes a
+    // tile of 2^12 amplitudes = the four lowest M-register bits x 8 hot bits
     // an M register beyond the LDS tile (M > 12): its modular multiplies never join a tile pass -- stand-alone (K3b), like the table form
     std::vector<QGate> big;
     if ((unsigned)r->M > 12) { big = gates_arg; for (QGate &g : big) if (g.type == FUSE_CAMODC) g.type = 99; }
@@ -663,7 +673,7 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         std::vector<unsigned> pass_diags;
         size_t n_diag = 0;
         for (size_t k = first; k < i; k++) n_diag += gates[k].type == FUSE_DIAG;
-        bool keep_diags = tol && rounds && n_diag > 0 && n_diag <= 255;
+        bool keep_diags = tol && rounds && n_diag > 0 && n_diag <= 255 && !sh.cols;
         build_pass_ops(r, gates, first, i, tl, legacy, &specs, &gates_in, !keep_diags, &pass_diags);
         act.op_off = all_ops.size();
         if (rounds) {
@@ -783,6 +793,7 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         // n = 30), so that geometry is taken when it saves enough passes.  Passes with phases or multiplies keep theirs.
         unsigned Tcur = T, ccur = c_def;
         bool want_q3 = false;
+        const bool cols_pass = first_cols && first == 0 && n >= 14;
         {
             const unsigned Ta = (unsigned)tn.fuse_hsweep_T, ca = (unsigned)tn.fuse_hsweep_c;
             bool tail_h = Ta >= 10 && Ta <= 12 && Ta <= n && ca <= Ta && tn.fuse_rounds;
@@ -810,7 +821,7 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         // Tolerance mode: passes with merged diagonals overlap their arithmetic better on the smaller tile (2^10 amplitudes,
         // 256-thread workgroups: n = 28 inverse QFT 7.4 against 8.0 ms) -- taken when it does not cost a pass, estimated from
         // the distinct Hadamard targets above the tile's low bits in the rest of the queue.
-        if (tol && tn.fuse_tol_T >= 10 && (unsigned)tn.fuse_tol_T < Tcur && (unsigned)tn.fuse_tol_T <= n && tn.fuse_rounds) {
+        if (tol && !cols_pass && tn.fuse_tol_T >= 10 && (unsigned)tn.fuse_tol_T < Tcur && (unsigned)tn.fuse_tol_T <= n && tn.fuse_rounds) {
             bool pure = true; uint64_t hot = 0;
             for (size_t k = first; k < gates.size(); k++) {
                 if (gates[k].type == FUSE_H) { if (gates[k].q >= ccur) hot |= (uint64_t)1 << gates[k].q; }
@@ -841,10 +852,10 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         // A pass dominated by controlled phases is bound by FP64 issue and latency, not by HBM: it runs better on
         // smaller tiles (256-thread workgroups: smaller barrier domains, more of them resident), at the price of
         // fewer hot bits per pass; and never on the pipelined kernel.
-        const unsigned Tp = (unsigned)tn.fuse_T_phase;
+        const unsigned Tp = cols_pass ? 12u : (unsigned)tn.fuse_T_phase;
         if (!want_q3 && Tp >= 9 && Tp <= 12 && Tp <= n && tn.fuse_rounds && n_other == 0 &&
-            n_ph >= (size_t)tn.fuse_phase_ratio * std::max<size_t>(n_h, 1)) {
-            c = std::min((unsigned)tn.fuse_c_phase, Tp); budget = Tp - c;
+            (cols_pass || n_ph >= (size_t)tn.fuse_phase_ratio * std::max<size_t>(n_h, 1))) {
+            c = cols_pass ? 4u : std::min((unsigned)tn.fuse_c_phase, Tp); budget = Tp - c;
             grow(c, budget);
             act.nopipe = 1;
         }
@@ -870,7 +881,7 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         std::sort(hbits.begin(), hbits.end());
 
         PassShape sh;
-        sh.first = first; sh.last = i; sh.c = c; sh.hbits = hbits; sh.want_q3 = want_q3;
+        sh.first = first; sh.last = i; sh.c = c; sh.hbits = hbits; sh.want_q3 = want_q3; sh.cols = cols_pass;
         sh.n_h = n_h; sh.n_ph = n_ph; sh.n_other = n_other; sh.nopipe = act.nopipe;
         for (unsigned b = 0; b < c; b++) sh.tl.push_back(b);
         for (unsigned b : hbits) sh.tl.push_back(b);
@@ -959,7 +970,7 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         memset(&act, 0, sizeof act);
         if (emit(shapes[shape_of[a]], act)) {                      // (cannot happen: the same gates were emitted once already)
             acts.clear(); all_ops.clear();
-            fuse_plan(r, tn, gates_in, acts, all_ops, tol, false);
+            fuse_plan(r, tn, gates_in, acts, all_ops, tol, false, first_cols);
             return;
         }
         const FusePass &O = old[a].P;                             // the addressing tables were computed above
@@ -1139,7 +1150,47 @@ static int fuse_flush(qcx_register *r)
     // chains of passes go through the register's second buffer (allocated on first use; a register whose buffer pointer has
     // been handed out, a shard view and a register too large for a second buffer work in place)
     bool chain = tn.fuse_chain && r->own_stream && !r->no_chain && r->n >= (unsigned)std::max<long>(tn.fuse_chain_min_n, 13);
-    fuse_plan(r, tn, gates, acts, all_ops, r->fusion == 2, chain);
+    // The generated first pass by columns (K6g): possible when nothing of the list touches the M register (>= 4 qubits), the front
+    // left it on the orbit of ONE multiplier ladder, and that orbit populates at most 8 of the 16 values of the four lowest
+    // M-register bits per value of the others (the columns a workgroup keeps in LDS).  maxcols = that bound.
+    unsigned maxcols = 0;
+    if (gen_try && tn.fuse_gen_cols && r->M >= 4 && r->M <= 12 && r->n >= 14 && tn.fuse_ldsdma && tn.fuse_rounds_occ >= 6) {
+        const uint32_t lowmask = (1u << r->M) - 1u;
+        bool ok = (Bf.hmask & lowmask) == 0 && Bf.ncam <= 64;
+        for (const QGate &g : gates) ok &= !((g.type == FUSE_H && g.q < (unsigned)r->M) || g.type == FUSE_CAMODC || g.type == 99);
+        const uint32_t Cn = Bf.ncam ? Bf.C[0] : 0u, f0 = (uint32_t)(Bf.basis & lowmask);
+        for (unsigned g = 0; g < Bf.ncam && ok; g++) ok &= Bf.C[g] == Cn;
+        if (Bf.ncam) ok &= Cn > 0 && Cn <= 4096u && f0 < Cn;
+        if (ok && !Bf.ncam) maxcols = 1;                            // no multiplies: every populated block holds f0
+        else if (ok) {
+            std::vector<char> seen(Cn, 0);
+            std::vector<uint32_t> todo(1, f0);
+            seen[f0] = 1;
+            while (!todo.empty()) {                                 // closure under every multiplier: a superset of the subset products
+                const uint32_t x = todo.back(); todo.pop_back();
+                for (unsigned g = 0; g < Bf.ncam; g++) { const uint32_t y = (uint32_t)(((uint64_t)x * (Bf.A[g] % Cn)) % Cn); if (!seen[y]) { seen[y] = 1; todo.push_back(y); } }
+            }
+            std::vector<uint16_t> colsets(((size_t)lowmask >> 4) + 1, 0);
+            for (uint32_t x = 0; x < Cn; x++) if (seen[x] && x <= lowmask) colsets[x >> 4] |= (uint16_t)(1u << (x & 15u));
+            for (uint16_t s : colsets) maxcols = std::max(maxcols, (unsigned)__builtin_popcount(s));
+            if (maxcols > 8) maxcols = 0;
+        }
+    }
+    auto cols_shape_ok = [&]() {
+        if (acts.empty() || !acts[0].fused) return false;
+        const FusePass &P0 = acts[0].P;
+        if (P0.T != 12 || P0.c != 4 || P0.cam_ctl_local[0] != 1 || P0.has_cam || P0.dg_cnt || P0.dg_slim) return false;
+        for (unsigned j = 0; j < 4; j++) if (acts[0].tl[j] != j) return false;
+        for (unsigned j = 4; j < 12; j++) if (acts[0].tl[j] < (unsigned)r->M) return false;
+        for (size_t o = acts[0].op_off; o < acts[0].op_off + P0.nops; ) {
+            const FuseOp &hdr = all_ops[o];
+            if ((hdr.type & 0xffu) != FUSE_ROUND || (hdr.a & 0xffu) < 4 || ((hdr.a >> 8) & 0xffu) < 4) return false;
+            o += 1 + (size_t)hdr.mask;
+        }
+        return true;
+    };
+    fuse_plan(r, tn, gates, acts, all_ops, r->fusion == 2, chain, maxcols != 0);
+    if (maxcols && !cols_shape_ok()) { maxcols = 0; acts.clear(); all_ops.clear(); fuse_plan(r, tn, gates, acts, all_ops, r->fusion == 2, chain); }
     bool chained_any = false;
     for (const FuseAction &a : acts) chained_any |= a.fused && a.P.chained;
     if (chained_any && !r->scratch) {
@@ -1147,7 +1198,8 @@ static int fuse_flush(qcx_register *r)
             (void)hipGetLastError();
             r->scratch = nullptr; r->no_chain = 1;                 // no room (n = 34 fills the card): in place from now on
             acts.clear(); all_ops.clear();
-            fuse_plan(r, tn, gates, acts, all_ops, r->fusion == 2, false);
+            fuse_plan(r, tn, gates, acts, all_ops, r->fusion == 2, false, maxcols != 0);
+            if (maxcols && !cols_shape_ok()) { maxcols = 0; acts.clear(); all_ops.clear(); fuse_plan(r, tn, gates, acts, all_ops, r->fusion == 2, false); }
         }
     }
     // Behind a circuit front only a few of the 2^M low index values are populated (the multiply ladder's orbit), and no gate of
@@ -1158,6 +1210,7 @@ static int fuse_flush(qcx_register *r)
         bool h_on_m = false;
         for (const QGate &g : gates) h_on_m |= (g.type == FUSE_H && g.q < (unsigned)r->M) || g.type == FUSE_CAMODC || g.type == 99;
         for (FuseAction &a : acts) {
+            if (maxcols && &a == &acts[0]) continue;               // (the generated first pass by columns has no empty waves to skip)
             if (h_on_m || !a.fused || a.P.cam_ctl_local[0] != 1 || a.P.has_cam || a.P.dg_slim == 2 || a.P.T < 10 || a.P.T > 12) continue;
             const unsigned W = a.P.T - 8;                          // waves per workgroup = 2^W (4 amplitudes per thread)
             std::vector<unsigned> passive;                         // tile-local positions of M-register bits, by ascending qubit
@@ -1195,6 +1248,7 @@ static int fuse_flush(qcx_register *r)
             memset(&all_ops[at], 0, nrec * sizeof(FuseOp));
             memcpy(&all_ops[at], &G, sizeof G);
             acts[0].P.gen = 1;
+            if (maxcols && G.cmpmask == (1u << r->M) - 1u && G.h == 8) { acts[0].P.gen = 2; acts[0].P.zpad = (uint16_t)maxcols; gq->gen_cols++; }
             acts[0].P.gen_rec_off = (uint32_t)(at - acts[0].op_off);
             r->basis_pending = 0;                                 // (the pass that generates it is launched below; a failed launch returns its error)
             r->fronts++;

@@ -2066,6 +2066,141 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
 }
 
 // ---------------------------------------------------------------------------
+// K6g  the generated first pass of a circuit by COLUMNS (FusePass::gen = 2; bit-exact).  Behind a circuit front only a few of
+// the 2^M low index values are populated -- the residues of the multiply ladder's orbit (C = 21, a = 2: six of 32) -- and no
+// gate of an inverse QFT touches the M register, so an amplitude's low bits never change: the tile of 2^12 amplitudes =
+// 16 values of the four lowest M-register bits x 2^8 combinations of eight hot bits falls into 16 independent COLUMNS of
+// which at most a handful hold anything but +0.  The workgroup (256 threads = the 2^8 hot combinations) generates the tile
+// as GenFront says, keeps ONLY the populated columns in LDS (maxcols of them, host-computed bound from the orbit; 257
+// elements apart so that the store's column-major reads spread over the banks), and each wave takes whole columns through
+// all rounds of the pass on its own: a column is 64 lanes x 4 registers, so there is no barrier between rounds and no wave
+// without work -- the k_fused_rounds form of this pass spends half of its waves on zeros (zskip finds a quarter or three
+// quarters of a 2^10 tile empty) or, on 2^12 tiles, leaves 13 of 16 waves of a 64-KiB workgroup idle.  Empty columns are
+// stored as +0 straight from registers.  Same records, same walk (fuse_round_item), same bits.
+// ---------------------------------------------------------------------------
+#define QCX_COL_STRIDE 257u
+template <int OCC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void k_gen_cols(
+    amp_t *amp_out, unsigned n, FusePass P, const FuseOp *__restrict__ ops, uint64_t ntiles, const FuseOp *ops_asm)
+{
+    constexpr unsigned TT = 12, BLOCK = 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char qcx_lds_raw[];
+    const unsigned maxcols = P.zpad;
+    amp_t *cols = reinterpret_cast<amp_t *>(qcx_lds_raw);                         // [maxcols][QCX_COL_STRIDE]
+    unsigned char *behind = reinterpret_cast<unsigned char *>(cols + maxcols * QCX_COL_STRIDE);
+    uint64_t *xm = reinterpret_cast<uint64_t *>(behind + P.xm_off);
+    for (unsigned b = threadIdx.x; b < P.xm_cnt + 66u; b += BLOCK) xm[b] = b < P.xm_cnt ? ops[b].mask : 0;    // + padding
+    __shared__ unsigned s_mask;
+    const GenFront *GF = reinterpret_cast<const GenFront *>(ops + P.gen_rec_off);
+    // this thread IS hot combination h = threadIdx.x (tile-local bits 4 .. 11; slot h of the generated fill)
+    const unsigned h = threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned phot = GF->f0;                                                       // residue factor of the tile-local controls, times f0
+    if ((h & GF->sfm) != GF->sbv) phot = 0xffffu;
+    else if (GF->C)
+        for (unsigned g = 0; g < GF->ncam; g++)
+            if (GF->camloc[g] != 0xff && ((h >> GF->camloc[g]) & 1u)) phot = (phot * GF->camA[g]) % GF->C;
+    const uint32_t packH = gen_pack(h << 4, GF, TT);
+    const uint64_t st_t = fuse_spread(threadIdx.x, P.st_pos, TT);
+    const unsigned ld_t = (unsigned)fuse_spread(threadIdx.x, P.st_loc, TT);
+    // store order: element k * 256 + thread of the OUTPUT order; the four bits of k spread linearly (uniform values)
+    unsigned bl[4]; uint64_t bp[4];
+#pragma unroll
+    for (unsigned b = 0; b < 4; b++) { bl[b] = (unsigned)fuse_spread(256u << b, P.st_loc, TT); bp[b] = fuse_spread(256u << b, P.st_pos, TT); }
+    if (threadIdx.x == 0) s_mask = 0;
+    __syncthreads();
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const uint64_t base_in = fuse_deposit(t, P.seg_in, P.nseg_in);
+        uint64_t base = base_in, base_out = base_in;
+        if (P.chained) { base = fuse_deposit(t, P.seg_lg, P.nseg_lg); base_out = fuse_deposit(t, P.seg_out, P.nseg_out); }
+        amp_t *go = amp_out + (base_out | st_t);
+        // ---- generate: this thread's one candidate amplitude (hot combination h): its residue, column and sign ----------
+        unsigned f = 0xffffu;
+        if ((base & GF->fixed_out) == (GF->basis & GF->fixed_out) && phot != 0xffffu) {
+            f = phot;
+            if (GF->C) {
+                unsigned pt = 1;                                                  // controls outside the tile: one factor per tile
+#pragma unroll
+                for (unsigned k = 0; k < 5; k++)
+                    if ((GF->present >> k) & 1u) pt = (pt * (unsigned)GF->tabP[k][(unsigned)((base >> (8u * k)) & 255u)]) % GF->C;
+                f = (f * pt) % GF->C;
+            }
+            if ((f & GF->lowout_mask) != ((uint32_t)base & GF->lowout_mask)) f = 0xffffu;   // its low bits outside the tile belong to another tile
+        }
+        const unsigned mycol = f & 15u;
+        if (f != 0xffffu) atomicOr(&s_mask, 1u << mycol);
+        __syncthreads();
+        const unsigned mask = s_mask;
+        const unsigned ncol = (unsigned)__builtin_popcount(mask);
+        for (unsigned s = 0; s < ncol; s++) { amp_t z; z.x = 0.0; z.y = 0.0; cols[s * QCX_COL_STRIDE + h] = z; }
+        if (f != 0xffffu) {
+            const uint32_t par = ((packH >> 24) ^ (uint32_t)__builtin_popcountll(base & GF->sign_out)) & 1u;
+            amp_t a; a.x = par ? -GF->v : GF->v; a.y = 0.0;
+            cols[(unsigned)__builtin_popcount(mask & ((1u << mycol) - 1u)) * QCX_COL_STRIDE + h] = a;
+        }
+        __syncthreads();
+        // ---- rounds: every wave takes whole columns through the pass on its own --------------------------------------
+        if (!(P.dbg & 1u))
+        for (unsigned s = wave; s < ncol; s += BLOCK / 64) {
+            unsigned cpat = 0;                                                    // the column's low-bit value: the s-th set bit of mask
+            { unsigned m = mask; for (unsigned k = 0; k < s; k++) m &= m - 1u; cpat = (unsigned)__builtin_ctz(m); }
+            amp_t *col = cols + s * QCX_COL_STRIDE;
+            unsigned i = 0;
+            while (i < P.nops) {
+                const unsigned rb0 = ops[i].a & 0xffu, rb1 = (ops[i].a >> 8) & 0xffu;     // (>= 4: hot bits; the host checks)
+                const unsigned cnt = (unsigned)ops[i].mask;
+                const unsigned hh = (unsigned)insert_zero(insert_zero(lane, rb0 - 4u), rb1 - 4u);
+                const unsigned p = (hh << 4) | cpat;                                      // logical tile-local index (the walk tests its bits)
+                const unsigned l0 = hh, l1 = hh | (1u << (rb0 - 4u)), l2 = hh | (1u << (rb1 - 4u)), l3 = l1 | l2;
+                Quad q;
+                { const amp_t v0 = col[l0], v1 = col[l1], v2 = col[l2], v3 = col[l3];
+                  q.x0 = v0.x; q.y0 = v0.y; q.x1 = v1.x; q.y1 = v1.y; q.x2 = v2.x; q.y2 = v2.y; q.x3 = v3.x; q.y3 = v3.y; }
+                const bool has_h = (ops[i].a >> 16) & 1u;
+                unsigned o = i + 1;
+                const unsigned oend = i + cnt;
+                const __attribute__((address_space(3))) uint64_t *xl = (const __attribute__((address_space(3))) uint64_t *)xm + o + 1 + lane;
+                uint32_t xaddr = (uint32_t)(uintptr_t)xl;
+                uint32_t ty = ops[o].type;
+                uint64_t m = *xl;
+                do {
+                    const unsigned rc = ty >> 16;
+                    const uint64_t live = __builtin_amdgcn_ballot_w64((base & m) == m) & (rc >= 64 ? ~(uint64_t)0 : ((uint64_t)1 << rc) - 1);
+                    uint32_t tn; uint64_t mn;
+                    fuse_round_item(q, ops_asm + o, live, p, ty, xaddr, tn, mn);
+                    o += 1 + rc; ty = tn; m = mn;
+                } while (o <= oend);
+                if (has_h) {
+                    q.x0 += 0.0; q.y0 += 0.0; q.x1 += 0.0; q.y1 += 0.0; q.x2 += 0.0; q.y2 += 0.0; q.x3 += 0.0; q.y3 += 0.0;
+                }
+                { amp_t v0, v1, v2, v3;
+                  v0.x = q.x0; v0.y = q.y0; v1.x = q.x1; v1.y = q.y1; v2.x = q.x2; v2.y = q.y2; v3.x = q.x3; v3.y = q.y3;
+                  col[l0] = v0; col[l1] = v1; col[l2] = v2; col[l3] = v3; }
+                // (the column is this wave's own: its LDS accesses are served in order, no workgroup barrier between rounds)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                i += 1 + cnt;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_mask = 0;                                         // (read by everyone before the barrier above)
+        // ---- store the whole tile: populated columns from LDS, the others as +0 ------------------------------------------
+        if (!(P.dbg & 2u)) {
+#pragma unroll
+            for (unsigned k = 0; k < 16; k++) {
+                unsigned elk = 0; uint64_t offk = 0;
+#pragma unroll
+                for (unsigned b = 0; b < 4; b++) if ((k >> b) & 1u) { elk |= bl[b]; offk |= bp[b]; }
+                const unsigned el = elk | ld_t;                                   // tile-local element, in store order
+                const unsigned c = el & 15u, eh = el >> 4;
+                amp_t v; v.x = 0.0; v.y = 0.0;
+                if ((mask >> c) & 1u) v = cols[(unsigned)__builtin_popcount(mask & ((1u << c) - 1u)) * QCX_COL_STRIDE + eh];
+                __builtin_nontemporal_store(v, go + offk);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K6t-8  tolerance mode, RADIX-8 fast rounds on 2^12-amplitude tiles: a thread keeps the 8 amplitudes that differ in THREE
 // register bits, a round is up to three steps  H(x) [D(x)]  -- three Hadamards and their merged diagonals per LDS round trip
 // and per barrier instead of two, with 512-thread workgroups (8 waves) on a tile that holds 8 hot bits: the n = 28 inverse

@@ -142,8 +142,15 @@ def _gen_fronts(qc, reg):
     return out.value
 
 
+def _gen_cols(qc, reg):
+    import ctypes as C
+    out = C.c_ulong(0)
+    qc.lib().qcx_gen_cols_stats(reg._h, C.byref(out))
+    return out.value
+
+
 @pytest.mark.parametrize("mode", [0, 2], ids=["exact", "tolerance"])
-@pytest.mark.parametrize("C,L,M,a", [(21, 9, 5, 2), (21, 14, 5, 2), (15, 12, 4, 11), (33, 10, 6, 7), (35, 17, 6, 2), (21, 16, 5, 16)])
+@pytest.mark.parametrize("C,L,M,a", [(21, 9, 5, 2), (21, 14, 5, 2), (15, 12, 4, 11), (33, 10, 6, 7), (35, 17, 6, 2), (21, 16, 5, 16), (255, 9, 8, 2), (255, 12, 8, 2), (15, 13, 4, 7)])
 def test_front_generated_inside_the_first_pass(qc, ob, C, L, M, a, mode):
     """round 4: when a fused pass follows the circuit front, the front is not written at all -- the pass generates its tiles
     (GenFront) instead of reading them.  Same bits as with the separate write pass (fuse_gen = 0) and as the oracle; from
@@ -151,13 +158,17 @@ def test_front_generated_inside_the_first_pass(qc, ob, C, L, M, a, mode):
     n = L + M
     old = qc.lib().qcx_tune_get(b"fuse_gen")
     oldz = qc.lib().qcx_tune_get(b"fuse_zskip")
+    oldc = qc.lib().qcx_tune_get(b"fuse_gen_cols")
     try:
         outs = []
-        for gen, zskip in ((1, 1), (0, 1), (1, 0)):                      # (zskip: waves whose share of a tile is all +0 skip the rounds)
-            qc.tune(fuse_gen=gen, fuse_zskip=zskip)
+        # (zskip: waves whose share of a tile is all +0 skip the rounds; cols: the generated pass keeps only the populated
+        #  columns of the four lowest M-register bits, a wave per column -- k_gen_cols, n >= 14)
+        for gen, zskip, cols in ((1, 1, 1), (0, 1, 1), (1, 0, 1), (1, 1, 0)):
+            qc.tune(fuse_gen=gen, fuse_zskip=zskip, fuse_gen_cols=cols)
             with qc.Register(L, M) as reg:
                 reg.set_fusion(mode)
                 g0 = _gen_fronts(qc, reg)
+                c0 = _gen_cols(qc, reg)
                 qc.reset_register(reg); qc.quantum_computation(C, a, reg)
                 first = reg.read()
                 idx = qc.measure_state(reg, 0.41)                       # collapse: a basis state with bits inside the Hadamard set
@@ -167,12 +178,13 @@ def test_front_generated_inside_the_first_pass(qc, ob, C, L, M, a, mode):
                 second = reg.read()
                 outs.append((first, idx, second))
                 assert (_gen_fronts(qc, reg) - g0 >= 1) == bool(gen)
+                assert (_gen_cols(qc, reg) - c0 >= 1) == bool(gen and cols)     # (both modes: the tolerance mode takes the exact first pass)
         want = np.zeros(2 << n); ob.reset(want, n); ob.quantum_computation(want, n, M, C, a, threads=8)
         if mode == 0:
             assert all(np.array_equal(bits(o[0]), bits(want)) for o in outs)
         else:
             assert all(float(np.max(np.abs(o[0] - want))) <= 1e-12 for o in outs)
-        assert outs[0][1] == outs[1][1] == outs[2][1] == ob.measure(want, n, 0.41)
+        assert outs[0][1] == outs[1][1] == outs[2][1] == outs[3][1] == ob.measure(want, n, 0.41)
         w2 = want                                                        # collapsed by ob.measure
         for l in range(M, n):
             ob.hadamard(w2, n, l, 8)
@@ -182,4 +194,4 @@ def test_front_generated_inside_the_first_pass(qc, ob, C, L, M, a, mode):
         else:
             assert all(float(np.max(np.abs(o[2] - w2))) <= 1e-12 for o in outs)
     finally:
-        qc.tune(fuse_gen=old, fuse_zskip=oldz)
+        qc.tune(fuse_gen=old, fuse_zskip=oldz, fuse_gen_cols=oldc)

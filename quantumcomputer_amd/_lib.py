@@ -109,6 +109,7 @@ _EXTRA = {
     "qcx_chain_stats": (_i, [_p, C.POINTER(_ul)]),
     "qcx_gen_stats": (_i, [_p, C.POINTER(_ul)]),
     "qcx_gen_cols_stats": (_i, [_p, C.POINTER(_ul)]),
+    "qcx_compact_stats": (_i, [_p, C.POINTER(_ul)]),
 }
 
 

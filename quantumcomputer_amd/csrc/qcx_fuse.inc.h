@@ -84,7 +84,7 @@ struct GateQueue {
     size_t   d_cap = 0;
     FuseOp  *h_ops = nullptr;       // pinned staging
     size_t   h_cap = 0;
-    unsigned long passes_launched = 0, gates_fused = 0, chained_passes = 0, gen_fronts = 0, gen_cols = 0;
+    unsigned long passes_launched = 0, gates_fused = 0, chained_passes = 0, gen_fronts = 0, gen_cols = 0, compact_chains = 0;
     hipEvent_t ev;                  // recorded after the last kernel of a flush: guards the record buffers
     bool     ev_valid = false;
 };
@@ -503,7 +503,7 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
         P.gen_lds_off = (uint32_t)((lut_bytes + 15) & ~(size_t)15);
         lut_bytes = P.gen_lds_off + 2 * (P.dg_slim == 2 ? 512 : 1024) * sizeof(unsigned short);
     }
-    if (P.gen == 2) {                     // the generated first pass by columns (K6g): populated columns + the records' masks in LDS
+    if (P.gen >= 2) {                     // the generated first pass by columns (K6g; 3: of a compact chain): populated columns + the records' masks in LDS
         P.xm_off = 0;
         const size_t lds_cols = (size_t)P.zpad * QCX_COL_STRIDE * sizeof(amp_t) + 8 * ((size_t)P.xm_cnt + 66);
         hipLaunchKernelGGL((k_gen_cols<6>), dim3(grid), dim3(256), lds_cols, r->stream, amp_out, n, P, d_ops, ntiles, d_ops);
@@ -852,10 +852,11 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         // A pass dominated by controlled phases is bound by FP64 issue and latency, not by HBM: it runs better on
         // smaller tiles (256-thread workgroups: smaller barrier domains, more of them resident), at the price of
         // fewer hot bits per pass; and never on the pipelined kernel.
-        const unsigned Tp = cols_pass ? 12u : (unsigned)tn.fuse_T_phase;
+        const unsigned colb = std::min(4u, (unsigned)r->M);       // column bits of the by-columns pass: the lowest M-register bits (a compact chain's virtual register: all of them)
+        const unsigned Tp = cols_pass ? colb + 8u : (unsigned)tn.fuse_T_phase;
         if (!want_q3 && Tp >= 9 && Tp <= 12 && Tp <= n && tn.fuse_rounds && n_other == 0 &&
             (cols_pass || n_ph >= (size_t)tn.fuse_phase_ratio * std::max<size_t>(n_h, 1))) {
-            c = cols_pass ? 4u : std::min((unsigned)tn.fuse_c_phase, Tp); budget = Tp - c;
+            c = cols_pass ? colb : std::min((unsigned)tn.fuse_c_phase, Tp); budget = Tp - c;
             grow(c, budget);
             act.nopipe = 1;
         }
@@ -1115,6 +1116,171 @@ static bool gen_front_build(unsigned n, unsigned M, const BasisFront &B, const F
     return true;
 }
 
+// the records of a flush: one pinned copy, one upload
+static int upload_ops(qcx_register *r, GateQueue *gq, const std::vector<FuseOp> &all_ops)
+{
+    if (all_ops.empty()) return QCX_NO_ERROR;
+    if (gq->ev_valid) HIP_TRY(hipEventSynchronize(gq->ev));       // the previous flush may still read the buffers
+    const size_t need_ops = all_ops.size() + 1;                  // + 1: the walk prefetches one header past the last item
+    if (gq->h_cap < need_ops) {
+        if (gq->h_ops) HIP_TRY(hipHostFree(gq->h_ops));
+        gq->h_ops = nullptr; gq->h_cap = 0;
+        HIP_TRY(hipHostMalloc(&gq->h_ops, need_ops * sizeof(FuseOp)));
+        gq->h_cap = need_ops;
+    }
+    if (gq->d_cap < need_ops) {
+        if (gq->d_ops) HIP_TRY(hipFree(gq->d_ops));
+        gq->d_ops = nullptr; gq->d_cap = 0;
+        HIP_TRY(hipMalloc(&gq->d_ops, need_ops * sizeof(FuseOp)));
+        gq->d_cap = need_ops;
+    }
+    memcpy(gq->h_ops, all_ops.data(), all_ops.size() * sizeof(FuseOp));
+    memset(gq->h_ops + all_ops.size(), 0, sizeof(FuseOp));
+    HIP_TRY(hipMemcpyAsync(gq->d_ops, gq->h_ops, need_ops * sizeof(FuseOp), hipMemcpyHostToDevice, r->stream));
+    return QCX_NO_ERROR;
+}
+
+// ---- compact chains (round 4) ----------------------------------------------------------------------------------------------
+// Behind a circuit front the M register reads one of the R residues of the multiply ladder's orbit (C = 21, a = 2: six of 32
+// values) and nothing that follows in the queue touches it (an inverse QFT works on the L register): all other amplitudes
+// are +0 and stay +0.  Such a flush runs on a COMPACT copy of the state -- index [L-register bits][column], 2^cb >= R columns,
+// column j = the amplitudes whose M register reads orbit[j] -- which is a register of L + cb qubits in its own right (the
+// "virtual" register: M' = cb, qubit q of the real register is qubit q - M + cb): the first pass generates it by columns
+// (K6g, gen = 3), the ordinary planner and pass kernels take the rest of the gate list through it (chained between two
+// compact buffers carved out of the register's second buffer), and k_expand_compact writes the real register once at the
+// end: 2^(M - cb) times less memory traffic in every pass but the last write.  Same arithmetic on the same amplitudes in the
+// same order: same bits.  *done = false: not applicable, nothing was launched.
+static int compact_chain(qcx_register *r, GateQueue *gq, const Tune &tn, const BasisFront &Bf, size_t kfront, const std::vector<QGate> &gates, bool *done)
+{
+    *done = false;
+    const unsigned M = (unsigned)r->M, n = r->n, L = n - M;
+    if (!tn.fuse_compact || !tn.fuse_gen_cols || !tn.fuse_chain || !tn.fuse_ldsdma || tn.fuse_rounds_occ < 6 || !tn.fuse_rounds) return QCX_NO_ERROR;
+    if (M < 4 || M > 12 || r->no_chain || !r->own_stream || Bf.first != 0 || gates.empty()) return QCX_NO_ERROR;
+    const uint32_t lowmask = (1u << M) - 1u;
+    if ((Bf.hmask & lowmask) != 0 || Bf.ncam > 64) return QCX_NO_ERROR;
+    for (const QGate &g : gates) {
+        if (g.type == FUSE_H) { if (g.q < M) return QCX_NO_ERROR; }
+        else if (g.type == FUSE_PHASE) { if (g.mask & lowmask) return QCX_NO_ERROR; }
+        else return QCX_NO_ERROR;
+    }
+    // the orbit: closure of f0 under every multiplier (a superset of the subset products the front can reach)
+    const uint32_t Cn = Bf.ncam ? Bf.C[0] : 0u, f0 = (uint32_t)(Bf.basis & lowmask);
+    for (unsigned g = 0; g < Bf.ncam; g++) if (Bf.C[g] != Cn) return QCX_NO_ERROR;
+    std::vector<uint16_t> orbit;
+    if (!Bf.ncam) orbit.push_back((uint16_t)f0);
+    else {
+        if (Cn == 0 || Cn > 4096u || f0 >= Cn) return QCX_NO_ERROR;
+        std::vector<char> seen(Cn, 0);
+        std::vector<uint32_t> todo(1, f0);
+        seen[f0] = 1;
+        while (!todo.empty()) {
+            const uint32_t x = todo.back(); todo.pop_back();
+            for (unsigned g = 0; g < Bf.ncam; g++) { const uint32_t y = (uint32_t)(((uint64_t)x * (Bf.A[g] % Cn)) % Cn); if (!seen[y]) { seen[y] = 1; todo.push_back(y); } }
+        }
+        for (uint32_t x = 0; x < Cn; x++) if (seen[x]) { if (x > lowmask) return QCX_NO_ERROR; orbit.push_back((uint16_t)x); }
+    }
+    if (orbit.size() > 16) return QCX_NO_ERROR;
+    unsigned cb = 2;
+    while ((1u << cb) < orbit.size()) cb++;
+    if (cb + 2 > M) return QCX_NO_ERROR;                            // less than 4 x smaller: the plain paths
+    const unsigned nv = L + cb;
+    if (nv < 14 || L < 8) return QCX_NO_ERROR;
+    // the virtual register's gate list
+    std::vector<QGate> vg(gates);
+    for (QGate &g : vg) { if (g.type == FUSE_H) g.q -= M - cb; else g.mask >>= (M - cb); }
+    if (!r->scratch) {
+        if (hipMalloc(&r->scratch, r->dim * sizeof(amp_t)) != hipSuccess) { (void)hipGetLastError(); r->scratch = nullptr; r->no_chain = 1; return QCX_NO_ERROR; }
+    }
+    qcx_register v;
+    memset(&v, 0, sizeof v);
+    v.L = (int)L; v.M = (int)cb; v.n = nv; v.dim = (uint64_t)1 << nv;
+    v.amp = r->scratch; v.scratch = r->scratch + v.dim;             // (2 * 2^nv <= 2^n amplitudes: cb + 1 <= M)
+    v.own_stream = r->own_stream; v.stream = r->stream; v.fusion = r->fusion;
+    std::vector<FuseAction> acts;
+    std::vector<FuseOp> all_ops;
+    fuse_plan(&v, tn, vg, acts, all_ops, r->fusion == 2, true, true);
+    if (acts.empty() || !acts[0].fused) return QCX_NO_ERROR;
+    {
+        const FusePass &P0 = acts[0].P;
+        if (P0.T != cb + 8 || P0.c != cb || P0.cam_ctl_local[0] != 1 || P0.has_cam || P0.dg_cnt || P0.dg_slim) return QCX_NO_ERROR;
+        for (unsigned j = 0; j < cb; j++) if (acts[0].tl[j] != j) return QCX_NO_ERROR;
+        for (unsigned j = cb; j < cb + 8; j++) if (acts[0].tl[j] < cb) return QCX_NO_ERROR;
+        for (size_t o = acts[0].op_off; o < acts[0].op_off + P0.nops; ) {
+            const FuseOp &hdr = all_ops[o];
+            if ((hdr.type & 0xffu) != FUSE_ROUND || (hdr.a & 0xffu) < cb || ((hdr.a >> 8) & 0xffu) < cb) return QCX_NO_ERROR;
+            o += 1 + (size_t)hdr.mask;
+        }
+    }
+    // the generated fill of the first pass, in REAL qubit numbers (its controls, fixed bits and signs), by hot slot
+    GenFront G;
+    memset(&G, 0, sizeof G);
+    {
+        uint64_t tilemask = lowmask;
+        int slot_of[64];
+        for (unsigned q = 0; q < 64; q++) slot_of[q] = -1;
+        for (unsigned j = cb; j < cb + 8; j++) {
+            const unsigned rq = acts[0].tl[j] - cb + M, slot = j - cb;
+            slot_of[rq] = (int)slot; tilemask |= (uint64_t)1 << rq;
+            if ((Bf.sign_mask >> rq) & 1u) G.sgn_slots |= 1u << slot;
+            if ((Bf.fixed_mask >> rq) & 1u) { G.sfm |= 1u << slot; G.sbv |= (uint32_t)((Bf.basis >> rq) & 1u) << slot; }
+        }
+        G.basis = Bf.basis; G.fixed_out = Bf.fixed_mask & ~tilemask; G.sign_out = Bf.sign_mask & ~tilemask;
+        G.v = Bf.v; G.M = M; G.ncam = Bf.ncam; G.C = Bf.ncam ? Cn : 0u; G.f0 = f0;
+        G.cmpmask = lowmask; G.lowout_mask = 0; G.h = 8;
+        for (unsigned f = 0; f < 5; f++) for (unsigned b = 0; b < 256; b++) G.tabP[f][b] = 1;
+        for (unsigned g = 0; g < Bf.ncam; g++) {
+            const unsigned ctl = Bf.ctl[g];
+            G.camA[g] = Bf.A[g] % Cn;
+            if (ctl >= 40 || ctl < M) return QCX_NO_ERROR;
+            if (slot_of[ctl] >= 0) { G.camloc[g] = (uint8_t)slot_of[ctl]; continue; }
+            G.camloc[g] = 0xff;
+            const unsigned f = ctl >> 3, bit = ctl & 7u;
+            G.present |= 1u << f;
+            for (unsigned b = 0; b < 256; b++)
+                if ((b >> bit) & 1u) G.tabP[f][b] = (uint16_t)(((uint32_t)G.tabP[f][b] * G.camA[g]) % Cn);
+        }
+        G.cb = cb; G.ncols = (uint32_t)orbit.size();
+        for (size_t j = 0; j < orbit.size(); j++) G.orbit[j] = orbit[j];
+    }
+    {
+        const size_t at = all_ops.size(), nrec = (sizeof(GenFront) + sizeof(FuseOp) - 1) / sizeof(FuseOp);
+        all_ops.resize(at + nrec);
+        memset(&all_ops[at], 0, nrec * sizeof(FuseOp));
+        memcpy(&all_ops[at], &G, sizeof G);
+        acts[0].P.gen = 3;
+        acts[0].P.zpad = (uint16_t)orbit.size();
+        acts[0].P.zskip = 0;
+        acts[0].P.gen_rec_off = (uint32_t)(at - acts[0].op_off);
+    }
+    QCX_TRY(upload_ops(r, gq, all_ops));
+    for (const FuseAction &act : acts) {
+        if (!act.fused) { QCX_TRY(launch_standalone(&v, vg[act.gate])); continue; }
+        if (act.P.chained) {
+            QCX_TRY(launch_pass(&v, tn, act.P, gq->d_ops + act.op_off, act.nopipe != 0, v.amp, v.scratch));
+            std::swap(v.amp, v.scratch);
+            gq->chained_passes++;
+        } else
+            QCX_TRY(launch_pass(&v, tn, act.P, gq->d_ops + act.op_off, act.nopipe != 0, v.amp, v.amp));
+        gq->passes_launched++;
+        gq->gates_fused += act.ngates;
+    }
+    ExpandParams E;
+    memset(&E, 0, sizeof E);
+    E.M = M; E.cb = cb; E.ncols = (unsigned)orbit.size();
+    for (size_t j = 0; j < orbit.size(); j++) E.orbit[j] = orbit[j];
+    hipLaunchKernelGGL(k_expand_compact, dim3(grid_for(r->dim, 256, 65536)), dim3(256), 0, r->stream, (const amp_t *)v.amp, r->amp, r->dim, E);
+    HIP_TRY(hipGetLastError());
+    r->basis_pending = 0;
+    r->zeros_dirty = 0;
+    r->fronts++;
+    gq->gen_fronts++; gq->gen_cols++; gq->compact_chains++;
+    gq->gates_fused += kfront;
+    if (!gq->ev_valid) { HIP_TRY(hipEventCreateWithFlags(&gq->ev, hipEventDisableTiming)); gq->ev_valid = true; }
+    HIP_TRY(hipEventRecord(gq->ev, r->stream));
+    *done = true;
+    return QCX_NO_ERROR;
+}
+
 // plan -> upload every pass's records in one copy -> launch in order.  No host synchronisation except waiting for
 // the PREVIOUS flush's kernels before its record buffers are reused.
 static int fuse_flush(qcx_register *r)
@@ -1145,6 +1311,11 @@ static int fuse_flush(qcx_register *r)
     std::vector<QGate> gates;
     gates.swap(gq->gates);                       // the queue is empty from here on (re-entrancy safe)
     if (gen_try) gates.erase(gates.begin(), gates.begin() + kfront);
+    if (gen_try) {                                // the whole flush on a compact copy of the state, when the front allows it
+        bool done = false;
+        QCX_TRY(compact_chain(r, gq, tn, Bf, kfront, gates, &done));
+        if (done) return QCX_NO_ERROR;
+    }
     std::vector<FuseAction> acts;
     std::vector<FuseOp> all_ops;
     // chains of passes go through the register's second buffer (allocated on first use; a register whose buffer pointer has
@@ -1260,25 +1431,7 @@ static int fuse_flush(qcx_register *r)
         }
         gq->gates_fused += kfront;
     }
-    if (!all_ops.empty()) {
-        if (gq->ev_valid) HIP_TRY(hipEventSynchronize(gq->ev));       // the previous flush may still read the buffers
-        const size_t need_ops = all_ops.size() + 1;                  // + 1: the walk prefetches one header past the last item
-        if (gq->h_cap < need_ops) {
-            if (gq->h_ops) HIP_TRY(hipHostFree(gq->h_ops));
-            gq->h_ops = nullptr; gq->h_cap = 0;
-            HIP_TRY(hipHostMalloc(&gq->h_ops, need_ops * sizeof(FuseOp)));
-            gq->h_cap = need_ops;
-        }
-        if (gq->d_cap < need_ops) {
-            if (gq->d_ops) HIP_TRY(hipFree(gq->d_ops));
-            gq->d_ops = nullptr; gq->d_cap = 0;
-            HIP_TRY(hipMalloc(&gq->d_ops, need_ops * sizeof(FuseOp)));
-            gq->d_cap = need_ops;
-        }
-        memcpy(gq->h_ops, all_ops.data(), all_ops.size() * sizeof(FuseOp));
-        memset(gq->h_ops + all_ops.size(), 0, sizeof(FuseOp));
-        HIP_TRY(hipMemcpyAsync(gq->d_ops, gq->h_ops, need_ops * sizeof(FuseOp), hipMemcpyHostToDevice, r->stream));
-    }
+    QCX_TRY(upload_ops(r, gq, all_ops));
     for (const FuseAction &act : acts) {
         if (!act.fused) { QCX_TRY(launch_standalone(r, gates[act.gate])); continue; }
         if (act.P.chained) {

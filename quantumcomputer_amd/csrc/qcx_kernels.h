@@ -1205,6 +1205,10 @@ struct GenFront {
     uint8_t  camloc[64];                    // per multiply: slot bit of its control, 0xff = outside the tile (in the byte tables)
     uint32_t camA[64];
     uint16_t tabP[5][256];                  // product of the A_g whose control is a set bit of byte f of the base index, mod C
+    // the COMPACT form (FusePass::gen = 3, k_gen_cols on the virtual register of a compact chain): the pass's index space is
+    // [L-register bits][column number], cb column bits; column j holds the amplitudes whose M register reads orbit[j]
+    uint32_t cb, ncols, sgn_slots;          // sgn_slots: which of the tile's hot bits lie in the sign mask
+    uint16_t orbit[16];                     // the populated M-register values, ascending
 };
 
 // per-thread / per-k constant of the generated fill: slot bits | low bits << 12 | sign parity << 24 of a tile-local element index
@@ -2079,11 +2083,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
 // stored as +0 straight from registers.  Same records, same walk (fuse_round_item), same bits.
 // ---------------------------------------------------------------------------
 #define QCX_COL_STRIDE 257u
+// gen = 2: on the register itself -- tile = its four lowest M-register bits x 8 hot bits, columns = the values of those four
+//          bits, the populated ones found per tile (a tile whose other M-register bits, outside the tile, do not match a
+//          residue holds nothing there);
+// gen = 3: on the VIRTUAL register of a compact chain (qcx_fuse.inc.h) -- index = [L-register bits][column], cb column bits,
+//          column j = the amplitudes whose M register reads GenFront::orbit[j]: every column is kept, the store writes the
+//          compact layout (the real index of a tile's base is its L part shifted up by M).
 template <int OCC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void k_gen_cols(
     amp_t *amp_out, unsigned n, FusePass P, const FuseOp *__restrict__ ops, uint64_t ntiles, const FuseOp *ops_asm)
 {
-    constexpr unsigned TT = 12, BLOCK = 256;
+    constexpr unsigned BLOCK = 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char qcx_lds_raw[];
     const unsigned maxcols = P.zpad;
     amp_t *cols = reinterpret_cast<amp_t *>(qcx_lds_raw);                         // [maxcols][QCX_COL_STRIDE]
@@ -2092,17 +2102,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
     for (unsigned b = threadIdx.x; b < P.xm_cnt + 66u; b += BLOCK) xm[b] = b < P.xm_cnt ? ops[b].mask : 0;    // + padding
     __shared__ unsigned s_mask;
     const GenFront *GF = reinterpret_cast<const GenFront *>(ops + P.gen_rec_off);
-    // this thread IS hot combination h = threadIdx.x (tile-local bits 4 .. 11; slot h of the generated fill)
+    const bool compact = P.gen == 3;
+    const unsigned cb = compact ? GF->cb : 4u, TT = cb + 8u, cmask = (1u << cb) - 1u;
+    // this thread IS hot combination h = threadIdx.x (tile-local bits cb .. cb + 7; slot h of the generated fill)
     const unsigned h = threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     unsigned phot = GF->f0;                                                       // residue factor of the tile-local controls, times f0
     if ((h & GF->sfm) != GF->sbv) phot = 0xffffu;
     else if (GF->C)
         for (unsigned g = 0; g < GF->ncam; g++)
             if (GF->camloc[g] != 0xff && ((h >> GF->camloc[g]) & 1u)) phot = (phot * GF->camA[g]) % GF->C;
-    const uint32_t packH = gen_pack(h << 4, GF, TT);
+    const uint32_t parH = compact ? ((uint32_t)__builtin_popcount(h & GF->sgn_slots) & 1u) : ((gen_pack(h << 4, GF, TT) >> 24) & 1u);
     const uint64_t st_t = fuse_spread(threadIdx.x, P.st_pos, TT);
     const unsigned ld_t = (unsigned)fuse_spread(threadIdx.x, P.st_loc, TT);
-    // store order: element k * 256 + thread of the OUTPUT order; the four bits of k spread linearly (uniform values)
+    // store order: element k * 256 + thread of the OUTPUT order; the bits of k spread linearly (uniform values)
     unsigned bl[4]; uint64_t bp[4];
 #pragma unroll
     for (unsigned b = 0; b < 4; b++) { bl[b] = (unsigned)fuse_spread(256u << b, P.st_loc, TT); bp[b] = fuse_spread(256u << b, P.st_pos, TT); }
@@ -2113,27 +2125,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
         uint64_t base = base_in, base_out = base_in;
         if (P.chained) { base = fuse_deposit(t, P.seg_lg, P.nseg_lg); base_out = fuse_deposit(t, P.seg_out, P.nseg_out); }
         amp_t *go = amp_out + (base_out | st_t);
+        const uint64_t rbase = compact ? (base >> cb) << GF->M : base;            // the tile's base as an index of the REAL register
         // ---- generate: this thread's one candidate amplitude (hot combination h): its residue, column and sign ----------
         unsigned f = 0xffffu;
-        if ((base & GF->fixed_out) == (GF->basis & GF->fixed_out) && phot != 0xffffu) {
+        if ((rbase & GF->fixed_out) == (GF->basis & GF->fixed_out) && phot != 0xffffu) {
             f = phot;
             if (GF->C) {
                 unsigned pt = 1;                                                  // controls outside the tile: one factor per tile
 #pragma unroll
                 for (unsigned k = 0; k < 5; k++)
-                    if ((GF->present >> k) & 1u) pt = (pt * (unsigned)GF->tabP[k][(unsigned)((base >> (8u * k)) & 255u)]) % GF->C;
+                    if ((GF->present >> k) & 1u) pt = (pt * (unsigned)GF->tabP[k][(unsigned)((rbase >> (8u * k)) & 255u)]) % GF->C;
                 f = (f * pt) % GF->C;
             }
-            if ((f & GF->lowout_mask) != ((uint32_t)base & GF->lowout_mask)) f = 0xffffu;   // its low bits outside the tile belong to another tile
+            if (!compact && (f & GF->lowout_mask) != ((uint32_t)base & GF->lowout_mask)) f = 0xffffu;   // its low bits outside the tile belong to another tile
         }
-        const unsigned mycol = f & 15u;
-        if (f != 0xffffu) atomicOr(&s_mask, 1u << mycol);
+        unsigned mycol = f & 15u;
+        if (compact) {                                                            // column = the residue's place in the orbit
+            mycol = 0xffu;
+            for (unsigned j = 0; j < GF->ncols; j++) if (GF->orbit[j] == f) mycol = j;
+            if (mycol == 0xffu) f = 0xffffu;                                      // (cannot happen: the orbit holds every reachable residue)
+        } else if (f != 0xffffu) atomicOr(&s_mask, 1u << mycol);
         __syncthreads();
-        const unsigned mask = s_mask;
+        const unsigned mask = compact ? (1u << GF->ncols) - 1u : s_mask;
         const unsigned ncol = (unsigned)__builtin_popcount(mask);
         for (unsigned s = 0; s < ncol; s++) { amp_t z; z.x = 0.0; z.y = 0.0; cols[s * QCX_COL_STRIDE + h] = z; }
         if (f != 0xffffu) {
-            const uint32_t par = ((packH >> 24) ^ (uint32_t)__builtin_popcountll(base & GF->sign_out)) & 1u;
+            const uint32_t par = (parH ^ (uint32_t)__builtin_popcountll(rbase & GF->sign_out)) & 1u;
             amp_t a; a.x = par ? -GF->v : GF->v; a.y = 0.0;
             cols[(unsigned)__builtin_popcount(mask & ((1u << mycol) - 1u)) * QCX_COL_STRIDE + h] = a;
         }
@@ -2146,11 +2163,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
             amp_t *col = cols + s * QCX_COL_STRIDE;
             unsigned i = 0;
             while (i < P.nops) {
-                const unsigned rb0 = ops[i].a & 0xffu, rb1 = (ops[i].a >> 8) & 0xffu;     // (>= 4: hot bits; the host checks)
+                const unsigned rb0 = (ops[i].a & 0xffu) - cb, rb1 = ((ops[i].a >> 8) & 0xffu) - cb;     // (hot bits; the host checks)
                 const unsigned cnt = (unsigned)ops[i].mask;
-                const unsigned hh = (unsigned)insert_zero(insert_zero(lane, rb0 - 4u), rb1 - 4u);
-                const unsigned p = (hh << 4) | cpat;                                      // logical tile-local index (the walk tests its bits)
-                const unsigned l0 = hh, l1 = hh | (1u << (rb0 - 4u)), l2 = hh | (1u << (rb1 - 4u)), l3 = l1 | l2;
+                const unsigned hh = (unsigned)insert_zero(insert_zero(lane, rb0), rb1);
+                const unsigned p = (hh << cb) | cpat;                                     // logical tile-local index (the walk tests its bits)
+                const unsigned l0 = hh, l1 = hh | (1u << rb0), l2 = hh | (1u << rb1), l3 = l1 | l2;
                 Quad q;
                 { const amp_t v0 = col[l0], v1 = col[l1], v2 = col[l2], v3 = col[l3];
                   q.x0 = v0.x; q.y0 = v0.y; q.x1 = v1.x; q.y1 = v1.y; q.x2 = v2.x; q.y2 = v2.y; q.x3 = v3.x; q.y3 = v3.y; }
@@ -2184,19 +2201,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
         if (threadIdx.x == 0) s_mask = 0;                                         // (read by everyone before the barrier above)
         // ---- store the whole tile: populated columns from LDS, the others as +0 ------------------------------------------
         if (!(P.dbg & 2u)) {
+            const unsigned nk = 1u << cb;
 #pragma unroll
             for (unsigned k = 0; k < 16; k++) {
+                if (k >= nk) break;
                 unsigned elk = 0; uint64_t offk = 0;
 #pragma unroll
                 for (unsigned b = 0; b < 4; b++) if ((k >> b) & 1u) { elk |= bl[b]; offk |= bp[b]; }
                 const unsigned el = elk | ld_t;                                   // tile-local element, in store order
-                const unsigned c = el & 15u, eh = el >> 4;
+                const unsigned c = el & cmask, eh = el >> cb;
                 amp_t v; v.x = 0.0; v.y = 0.0;
                 if ((mask >> c) & 1u) v = cols[(unsigned)__builtin_popcount(mask & ((1u << c) - 1u)) * QCX_COL_STRIDE + eh];
                 __builtin_nontemporal_store(v, go + offk);
             }
         }
         __syncthreads();
+    }
+}
+
+// the end of a compact chain: the real register from its compact form.  real[(l << M) | f] = compact[(l << cb) | j] where
+// f = orbit[j], and +0 for every other f: one thread per real amplitude, the whole register is written (16 * 2^n bytes).
+struct ExpandParams { unsigned M, cb, ncols; uint16_t orbit[16]; };
+__global__ __launch_bounds__(256) void k_expand_compact(const amp_t *__restrict__ compact, amp_t *__restrict__ real, uint64_t count, ExpandParams E)
+{
+    const uint64_t lowmask = ((uint64_t)1 << E.M) - 1;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256) {
+        const unsigned f = (unsigned)(i & lowmask);
+        amp_t v; v.x = 0.0; v.y = 0.0;
+        unsigned j = 0xffu;
+        for (unsigned k = 0; k < E.ncols; k++) if (E.orbit[k] == f) j = k;
+        if (j != 0xffu) v = compact[((i >> E.M) << E.cb) | j];
+        __builtin_nontemporal_store(v, real + i);
     }
 }
 

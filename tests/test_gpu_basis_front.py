@@ -149,6 +149,13 @@ def _gen_cols(qc, reg):
     return out.value
 
 
+def _compact(qc, reg):
+    import ctypes as C
+    out = C.c_ulong(0)
+    qc.lib().qcx_compact_stats(reg._h, C.byref(out))
+    return out.value
+
+
 @pytest.mark.parametrize("mode", [0, 2], ids=["exact", "tolerance"])
 @pytest.mark.parametrize("C,L,M,a", [(21, 9, 5, 2), (21, 14, 5, 2), (15, 12, 4, 11), (33, 10, 6, 7), (35, 17, 6, 2), (21, 16, 5, 16), (255, 9, 8, 2), (255, 12, 8, 2), (15, 13, 4, 7)])
 def test_front_generated_inside_the_first_pass(qc, ob, C, L, M, a, mode):
@@ -159,16 +166,19 @@ def test_front_generated_inside_the_first_pass(qc, ob, C, L, M, a, mode):
     old = qc.lib().qcx_tune_get(b"fuse_gen")
     oldz = qc.lib().qcx_tune_get(b"fuse_zskip")
     oldc = qc.lib().qcx_tune_get(b"fuse_gen_cols")
+    oldk = qc.lib().qcx_tune_get(b"fuse_compact")
     try:
         outs = []
         # (zskip: waves whose share of a tile is all +0 skip the rounds; cols: the generated pass keeps only the populated
         #  columns of the four lowest M-register bits, a wave per column -- k_gen_cols, n >= 14)
-        for gen, zskip, cols in ((1, 1, 1), (0, 1, 1), (1, 0, 1), (1, 1, 0)):
-            qc.tune(fuse_gen=gen, fuse_zskip=zskip, fuse_gen_cols=cols)
+        #  compact: the whole flush on a compact copy of the state, [L register][orbit column] -- compact_chain)
+        for gen, zskip, cols, compact in ((1, 1, 1, 1), (0, 1, 1, 1), (1, 0, 1, 0), (1, 1, 0, 1), (1, 1, 1, 0)):
+            qc.tune(fuse_gen=gen, fuse_zskip=zskip, fuse_gen_cols=cols, fuse_compact=compact)
             with qc.Register(L, M) as reg:
                 reg.set_fusion(mode)
                 g0 = _gen_fronts(qc, reg)
                 c0 = _gen_cols(qc, reg)
+                k0 = _compact(qc, reg)
                 qc.reset_register(reg); qc.quantum_computation(C, a, reg)
                 first = reg.read()
                 idx = qc.measure_state(reg, 0.41)                       # collapse: a basis state with bits inside the Hadamard set
@@ -179,12 +189,14 @@ def test_front_generated_inside_the_first_pass(qc, ob, C, L, M, a, mode):
                 outs.append((first, idx, second))
                 assert (_gen_fronts(qc, reg) - g0 >= 1) == bool(gen)
                 assert (_gen_cols(qc, reg) - c0 >= 1) == bool(gen and cols)     # (both modes: the tolerance mode takes the exact first pass)
+                if (C, L, M) in ((21, 14, 5), (35, 17, 6), (21, 16, 5), (255, 12, 8), (15, 13, 4)):
+                    assert (_compact(qc, reg) - k0 >= 1) == bool(gen and cols and compact)
         want = np.zeros(2 << n); ob.reset(want, n); ob.quantum_computation(want, n, M, C, a, threads=8)
         if mode == 0:
             assert all(np.array_equal(bits(o[0]), bits(want)) for o in outs)
         else:
             assert all(float(np.max(np.abs(o[0] - want))) <= 1e-12 for o in outs)
-        assert outs[0][1] == outs[1][1] == outs[2][1] == outs[3][1] == ob.measure(want, n, 0.41)
+        assert outs[0][1] == outs[1][1] == outs[2][1] == outs[3][1] == outs[4][1] == ob.measure(want, n, 0.41)
         w2 = want                                                        # collapsed by ob.measure
         for l in range(M, n):
             ob.hadamard(w2, n, l, 8)
@@ -194,4 +206,4 @@ def test_front_generated_inside_the_first_pass(qc, ob, C, L, M, a, mode):
         else:
             assert all(float(np.max(np.abs(o[2] - w2))) <= 1e-12 for o in outs)
     finally:
-        qc.tune(fuse_gen=old, fuse_zskip=oldz, fuse_gen_cols=oldc)
+        qc.tune(fuse_gen=old, fuse_zskip=oldz, fuse_gen_cols=oldc, fuse_compact=oldk)

@@ -1268,7 +1268,8 @@ static int compact_chain(qcx_register *r, GateQueue *gq, const Tune &tn, const B
     memset(&E, 0, sizeof E);
     E.M = M; E.cb = cb; E.ncols = (unsigned)orbit.size();
     for (size_t j = 0; j < orbit.size(); j++) E.orbit[j] = orbit[j];
-    hipLaunchKernelGGL(k_expand_compact, dim3(grid_for(r->dim, 256, 65536)), dim3(256), 0, r->stream, (const amp_t *)v.amp, r->amp, r->dim, E);
+    const uint64_t nchunks = ((uint64_t)1 << L) >> 6;               // 64 blocks per workgroup iteration (L >= 8)
+    hipLaunchKernelGGL(k_expand_compact, dim3(grid_for(nchunks, 1, 65536)), dim3(256), 0, r->stream, (const amp_t *)v.amp, r->amp, nchunks, E);
     HIP_TRY(hipGetLastError());
     r->basis_pending = 0;
     r->zeros_dirty = 0;

@@ -2220,18 +2220,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
 }
 
 // the end of a compact chain: the real register from its compact form.  real[(l << M) | f] = compact[(l << cb) | j] where
-// f = orbit[j], and +0 for every other f: one thread per real amplitude, the whole register is written (16 * 2^n bytes).
+// f = orbit[j], and +0 for every other f; the whole register is written (16 * 2^n bytes).  A workgroup takes 64 blocks at a
+// time: their compact rows (64 * 2^cb amplitudes, contiguous) are staged in LDS with coalesced loads, then the 64 * 2^M real
+// amplitudes leave as coalesced nontemporal stores (a per-amplitude gather of the compact form kept a dependent load in front
+// of every store: 8.0 ms at n = 30 against 3 ms for the bytes).
 struct ExpandParams { unsigned M, cb, ncols; uint16_t orbit[16]; };
-__global__ __launch_bounds__(256) void k_expand_compact(const amp_t *__restrict__ compact, amp_t *__restrict__ real, uint64_t count, ExpandParams E)
+__global__ __launch_bounds__(256) void k_expand_compact(const amp_t *__restrict__ compact, amp_t *__restrict__ real, uint64_t nchunks, ExpandParams E)
 {
-    const uint64_t lowmask = ((uint64_t)1 << E.M) - 1;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256) {
-        const unsigned f = (unsigned)(i & lowmask);
-        amp_t v; v.x = 0.0; v.y = 0.0;
-        unsigned j = 0xffu;
-        for (unsigned k = 0; k < E.ncols; k++) if (E.orbit[k] == f) j = k;
-        if (j != 0xffu) v = compact[((i >> E.M) << E.cb) | j];
-        __builtin_nontemporal_store(v, real + i);
+    __shared__ __attribute__((aligned(16))) amp_t stage[64 << 4];
+    __shared__ unsigned char lut[1 << 12];
+    const unsigned M = E.M, cb = E.cb, lowmask = (1u << M) - 1u;
+    for (unsigned f = threadIdx.x; f <= lowmask; f += 256) {
+        unsigned char j = 0xff;
+        for (unsigned k = 0; k < E.ncols; k++) if (E.orbit[k] == f) j = (unsigned char)k;
+        lut[f] = j;
+    }
+    __syncthreads();
+    for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const amp_t *from = compact + ((chunk * 64) << cb);
+        for (unsigned e = threadIdx.x; e < (64u << cb); e += 256) stage[e] = __builtin_nontemporal_load(from + e);
+        __syncthreads();
+        amp_t *to = real + ((chunk * 64) << M);
+        for (unsigned e = threadIdx.x; e < (64u << M); e += 256) {
+            const unsigned j = lut[e & lowmask];
+            amp_t v; v.x = 0.0; v.y = 0.0;
+            if (j != 0xffu) v = stage[((e >> M) << cb) | j];
+            __builtin_nontemporal_store(v, to + e);
+        }
+        __syncthreads();
     }
 }
 

@@ -116,6 +116,7 @@ struct Tune {
     long cam_block   = 0;      // threads per workgroup of k_camodc (0: 256; 1024 for tiles of 2^12 amplitudes)
     long cam_stage_mb = 1024;  // M > 12: staging buffer of the in-place modular multiply (MiB; at least one 2^M-block)
     long fuse_compact = 1;     // behind a circuit front whose M register stays on a small orbit: the flush runs on a compact copy of the state (compact_chain)
+    long fuse_compact_lazy = 1; // ... and stays compact behind a whole-circuit entry point until something other than measure_state looks at the state
     long fuse_gen_cols = 1;    // the generated first pass by COLUMNS of the four lowest M-register bits (K6g, k_gen_cols)
     long fuse_zskip  = 1;      // passes behind a circuit front: waves whose share of the tile is all +0 skip the rounds (FusePass::zskip)
     long fuse_zskip_maxw = 2;  // ... on tiles of at most 2^(8 + this) amplitudes
@@ -153,7 +154,7 @@ static Tune tune_now() { std::lock_guard<std::mutex> lock(g_tune_mutex); return 
 extern "C" int qcx_tune_set(const char *key, long value)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); g_tune.name = value; return QCX_NO_ERROR; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_full) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_onepass) K(meas_spin_limit) K(meas_dbg) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_dir) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_gen_cols) K(fuse_compact) K(fuse_zskip) K(fuse_zskip_maxw)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_full) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_onepass) K(meas_spin_limit) K(meas_dbg) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_dir) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_gen_cols) K(fuse_compact) K(fuse_compact_lazy) K(fuse_zskip) K(fuse_zskip_maxw)
 #undef K
     return QCX_BAD_ARGUMENTS;
 }
@@ -161,7 +162,7 @@ extern "C" int qcx_tune_set(const char *key, long value)
 extern "C" long qcx_tune_get(const char *key)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); return g_tune.name; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_full) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_onepass) K(meas_spin_limit) K(meas_dbg) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_dir) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_gen_cols) K(fuse_compact) K(fuse_zskip) K(fuse_zskip_maxw)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_full) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_onepass) K(meas_spin_limit) K(meas_dbg) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_dir) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_gen_cols) K(fuse_compact) K(fuse_compact_lazy) K(fuse_zskip) K(fuse_zskip_maxw)
 #undef K
     return -1;
 }
@@ -843,6 +844,12 @@ struct qcx_register {
     int        basis_pending;   // the state IS the basis state basis_index (reset / collapse) but has not been written yet:
     uint64_t   basis_index;     // the next flush writes it, together with a closed-form gate prefix if the queue has one
     unsigned long fronts;       // basis-state fronts executed as one write pass (K0b)
+    // a compact chain left the state in its compact form (qcx_fuse.inc.h, compact_chain): r->amp is stale until expand_pending()
+    // runs -- at the next flush, unless measure_state gets there first (it scans the compact form and collapses lazily)
+    int        compact_pending;
+    amp_t     *compact_amp;     // inside r->scratch
+    unsigned   compact_cb, compact_ncols;
+    uint16_t   compact_orbit[16];
     struct ShardSet *sh;     // non-null: the register is sharded over several GPUs by this process (qcx_sharded.inc.h)
 };
 
@@ -1321,6 +1328,7 @@ extern "C" int qcx_reset_register(qcx_register *r)
     if (r->sh) return sh_reset(r->sh);
     if (r->queue) r->queue->gates.clear();         // pending gates act on a state that is being overwritten
     r->zeros_dirty = 0;
+    r->compact_pending = 0;
     if (r->fusion >= 0 && r->n >= 1) {             // lazily: the write happens at the next flush, fused with the circuit front (K0b)
         r->basis_pending = 1; r->basis_index = 1;
         return QCX_NO_ERROR;
@@ -1398,7 +1406,7 @@ struct CircuitScope {
     {
         if (!mine) return status;
         mine = false;
-        if (--r->composite == 0) { const int f = fuse_flush(r); if (status == QCX_NO_ERROR) status = f; }
+        if (--r->composite == 0) { const int f = fuse_flush(r, true); if (status == QCX_NO_ERROR) status = f; }     // (a compact chain's result may stay compact)
         return status;
     }
     ~CircuitScope() { (void)done(QCX_NO_ERROR); }
@@ -1460,8 +1468,23 @@ extern "C" int qcx_measure_state_r(qcx_register *r, double rnd, unsigned long *s
 {
     if (!r || !state_num) return QCX_BAD_ARGUMENTS;
     if (r->sh) return sh_measure(r->sh, rnd, state_num);
-    FLUSH(r);
+    QCX_TRY(fuse_flush(r, true));                                           // (a compact chain's result may stay compact)
     int found = 0; uint64_t idx = 0; double cum = 0.0;
+    if (r->compact_pending) {
+        // The scan of Q:283-292 on the compact form: the amplitudes it leaves out are +0 and add exactly nothing to the running
+        // sum, and the compact order IS the index order (orbit ascending), so the first compact element with cum >= r is the
+        // first real one -- except for r <= 0, where the reference stops at index 0 whatever it holds.
+        const unsigned M = (unsigned)r->M, cb = r->compact_cb, nv = r->n - M + cb;
+        if (rnd <= 0.0) { found = 1; idx = 0; }
+        else {
+            uint64_t last_excl = (uint64_t)1 << nv;                         // compact elements whose real index is below dim - 1
+            if (r->compact_orbit[r->compact_ncols - 1] == (1u << M) - 1u) last_excl = ((((uint64_t)1 << (r->n - M)) - 1) << cb) | (r->compact_ncols - 1);
+            uint64_t cidx = 0;
+            QCX_TRY(qcx_shard_measure_scan(r->compact_amp, nv, 0, last_excl, 0.0, rnd, &found, &cidx, &cum, r->stream));
+            if (found) idx = ((cidx >> cb) << M) | r->compact_orbit[cidx & ((1u << cb) - 1u)];
+        }
+        r->compact_pending = 0;                                             // the collapse below replaces the whole state
+    } else
     QCX_TRY(qcx_shard_measure_scan(r->amp, r->n, 0, r->dim - 1, 0.0, rnd, &found, &idx, &cum, r->stream));
     if (!found) idx = r->dim - 1;                                           // Q:283 fall-through
     r->zeros_dirty = 0;                                                     // (the collapse replaces the whole state)
@@ -1630,6 +1653,7 @@ extern "C" int qcx_state_fill_random(qcx_register *r, uint64_t seed)
     if (r->sh) return sh_fill_random(r->sh, seed);
     if (r->queue) r->queue->gates.clear();
     r->basis_pending = 0;                           // everything is overwritten
+    r->compact_pending = 0;
     r->zeros_dirty = 0;
     // U(-0.5, 0.5) components have variance 1/12: this scale makes the expected norm 1
     return qcx_shard_fill_random(r->amp, r->n, 0, seed, sqrt(6.0 / (double)r->dim), r->stream);

@@ -1150,7 +1150,23 @@ static int upload_ops(qcx_register *r, GateQueue *gq, const std::vector<FuseOp> 
 // compact buffers carved out of the register's second buffer), and k_expand_compact writes the real register once at the
 // end: 2^(M - cb) times less memory traffic in every pass but the last write.  Same arithmetic on the same amplitudes in the
 // same order: same bits.  *done = false: not applicable, nothing was launched.
-static int compact_chain(qcx_register *r, GateQueue *gq, const Tune &tn, const BasisFront &Bf, size_t kfront, const std::vector<QGate> &gates, bool *done)
+// the real register from a pending compact form
+static int expand_pending(qcx_register *r)
+{
+    if (!r->compact_pending) return QCX_NO_ERROR;
+    ExpandParams E;
+    memset(&E, 0, sizeof E);
+    E.M = (unsigned)r->M; E.cb = r->compact_cb; E.ncols = r->compact_ncols;
+    for (unsigned j = 0; j < r->compact_ncols; j++) E.orbit[j] = r->compact_orbit[j];
+    const uint64_t nchunks = ((uint64_t)1 << (r->n - (unsigned)r->M)) >> 6;  // 64 blocks per workgroup iteration (L >= 8)
+    hipLaunchKernelGGL(k_expand_compact, dim3(grid_for(nchunks, 1, 65536)), dim3(256), 0, r->stream, (const amp_t *)r->compact_amp, r->amp, nchunks, E);
+    HIP_TRY(hipGetLastError());
+    r->compact_pending = 0;
+    return QCX_NO_ERROR;
+}
+
+// keep: leave the result in its compact form (r->compact_pending; measure_state reads it there, everything else expands it first)
+static int compact_chain(qcx_register *r, GateQueue *gq, const Tune &tn, const BasisFront &Bf, size_t kfront, const std::vector<QGate> &gates, bool keep, bool *done)
 {
     *done = false;
     const unsigned M = (unsigned)r->M, n = r->n, L = n - M;
@@ -1264,13 +1280,10 @@ static int compact_chain(qcx_register *r, GateQueue *gq, const Tune &tn, const B
         gq->passes_launched++;
         gq->gates_fused += act.ngates;
     }
-    ExpandParams E;
-    memset(&E, 0, sizeof E);
-    E.M = M; E.cb = cb; E.ncols = (unsigned)orbit.size();
-    for (size_t j = 0; j < orbit.size(); j++) E.orbit[j] = orbit[j];
-    const uint64_t nchunks = ((uint64_t)1 << L) >> 6;               // 64 blocks per workgroup iteration (L >= 8)
-    hipLaunchKernelGGL(k_expand_compact, dim3(grid_for(nchunks, 1, 65536)), dim3(256), 0, r->stream, (const amp_t *)v.amp, r->amp, nchunks, E);
-    HIP_TRY(hipGetLastError());
+    r->compact_pending = 1;
+    r->compact_amp = v.amp; r->compact_cb = cb; r->compact_ncols = (unsigned)orbit.size();
+    for (size_t j = 0; j < orbit.size(); j++) r->compact_orbit[j] = orbit[j];
+    if (!keep) QCX_TRY(expand_pending(r));
     r->basis_pending = 0;
     r->zeros_dirty = 0;
     r->fronts++;
@@ -1284,10 +1297,15 @@ static int compact_chain(qcx_register *r, GateQueue *gq, const Tune &tn, const B
 
 // plan -> upload every pass's records in one copy -> launch in order.  No host synchronisation except waiting for
 // the PREVIOUS flush's kernels before its record buffers are reused.
-static int fuse_flush(qcx_register *r)
+static int fuse_flush(qcx_register *r, bool keep_compact = false)
 {
     GateQueue *gq = r->queue;
     const Tune tn = tune_now();
+    if (r->compact_pending) {                    // an earlier flush left the state compact
+        if (keep_compact && (!gq || gq->gates.empty()) && !r->basis_pending) return QCX_NO_ERROR;
+        if (r->basis_pending) r->compact_pending = 0;       // (a reset / collapse came after it: the compact form is history)
+        else QCX_TRY(expand_pending(r));
+    }
     // A lazily pending reset / collapse: the register IS a basis state that has not been written.  The closed-form front of
     // the queue (Hadamards, then the multiply ladder) is either written by a pass of its own (K0b) or -- when a fused pass
     // follows it -- generated tile by tile inside that pass (GenFront): no write pass, and that pass reads nothing.
@@ -1314,7 +1332,7 @@ static int fuse_flush(qcx_register *r)
     if (gen_try) gates.erase(gates.begin(), gates.begin() + kfront);
     if (gen_try) {                                // the whole flush on a compact copy of the state, when the front allows it
         bool done = false;
-        QCX_TRY(compact_chain(r, gq, tn, Bf, kfront, gates, &done));
+        QCX_TRY(compact_chain(r, gq, tn, Bf, kfront, gates, keep_compact && tn.fuse_compact_lazy, &done));
         if (done) return QCX_NO_ERROR;
     }
     std::vector<FuseAction> acts;

@@ -207,3 +207,54 @@ def test_front_generated_inside_the_first_pass(qc, ob, C, L, M, a, mode):
             assert all(float(np.max(np.abs(o[2] - w2))) <= 1e-12 for o in outs)
     finally:
         qc.tune(fuse_gen=old, fuse_zskip=oldz, fuse_gen_cols=oldc, fuse_compact=oldk)
+
+
+@pytest.mark.parametrize("mode", [0, 2], ids=["exact", "tolerance"])
+@pytest.mark.parametrize("C,L,M,a", [(21, 14, 5, 2), (35, 13, 6, 2), (15, 13, 4, 7), (255, 12, 8, 2), (32, 12, 5, 31)])
+def test_measurement_on_the_compact_form(qc, ob, C, L, M, a, mode):
+    """a whole-circuit entry point may leave the state in the compact form of its chain ([L register][orbit column]):
+    measure_state scans it there -- the amplitudes it leaves out are +0 -- and must return the index the reference's scan of
+    the whole register returns, for draws over the whole range (r = 0 stops at index 0 whatever it holds; C = 32, a = 31 with
+    M = 5 puts the register's last index, which the scan never examines, on the orbit {1, 31}); every other observer sees the expanded state."""
+    n = L + M
+    want = np.zeros(2 << n); ob.reset(want, n); ob.quantum_computation(want, n, M, C, a, threads=8)
+    tot = float((want ** 2).sum())
+    old = {k: qc.lib().qcx_tune_get(k.encode()) for k in ("fuse_compact", "fuse_compact_lazy")}
+    try:
+        for lazy in (1, 0):
+            qc.tune(fuse_compact=1, fuse_compact_lazy=lazy)
+            with qc.Register(L, M) as reg:
+                reg.set_fusion(mode)
+                k0 = _compact(qc, reg)
+                for r in (0.0, 1e-12, 0.1, 0.37, 0.5, 0.93, 0.999999, tot, 1.0 - 1e-16, 1.5):
+                    qc.reset_register(reg)
+                    qc.quantum_computation(C, a, reg)
+                    idx = qc.measure_state(reg, r)
+                    w = want.copy()
+                    if mode == 0:
+                        assert idx == ob.measure(w, n, r), (lazy, r)
+                    else:                                   # the tolerance mode's sums differ in the last bits: the draw must fall next to the same boundary
+                        cum = np.cumsum((want.reshape(-1, 2) ** 2).sum(axis=1))
+                        lo = int(np.searchsorted(cum, r - 1e-9)); hi = int(np.searchsorted(cum, r + 1e-9))
+                        assert (r <= 0.0 and idx == 0) or lo <= idx <= max(hi, lo) or idx == (1 << n) - 1, (lazy, r, idx, lo, hi)
+                    got = reg.read()                        # the collapsed state, materialised by the read
+                    assert got[2 * idx] == 1.0 and float(np.abs(got).sum()) == 1.0
+                assert _compact(qc, reg) - k0 == 10
+                # not a measurement: the observer sees the expanded state
+                qc.reset_register(reg)
+                qc.quantum_computation(C, a, reg)
+                assert abs(reg.norm2() - tot) < 1e-12
+                got = reg.read()
+                if mode == 0:
+                    assert np.array_equal(bits(got), bits(want))
+                else:
+                    assert float(np.max(np.abs(got - want))) <= 1e-12
+                # gates queued behind a compact state run on the expanded one
+                qc.reset_register(reg)
+                qc.quantum_computation(C, a, reg)
+                qc.hadamard_gate(n - 1, reg); qc.hadamard_gate(0, reg)
+                w2 = want.copy(); ob.hadamard(w2, n, n - 1, 8); ob.hadamard(w2, n, 0, 8)
+                got = reg.read()
+                assert np.array_equal(bits(got), bits(w2)) if mode == 0 else float(np.max(np.abs(got - w2))) <= 1e-12
+    finally:
+        qc.tune(**old)

@@ -9,7 +9,7 @@ rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 out = []
 for r in rows:
     n = r["Kernel_Name"]
-    if any(k in n for k in ("k_fused", "k_gen_cols", "k_basis_front", "k_meas_onepass", "k_h_pair", "k_h_wave")) and int(r["Grid_Size_X"]) >= 4096:
+    if any(k in n for k in ("k_fused", "k_gen_cols", "k_expand_compact", "k_basis_front", "k_meas_onepass", "k_h_pair", "k_h_wave")) and int(r["Grid_Size_X"]) >= 4096:
         short = n[n.find("k_"):].split("(")[0].replace("k_fused_", "").replace(" ", "")
         out.append(f"{short}:{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6:.2f}")
 print(" ".join(out))

@@ -506,7 +506,9 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
     if (P.gen >= 2) {                     // the generated first pass by columns (K6g; 3: of a compact chain): populated columns + the records' masks in LDS
         P.xm_off = 0;
         const size_t lds_cols = (size_t)P.zpad * QCX_COL_STRIDE * sizeof(amp_t) + 8 * ((size_t)P.xm_cnt + 66);
-        hipLaunchKernelGGL((k_gen_cols<6>), dim3(grid), dim3(256), lds_cols, r->stream, amp_out, n, P, d_ops, ntiles, d_ops);
+        // (four waves; one wave per column -- six for the orbit of N = 21 -- is slower: 5.3 against 3.8 ms at n = 30, the extra waves idle through generation and store)
+        const unsigned waves = (unsigned)std::min<long>(8, std::max<long>(4, tn.fuse_cols_waves));
+        hipLaunchKernelGGL((k_gen_cols<6>), dim3(grid), dim3(64 * waves), lds_cols, r->stream, amp_out, n, P, d_ops, ntiles, d_ops);
         HIP_TRY(hipGetLastError());
         return QCX_NO_ERROR;
     }

@@ -2089,25 +2089,29 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
 // gen = 3: on the VIRTUAL register of a compact chain (qcx_fuse.inc.h) -- index = [L-register bits][column], cb column bits,
 //          column j = the amplitudes whose M register reads GenFront::orbit[j]: every column is kept, the store writes the
 //          compact layout (the real index of a tile's base is its L part shifted up by M).
+// Launched with 64 * W threads, W = 4 ... 8 (fuse_cols_waves; 4 by default): the first 256 threads generate and store the tile,
+// further waves only walk columns.
 template <int OCC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void k_gen_cols(
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC))) void k_gen_cols(
     amp_t *amp_out, unsigned n, FusePass P, const FuseOp *__restrict__ ops, uint64_t ntiles, const FuseOp *ops_asm)
 {
     constexpr unsigned BLOCK = 256;
+    const unsigned nthreads = blockDim.x, nwaves = blockDim.x >> 6;
+    const bool worker = threadIdx.x < BLOCK;                                      // takes part in generating and storing
     extern __shared__ __attribute__((aligned(16))) unsigned char qcx_lds_raw[];
     const unsigned maxcols = P.zpad;
     amp_t *cols = reinterpret_cast<amp_t *>(qcx_lds_raw);                         // [maxcols][QCX_COL_STRIDE]
     unsigned char *behind = reinterpret_cast<unsigned char *>(cols + maxcols * QCX_COL_STRIDE);
     uint64_t *xm = reinterpret_cast<uint64_t *>(behind + P.xm_off);
-    for (unsigned b = threadIdx.x; b < P.xm_cnt + 66u; b += BLOCK) xm[b] = b < P.xm_cnt ? ops[b].mask : 0;    // + padding
+    for (unsigned b = threadIdx.x; b < P.xm_cnt + 66u; b += nthreads) xm[b] = b < P.xm_cnt ? ops[b].mask : 0;    // + padding
     __shared__ unsigned s_mask;
     const GenFront *GF = reinterpret_cast<const GenFront *>(ops + P.gen_rec_off);
     const bool compact = P.gen == 3;
     const unsigned cb = compact ? GF->cb : 4u, TT = cb + 8u, cmask = (1u << cb) - 1u;
     // this thread IS hot combination h = threadIdx.x (tile-local bits cb .. cb + 7; slot h of the generated fill)
-    const unsigned h = threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned h = threadIdx.x & 255u, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     unsigned phot = GF->f0;                                                       // residue factor of the tile-local controls, times f0
-    if ((h & GF->sfm) != GF->sbv) phot = 0xffffu;
+    if (!worker || (h & GF->sfm) != GF->sbv) phot = 0xffffu;
     else if (GF->C)
         for (unsigned g = 0; g < GF->ncam; g++)
             if (GF->camloc[g] != 0xff && ((h >> GF->camloc[g]) & 1u)) phot = (phot * GF->camA[g]) % GF->C;
@@ -2148,7 +2152,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
         __syncthreads();
         const unsigned mask = compact ? (1u << GF->ncols) - 1u : s_mask;
         const unsigned ncol = (unsigned)__builtin_popcount(mask);
-        for (unsigned s = 0; s < ncol; s++) { amp_t z; z.x = 0.0; z.y = 0.0; cols[s * QCX_COL_STRIDE + h] = z; }
+        if (worker) for (unsigned s = 0; s < ncol; s++) { amp_t z; z.x = 0.0; z.y = 0.0; cols[s * QCX_COL_STRIDE + h] = z; }
         if (f != 0xffffu) {
             const uint32_t par = (parH ^ (uint32_t)__builtin_popcountll(rbase & GF->sign_out)) & 1u;
             amp_t a; a.x = par ? -GF->v : GF->v; a.y = 0.0;
@@ -2157,7 +2161,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
         __syncthreads();
         // ---- rounds: every wave takes whole columns through the pass on its own --------------------------------------
         if (!(P.dbg & 1u))
-        for (unsigned s = wave; s < ncol; s += BLOCK / 64) {
+        for (unsigned s = wave; s < ncol; s += nwaves) {
             unsigned cpat = 0;                                                    // the column's low-bit value: the s-th set bit of mask
             { unsigned m = mask; for (unsigned k = 0; k < s; k++) m &= m - 1u; cpat = (unsigned)__builtin_ctz(m); }
             amp_t *col = cols + s * QCX_COL_STRIDE;
@@ -2200,7 +2204,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
         __syncthreads();
         if (threadIdx.x == 0) s_mask = 0;                                         // (read by everyone before the barrier above)
         // ---- store the whole tile: populated columns from LDS, the others as +0 ------------------------------------------
-        if (!(P.dbg & 2u)) {
+        if (worker && !(P.dbg & 2u)) {
             const unsigned nk = 1u << cb;
 #pragma unroll
             for (unsigned k = 0; k < 16; k++) {

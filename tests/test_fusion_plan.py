@@ -435,3 +435,51 @@ def test_chain_of_the_n30_sweep_and_the_n28_iqft(qc, chain_guard):
     actions, recs, nrec = qc.fusion_plan(n, 0, iqft_descs(qc, n, 0), 2 | 4)
     assert [a.fused for a in actions] == [1, 1, 1] and [a.chained for a in actions] == [1, 1, 1]
     assert [int(x) for x in actions[1].in_pos[:12]] == list(range(12)) and [int(x) for x in actions[2].in_pos[:12]] == list(range(12))
+
+
+# ---- compact chains (round 4): the gate list of an inverse QFT on the VIRTUAL register [L register][orbit column] -------------
+@pytest.mark.parametrize("mode", [1, 2], ids=["exact", "tolerance"])
+@pytest.mark.parametrize("C,L,M,a", [(21, 9, 5, 2), (15, 10, 4, 7), (35, 8, 6, 2)])
+def test_compact_register_premise(qc, ob, chain_guard, C, L, M, a, mode):
+    """what compact_chain (csrc/qcx_fuse.inc.h) relies on, without a GPU: behind the circuit front the state lives on the
+    orbit's residues; gathered into [L register][column] it is a register of L + cb qubits whose gate list is the inverse
+    QFT's with every qubit shifted by M - cb, and running THAT through the planner's passes (chained, as on the GPU) and
+    spreading the result back gives the bits the oracle gets on the whole register (1e-12 in the tolerance mode)."""
+    n = L + M
+    state = np.zeros(2 << n); ob.reset(state, n)
+    for l in range(M, n):
+        ob.hadamard(state, n, l)
+    x = a % C
+    for l in range(M, n):
+        ob.camodc(state, n, M, C, x, l); x = (x * x) % C
+    orbit = sorted({pow(a, e, C) for e in range(4 * C)})
+    amp = state.reshape(-1, 2)
+    low = np.arange(1 << n) & ((1 << M) - 1)
+    assert not np.any(amp[~np.isin(low, orbit)]), "amplitudes off the orbit are exactly zero"
+    cb = 2
+    while (1 << cb) < len(orbit):
+        cb += 1
+    assert cb + 2 <= M
+    nv = L + cb
+    comp = np.zeros((1 << nv, 2))
+    for j, f in enumerate(orbit):
+        comp[(np.arange(1 << L) << cb) | j] = amp[(np.arange(1 << L) << M) | f]
+    comp = comp.reshape(-1).copy()
+    vdescs = iqft_descs(qc, nv, cb)                       # the inverse QFT of the virtual register: same angles, shifted qubits
+    rdescs = iqft_descs(qc, n, M)
+    assert [(d[0], d[3], d[4]) for d in vdescs] == [(d[0], d[3], d[4]) for d in rdescs]
+    qc.tune(fuse_T=11, fuse_c=4)
+    actions, recs, nrec = qc.fusion_plan(nv, cb, vdescs, mode | 4)
+    emu.check_chain_addressing(nv, actions)
+    emu.run_plan(comp, nv, cb, vdescs, actions, recs, ob)
+    want = state.copy(); ob.iqft(want, n, M)
+    got = np.zeros((1 << n, 2))
+    cc = comp.reshape(-1, 2)
+    for j, f in enumerate(orbit):
+        got[(np.arange(1 << L) << M) | f] = cc[(np.arange(1 << L) << cb) | j]
+    got = got.reshape(-1)
+    if mode == 1:
+        assert np.array_equal(bits(got), bits(want))
+    else:
+        assert float(np.max(np.abs(got - want))) <= 1e-12
+    assert not np.any(cc[(np.arange(1 << nv) & ((1 << cb) - 1)) >= len(orbit)]), "unused columns stay zero"

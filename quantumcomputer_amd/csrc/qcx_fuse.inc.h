@@ -1118,6 +1118,42 @@ static bool gen_front_build(unsigned n, unsigned M, const BasisFront &B, const F
     return true;
 }
 
+// zero-wave skipping (FusePass::zskip) for the passes of a flush whose M register no gate touches: the wave number rides on
+// M-register bits of the tile.  skip_first: the first pass is the generated one by columns (no empty waves there).
+static void zskip_setup(std::vector<FuseAction> &acts, std::vector<FuseOp> &all_ops, unsigned M, const Tune &tn, bool skip_first)
+{
+    for (FuseAction &a : acts) {
+        if (skip_first && &a == &acts[0]) continue;
+        if (!a.fused || a.P.cam_ctl_local[0] != 1 || a.P.has_cam || a.P.dg_slim == 2 || a.P.T < 10 || a.P.T > 12) continue;
+        const unsigned W = a.P.T - 8;                          // waves per workgroup = 2^W (4 amplitudes per thread)
+        std::vector<unsigned> passive;                         // tile-local positions of M-register bits, by ascending qubit
+        for (unsigned q = 0; q < M; q++)
+            for (unsigned j = 0; j < a.P.T; j++) if (a.tl[j] == q) passive.push_back(j);
+        if (passive.size() < W || W > (unsigned)tn.fuse_zskip_maxw) continue;          // (W = 3: the lanes' LDS stride costs 8-way bank conflicts -- the 2^11 pass of the n = 30 Shor circuit 7.4 -> 8.7 ms)
+        std::vector<unsigned> z(passive.end() - W, passive.end());
+        std::sort(z.begin(), z.end());
+        a.P.zskip = (uint8_t)W;
+        a.P.zlist = 0;
+        for (unsigned j = 0; j < W; j++) { a.P.zb[j] = (uint8_t)z[j]; a.P.zlist |= (uint64_t)z[j] << (8 * j); }
+        // every round's header gets the sorted list of the positions its threads' lane numbers leave out: zb[] + its register bits
+        bool ok = true;
+        for (size_t o = a.op_off; o < a.op_off + a.P.nops && ok; ) {
+            FuseOp &h = all_ops[o];
+            const uint32_t ty = h.type & 0xffu;
+            if (ty != FUSE_ROUND && ty != FUSE_QROUND) { ok = false; break; }
+            std::vector<unsigned> e(z);
+            e.push_back(h.a & 0xffu); e.push_back((h.a >> 8) & 0xffu);
+            std::sort(e.begin(), e.end());
+            for (size_t k = 1; k < e.size(); k++) ok &= e[k] != e[k - 1];          // (a register bit among the zb[]: cannot happen -- no Hadamard on the M register)
+            uint64_t list = 0;
+            for (size_t k = 0; k < e.size(); k++) list |= (uint64_t)e[k] << (8 * k);
+            memcpy(&h.c, &list, sizeof list);
+            o += 1 + (size_t)h.mask;
+        }
+        if (!ok) a.P.zskip = 0;
+    }
+}
+
 // the records of a flush: one pinned copy, one upload
 static int upload_ops(qcx_register *r, GateQueue *gq, const std::vector<FuseOp> &all_ops)
 {
@@ -1229,6 +1265,9 @@ static int compact_chain(qcx_register *r, GateQueue *gq, const Tune &tn, const B
             o += 1 + (size_t)hdr.mask;
         }
     }
+    // (columns beyond the orbit hold nothing -- 2 of 8 for the six residues of N = 21 -- but letting the waves that sit on them
+    //  skip the rounds of the later passes, zskip_setup, does not pay: 2.50 / 2.09 ms against 2.28 / 1.96 for the two 2^10-tile
+    //  passes at n = 30: the busy waves are a tile's critical path either way, and the lanes' stride costs bank conflicts)
     // the generated fill of the first pass, in REAL qubit numbers (its controls, fixed bits and signs), by hot slot
     GenFront G;
     memset(&G, 0, sizeof G);
@@ -1401,36 +1440,7 @@ static int fuse_flush(qcx_register *r, bool keep_compact = false)
     if (front_flush && tn.fuse_zskip && r->M >= 2) {
         bool h_on_m = false;
         for (const QGate &g : gates) h_on_m |= (g.type == FUSE_H && g.q < (unsigned)r->M) || g.type == FUSE_CAMODC || g.type == 99;
-        for (FuseAction &a : acts) {
-            if (maxcols && &a == &acts[0]) continue;               // (the generated first pass by columns has no empty waves to skip)
-            if (h_on_m || !a.fused || a.P.cam_ctl_local[0] != 1 || a.P.has_cam || a.P.dg_slim == 2 || a.P.T < 10 || a.P.T > 12) continue;
-            const unsigned W = a.P.T - 8;                          // waves per workgroup = 2^W (4 amplitudes per thread)
-            std::vector<unsigned> passive;                         // tile-local positions of M-register bits, by ascending qubit
-            for (unsigned q = 0; q < (unsigned)r->M; q++)
-                for (unsigned j = 0; j < a.P.T; j++) if (a.tl[j] == q) passive.push_back(j);
-            if (passive.size() < W || W > (unsigned)tn.fuse_zskip_maxw) continue;          // (W = 3: the lanes' LDS stride costs 8-way bank conflicts -- the 2^11 pass of the n = 30 Shor circuit 7.4 -> 8.7 ms)
-            std::vector<unsigned> z(passive.end() - W, passive.end());
-            std::sort(z.begin(), z.end());
-            a.P.zskip = (uint8_t)W;
-            a.P.zlist = 0;
-            for (unsigned j = 0; j < W; j++) { a.P.zb[j] = (uint8_t)z[j]; a.P.zlist |= (uint64_t)z[j] << (8 * j); }
-            // every round's header gets the sorted list of the positions its threads' lane numbers leave out: zb[] + its register bits
-            bool ok = true;
-            for (size_t o = a.op_off; o < a.op_off + a.P.nops && ok; ) {
-                FuseOp &h = all_ops[o];
-                const uint32_t ty = h.type & 0xffu;
-                if (ty != FUSE_ROUND && ty != FUSE_QROUND) { ok = false; break; }
-                std::vector<unsigned> e(z);
-                e.push_back(h.a & 0xffu); e.push_back((h.a >> 8) & 0xffu);
-                std::sort(e.begin(), e.end());
-                for (size_t k = 1; k < e.size(); k++) ok &= e[k] != e[k - 1];          // (a register bit among the zb[]: cannot happen -- no Hadamard on the M register)
-                uint64_t list = 0;
-                for (size_t k = 0; k < e.size(); k++) list |= (uint64_t)e[k] << (8 * k);
-                memcpy(&h.c, &list, sizeof list);
-                o += 1 + (size_t)h.mask;
-            }
-            if (!ok) a.P.zskip = 0;
-        }
+        if (!h_on_m) zskip_setup(acts, all_ops, (unsigned)r->M, tn, maxcols != 0);
     }
     if (gen_try) {
         GenFront G;

@@ -505,10 +505,15 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
     }
     if (P.gen >= 2) {                     // the generated first pass by columns (K6g; 3: of a compact chain): populated columns + the records' masks in LDS
         P.xm_off = 0;
-        const size_t lds_cols = (size_t)P.zpad * QCX_COL_STRIDE * sizeof(amp_t) + 8 * ((size_t)P.xm_cnt + 66);
+        size_t lds_cols = (size_t)P.zpad * QCX_COL_STRIDE * sizeof(amp_t) + 8 * ((size_t)P.xm_cnt + 66);
+        if (P.dg_cnt) {                                            // tolerance mode: E_out slots and G tables of the merged diagonals
+            P.dg_lds_off = (uint32_t)((8 * ((size_t)P.xm_cnt + 66) + 15) & ~(size_t)15);
+            lds_cols = (size_t)P.zpad * QCX_COL_STRIDE * sizeof(amp_t) + P.dg_lds_off + 16 * (size_t)P.dg_cnt * 49;
+        }
         // (four waves; one wave per column -- six for the orbit of N = 21 -- is slower: 5.3 against 3.8 ms at n = 30, the extra waves idle through generation and store)
         const unsigned waves = (unsigned)std::min<long>(8, std::max<long>(4, tn.fuse_cols_waves));
-        hipLaunchKernelGGL((k_gen_cols<6>), dim3(grid), dim3(64 * waves), lds_cols, r->stream, amp_out, n, P, d_ops, ntiles, d_ops);
+        if (P.dg_cnt) hipLaunchKernelGGL((k_gen_cols<6, true>), dim3(grid), dim3(64 * waves), lds_cols, r->stream, amp_out, n, P, d_ops, ntiles, d_ops);
+        else hipLaunchKernelGGL((k_gen_cols<6, false>), dim3(grid), dim3(64 * waves), lds_cols, r->stream, amp_out, n, P, d_ops, ntiles, d_ops);
         HIP_TRY(hipGetLastError());
         return QCX_NO_ERROR;
     }
@@ -621,15 +626,16 @@ struct PassShape {
     std::vector<unsigned> hbits;        // the tile's qubits above the low c, ascending
     std::vector<unsigned> tl;           // the tile's qubits in local order
     bool want_q3;
-    bool cols;                          // the generated first pass by columns (K6g): exact radix-4 rounds, merged diagonals expanded
+    bool cols;                          // the generated first pass by columns (K6g): radix-4 rounds; merged diagonals expanded unless cols_tol
+    bool cols_tol;
     size_t n_h, n_ph, n_other;
     int nopipe;
 };
 
 static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<QGate> &gates_arg, std::vector<FuseAction> &acts, std::vector<FuseOp> &all_ops,
-                      bool tol = false, bool chain = false, bool first_cols = false)
+                      bool tol = false, bool chain = false, int first_cols = 0)
 {
-    // first_cols: the list sits behind a circuit front that the first pass generates by columns (K6g, k_gen_cols): that pass takes a
+    // first_cols (1; 2: it may keep merged diagonals): the list sits behind a circuit front that the first pass generates by columns (K6g, k_gen_cols): that pass takes a
     // tile of 2^12 amplitudes = the four lowest M-register bits x 8 hot bits
     // an M register beyond the LDS tile (M > 12): its modular multiplies never join a tile pass -- stand-alone (K3b), like the table form
     std::vector<QGate> big;
@@ -675,7 +681,7 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         std::vector<unsigned> pass_diags;
         size_t n_diag = 0;
         for (size_t k = first; k < i; k++) n_diag += gates[k].type == FUSE_DIAG;
-        bool keep_diags = tol && rounds && n_diag > 0 && n_diag <= 255 && !sh.cols;
+        bool keep_diags = tol && rounds && n_diag > 0 && n_diag <= 255 && (!sh.cols || sh.cols_tol);
         build_pass_ops(r, gates, first, i, tl, legacy, &specs, &gates_in, !keep_diags, &pass_diags);
         act.op_off = all_ops.size();
         if (rounds) {
@@ -884,7 +890,7 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         std::sort(hbits.begin(), hbits.end());
 
         PassShape sh;
-        sh.first = first; sh.last = i; sh.c = c; sh.hbits = hbits; sh.want_q3 = want_q3; sh.cols = cols_pass;
+        sh.first = first; sh.last = i; sh.c = c; sh.hbits = hbits; sh.want_q3 = want_q3; sh.cols = cols_pass; sh.cols_tol = cols_pass && first_cols == 2;
         sh.n_h = n_h; sh.n_ph = n_ph; sh.n_other = n_other; sh.nopipe = act.nopipe;
         for (unsigned b = 0; b < c; b++) sh.tl.push_back(b);
         for (unsigned b : hbits) sh.tl.push_back(b);
@@ -1252,16 +1258,17 @@ static int compact_chain(qcx_register *r, GateQueue *gq, const Tune &tn, const B
     v.own_stream = r->own_stream; v.stream = r->stream; v.fusion = r->fusion;
     std::vector<FuseAction> acts;
     std::vector<FuseOp> all_ops;
-    fuse_plan(&v, tn, vg, acts, all_ops, r->fusion == 2, true, true);
+    fuse_plan(&v, tn, vg, acts, all_ops, r->fusion == 2, true, (r->fusion == 2 && tn.fuse_cols_tol) ? 2 : 1);
     if (acts.empty() || !acts[0].fused) return QCX_NO_ERROR;
     {
         const FusePass &P0 = acts[0].P;
-        if (P0.T != cb + 8 || P0.c != cb || P0.cam_ctl_local[0] != 1 || P0.has_cam || P0.dg_cnt || P0.dg_slim) return QCX_NO_ERROR;
+        if (P0.T != cb + 8 || P0.c != cb || P0.cam_ctl_local[0] != 1 || P0.has_cam || P0.dg_slim == 2 || P0.dg_cnt > 64) return QCX_NO_ERROR;
         for (unsigned j = 0; j < cb; j++) if (acts[0].tl[j] != j) return QCX_NO_ERROR;
         for (unsigned j = cb; j < cb + 8; j++) if (acts[0].tl[j] < cb) return QCX_NO_ERROR;
         for (size_t o = acts[0].op_off; o < acts[0].op_off + P0.nops; ) {
             const FuseOp &hdr = all_ops[o];
-            if ((hdr.type & 0xffu) != FUSE_ROUND || (hdr.a & 0xffu) < cb || ((hdr.a >> 8) & 0xffu) < cb) return QCX_NO_ERROR;
+            const uint32_t ty = hdr.type & 0xffu;
+            if ((ty != FUSE_ROUND && !(ty == FUSE_QROUND && P0.dg_cnt)) || (hdr.a & 0xffu) < cb || ((hdr.a >> 8) & 0xffu) < cb) return QCX_NO_ERROR;
             o += 1 + (size_t)hdr.mask;
         }
     }

@@ -1788,6 +1788,26 @@ __device__ __forceinline__ void qround_run(amp_t *tile, unsigned p, unsigned e1,
     tile[p] = v0; tile[e1] = v1; tile[e2] = v2; tile[e3] = v3;
 }
 
+// the same fast round on a COLUMN of k_gen_cols: the four amplitudes sit at l0 .. l3 of the column, p is their logical
+// tile-local index (the table look-ups want its bits)
+template <bool HA, bool HB>
+__device__ __forceinline__ void qround_run_col(amp_t *col, unsigned l0, unsigned l1, unsigned l2, unsigned l3, unsigned p, unsigned rb0, unsigned rb1,
+                                               uint32_t sA, uint32_t sB, const amp_t *dg, const amp_t *gtab)
+{
+    amp_t F, F3;
+    F.x = F3.x = 1.0; F.y = F3.y = 0.0;
+    const bool dA = (sA & 2u) != 0, two = sB != 0xffffffffu, dB = two && (sB & 2u);
+    amp_t v0 = col[l0], v1 = col[l1], v2 = col[l2], v3 = col[l3];
+    if (dA) qround_factors(sA, p, rb0, rb1, dg, gtab, F, F3);
+    if (HA) qround_step(dA, v0, v2, v1, v3, F, F3); else qround_step(dA, v0, v1, v2, v3, F, F3);
+    __builtin_amdgcn_sched_barrier(0);
+    if (two) {
+        if (dB) qround_factors(sB, p, rb0, rb1, dg, gtab, F, F3);
+        if (HB) qround_step(dB, v0, v2, v1, v3, F, F3); else qround_step(dB, v0, v1, v2, v3, F, F3);
+    }
+    col[l0] = v0; col[l1] = v1; col[l2] = v2; col[l3] = v3;
+}
+
 // zero-wave skipping (FusePass::zskip): the element index of a thread when the wave number rides on the tile-local bits zb[]
 // and the lane number on the remaining positions, ascending.  `list` = the positions to leave out of the lane number (the zb[]
 // and, inside a round, its register bits), ascending, one per byte (the host sorts them: FusePass::zlist for the whole tile,
@@ -2091,7 +2111,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
 //          compact layout (the real index of a tile's base is its L part shifted up by M).
 // Launched with 64 * W threads, W = 4 ... 8 (fuse_cols_waves; 4 by default): the first 256 threads generate and store the tile,
 // further waves only walk columns.
-template <int OCC>
+template <int OCC, bool TOL = false>     // TOL: the pass holds merged diagonals (tolerance mode): fast rounds run as in k_fused_rounds<.., TOL>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC))) void k_gen_cols(
     amp_t *amp_out, unsigned n, FusePass P, const FuseOp *__restrict__ ops, uint64_t ntiles, const FuseOp *ops_asm)
 {
@@ -2105,6 +2125,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC))) void
     uint64_t *xm = reinterpret_cast<uint64_t *>(behind + P.xm_off);
     for (unsigned b = threadIdx.x; b < P.xm_cnt + 66u; b += nthreads) xm[b] = b < P.xm_cnt ? ops[b].mask : 0;    // + padding
     __shared__ unsigned s_mask;
+    // tolerance mode: [E_out slot per diagonal][G tables, 48 entries per diagonal] in LDS; the tables are staged once
+    amp_t *dg = reinterpret_cast<amp_t *>(behind + P.dg_lds_off);
+    const amp_t *dg_area = reinterpret_cast<const amp_t *>(ops + P.dg_rec_off);
+    if constexpr (TOL)
+        for (unsigned b = threadIdx.x; b < P.dg_cnt * 48u; b += nthreads) dg[P.dg_cnt + b] = dg_area[3u * P.dg_cnt + b];
     const GenFront *GF = reinterpret_cast<const GenFront *>(ops + P.gen_rec_off);
     const bool compact = P.gen == 3;
     const unsigned cb = compact ? GF->cb : 4u, TT = cb + 8u, cmask = (1u << cb) - 1u;
@@ -2143,6 +2168,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC))) void
             }
             if (!compact && (f & GF->lowout_mask) != ((uint32_t)base & GF->lowout_mask)) f = 0xffffu;   // its low bits outside the tile belong to another tile
         }
+        if constexpr (TOL) {
+            // E_out of this tile for every diagonal of the pass: one thread each (read by the rounds, behind the barriers below)
+            if (threadIdx.x < P.dg_cnt) {
+                const DiagInfo *info = reinterpret_cast<const DiagInfo *>(dg_area) + threadIdx.x;
+                const uint32_t present = info->present;
+                amp_t E; E.x = info->kc; E.y = info->ks;
+#pragma unroll
+                for (unsigned k = 0; k < 5; k++)
+                    if ((present >> k) & 1u) cmul_tol(E, dg_area[info->field_off[k] + (unsigned)((base >> (8u * k)) & 255u)]);
+                dg[threadIdx.x] = E;
+            }
+        }
         unsigned mycol = f & 15u;
         if (compact) {                                                            // column = the residue's place in the orbit
             mycol = 0xffu;
@@ -2172,6 +2209,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC))) void
                 const unsigned hh = (unsigned)insert_zero(insert_zero(lane, rb0), rb1);
                 const unsigned p = (hh << cb) | cpat;                                     // logical tile-local index (the walk tests its bits)
                 const unsigned l0 = hh, l1 = hh | (1u << rb0), l2 = hh | (1u << rb1), l3 = l1 | l2;
+                if (TOL && (ops[i].type & 0xffu) == FUSE_QROUND) {
+                    const amp_t *gtab = dg + P.dg_cnt;
+                    const uint32_t sA = ops[i + 1].type, sB = ops[i + 1].a;
+                    if (sA & 1u) { if (sB & 1u) qround_run_col<true, true>(col, l0, l1, l2, l3, p, rb0 + cb, rb1 + cb, sA, sB, dg, gtab);
+                                   else         qround_run_col<true, false>(col, l0, l1, l2, l3, p, rb0 + cb, rb1 + cb, sA, sB, dg, gtab); }
+                    else         { if (sB & 1u) qround_run_col<false, true>(col, l0, l1, l2, l3, p, rb0 + cb, rb1 + cb, sA, sB, dg, gtab);
+                                   else         qround_run_col<false, false>(col, l0, l1, l2, l3, p, rb0 + cb, rb1 + cb, sA, sB, dg, gtab); }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                    i += 2;
+                    continue;
+                }
                 Quad q;
                 { const amp_t v0 = col[l0], v1 = col[l1], v2 = col[l2], v3 = col[l3];
                   q.x0 = v0.x; q.y0 = v0.y; q.x1 = v1.x; q.y1 = v1.y; q.x2 = v2.x; q.y2 = v2.y; q.x3 = v3.x; q.y3 = v3.y; }

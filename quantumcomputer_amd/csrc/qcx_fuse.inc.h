@@ -1106,6 +1106,7 @@ static bool gen_front_build(unsigned n, unsigned M, const BasisFront &B, const F
     G->sign_out = B.sign_mask & ~tilemask;
     G->v = B.v;
     G->M = M; G->ncam = B.ncam; G->C = B.ncam ? C : 0u; G->f0 = f0;
+    G->Cinv = G->C ? (uint32_t)(((uint64_t)1 << 32) / G->C) : 0u;
     G->cmpmask = ~(uint32_t)(B.hmask & lowmask) & lowmask;
     G->lowout_mask = lowmask & ~(uint32_t)tilemask;
     for (unsigned f = 0; f < 5; f++) for (unsigned b = 0; b < 256; b++) G->tabP[f][b] = 1;
@@ -1290,6 +1291,7 @@ static int compact_chain(qcx_register *r, GateQueue *gq, const Tune &tn, const B
         }
         G.basis = Bf.basis; G.fixed_out = Bf.fixed_mask & ~tilemask; G.sign_out = Bf.sign_mask & ~tilemask;
         G.v = Bf.v; G.M = M; G.ncam = Bf.ncam; G.C = Bf.ncam ? Cn : 0u; G.f0 = f0;
+        G.Cinv = G.C ? (uint32_t)(((uint64_t)1 << 32) / G.C) : 0u;
         G.cmpmask = lowmask; G.lowout_mask = 0; G.h = 8;
         for (unsigned f = 0; f < 5; f++) for (unsigned b = 0; b < 256; b++) G.tabP[f][b] = 1;
         for (unsigned g = 0; g < Bf.ncam; g++) {

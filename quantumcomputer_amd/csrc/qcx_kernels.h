@@ -1208,6 +1208,7 @@ struct GenFront {
     // the COMPACT form (FusePass::gen = 3, k_gen_cols on the virtual register of a compact chain): the pass's index space is
     // [L-register bits][column number], cb column bits; column j holds the amplitudes whose M register reads orbit[j]
     uint32_t cb, ncols, sgn_slots;          // sgn_slots: which of the tile's hot bits lie in the sign mask
+    uint32_t Cinv;                          // floor(2^32 / C): x mod C without a division (k_gen_cols; x < 2^32)
     uint16_t orbit[16];                     // the populated M-register values, ascending
 };
 
@@ -2103,6 +2104,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
 // stored as +0 straight from registers.  Same records, same walk (fuse_round_item), same bits.
 // ---------------------------------------------------------------------------
 #define QCX_COL_STRIDE 257u
+// x mod C with the host's Cinv = floor(2^32 / C): the quotient estimate is at most one short
+__device__ __forceinline__ unsigned gen_mod(unsigned x, unsigned C, unsigned Cinv)
+{
+    unsigned r = x - __umulhi(x, Cinv) * C;
+    return r >= C ? r - C : r;
+}
 // gen = 2: on the register itself -- tile = its four lowest M-register bits x 8 hot bits, columns = the values of those four
 //          bits, the populated ones found per tile (a tile whose other M-register bits, outside the tile, do not match a
 //          residue holds nothing there);
@@ -2139,7 +2146,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC))) void
     if (!worker || (h & GF->sfm) != GF->sbv) phot = 0xffffu;
     else if (GF->C)
         for (unsigned g = 0; g < GF->ncam; g++)
-            if (GF->camloc[g] != 0xff && ((h >> GF->camloc[g]) & 1u)) phot = (phot * GF->camA[g]) % GF->C;
+            if (GF->camloc[g] != 0xff && ((h >> GF->camloc[g]) & 1u)) phot = gen_mod(phot * GF->camA[g], GF->C, GF->Cinv);
     const uint32_t parH = compact ? ((uint32_t)__builtin_popcount(h & GF->sgn_slots) & 1u) : ((gen_pack(h << 4, GF, TT) >> 24) & 1u);
     const uint64_t st_t = fuse_spread(threadIdx.x, P.st_pos, TT);
     const unsigned ld_t = (unsigned)fuse_spread(threadIdx.x, P.st_loc, TT);
@@ -2163,8 +2170,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC))) void
                 unsigned pt = 1;                                                  // controls outside the tile: one factor per tile
 #pragma unroll
                 for (unsigned k = 0; k < 5; k++)
-                    if ((GF->present >> k) & 1u) pt = (pt * (unsigned)GF->tabP[k][(unsigned)((rbase >> (8u * k)) & 255u)]) % GF->C;
-                f = (f * pt) % GF->C;
+                    if ((GF->present >> k) & 1u) pt = gen_mod(pt * (unsigned)GF->tabP[k][(unsigned)((rbase >> (8u * k)) & 255u)], GF->C, GF->Cinv);
+                f = gen_mod(f * pt, GF->C, GF->Cinv);
             }
             if (!compact && (f & GF->lowout_mask) != ((uint32_t)base & GF->lowout_mask)) f = 0xffffu;   // its low bits outside the tile belong to another tile
         }

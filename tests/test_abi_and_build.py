@@ -123,11 +123,13 @@ def test_gate_kernels_have_no_fma():
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     txt = open(s_path).read()
-    # FMA appears in ONE place only: the opt-in tolerance-mode pass kernels (k_fused_rounds<..., TOL = 1 or 2> and k_fused_q3, K6t); every
-    # bit-exact kernel -- per-gate kernels, the exact fused passes, measurement, exchange -- is free of it
+    # FMA appears in ONE place only: the opt-in tolerance-mode pass kernels (k_fused_rounds<..., TOL = 1 or 2>, k_fused_q3 and
+    # k_gen_cols<.., TOL = true>, K6t); every bit-exact kernel -- per-gate kernels, the exact fused passes (k_gen_cols<.., false>
+    # among them), measurement, exchange -- is free of it
     funcs = {m.group(1): txt[m.start():txt.find(".Lfunc_end", m.start())] for m in re.finditer(r"^(_Z\w+):", txt, re.M)}
     with_fma = [name for name, body in funcs.items() if re.search(r"v_fma_f64|v_fmac_f64|v_pk_fma_f64", body)]
-    assert with_fma and all(re.match(r"_ZN3qcx14k_fused_roundsILi\d+ELi\d+ELi\d+ELb[01]ELi[12]ELb[01]EE|_ZN3qcx10k_fused_q3ILi\d+ELi\d+ELi\d+ELb0ELb[01]EE", name) for name in with_fma), with_fma
+    assert with_fma and all(re.match(r"_ZN3qcx14k_fused_roundsILi\d+ELi\d+ELi\d+ELb[01]ELi[12]ELb[01]EE|_ZN3qcx10k_fused_q3ILi\d+ELi\d+ELi\d+ELb0ELb[01]EE|_ZN3qcx10k_gen_colsILi\d+ELb1EE", name) for name in with_fma), with_fma
+    assert any(re.match(r"_ZN3qcx10k_gen_colsILi\d+ELb0EE", name) for name in funcs), "the exact by-columns kernel"
     assert any(re.match(r"_ZN3qcx10k_fused_q3ILi\d+ELi\d+ELi\d+ELb1ELb[01]EE", name) for name in funcs), "the exact radix-8 Hadamard kernel"
     assert txt.count("global_load_dwordx4") > 50            # 16-B amplitude accesses everywhere
     # the "+ 0.0" canonicalisation must survive optimisation in the Hadamard kernels

@@ -2,6 +2,8 @@
 measurement are lazy: the next flush writes the basis state together with the longest queue prefix of the shape
 "Hadamards on distinct qubits, then controlled modular multiplies" -- the front of quantum_computation (Q:720-731) -- in
 closed form, with the reference's own roundings.  Everything here is bit for bit against the oracle."""
+import math
+
 import numpy as np
 import pytest
 
@@ -258,3 +260,40 @@ def test_measurement_on_the_compact_form(qc, ob, C, L, M, a, mode):
                 assert np.array_equal(bits(got), bits(w2)) if mode == 0 else float(np.max(np.abs(got - w2))) <= 1e-12
     finally:
         qc.tune(**old)
+
+
+@pytest.mark.parametrize("mode", [1, 2], ids=["exact (every gate queued)", "tolerance"])
+@pytest.mark.parametrize("seed", range(6))
+def test_compact_chain_under_random_programs(qc, ob, seed, mode):
+    """behind the front ANY program of Hadamards and controlled phases on the L register qualifies for a compact chain, not
+    only the inverse QFT's schedule: random programs (the planner then produces stand-alone gates, single-Hadamard rounds,
+    several chains ...) against the oracle; a second batch of gates, queued behind the compact result, runs on the expanded state"""
+    rs = np.random.RandomState(4000 + seed)
+    C, M, a = [(21, 5, 2), (15, 4, 7), (35, 6, 2), (255, 8, 2), (33, 6, 7), (21, 5, 16)][seed]
+    L = int(rs.randint(11, 15))
+    n = L + M
+    want = np.zeros(2 << n); ob.reset(want, n)
+    with qc.Register(L, M) as reg:
+        reg.set_fusion(mode)
+        k0 = _compact(qc, reg)
+        qc.reset_register(reg)
+        for l in range(M, n):
+            qc.hadamard_gate(l, reg); ob.hadamard(want, n, l, 8)
+        x = a % C
+        for l in range(M, n):
+            qc.c_amodc_gate(C, x, l, reg); ob.camodc(want, n, M, C, x, l, 8); x = (x * x) % C
+        for batch in range(2):
+            for _ in range(int(rs.randint(30, 90))):
+                if rs.randint(0, 3) == 0:
+                    q = int(rs.randint(M, n)); qc.hadamard_gate(q, reg); ob.hadamard(want, n, q, 8)
+                else:
+                    c, t = (int(v) for v in rs.choice(np.arange(M, n), 2, replace=False))
+                    th = float(rs.uniform(-3.2, 3.2)) if rs.randint(0, 2) else math.pi / (1 << int(rs.randint(1, 12)))
+                    qc.c_phase_shift_gate(c, t, th, reg); ob.cphase(want, n, c, t, th, 8)
+            got = reg.read()
+            if mode == 1:
+                assert np.array_equal(bits(got), bits(want)), (seed, batch)
+            else:
+                assert float(np.max(np.abs(got - want))) <= 1e-12, (seed, batch)
+            if batch == 0 and L + max(2, (len({pow(a, e, C) for e in range(4 * C)}) - 1).bit_length()) >= 14:
+                assert _compact(qc, reg) - k0 == 1, "the first flush ran as a compact chain"

@@ -120,7 +120,10 @@ unsigned qcx_ref_int_pow(double base, double power);
 /* ---- gate fusion (no reference counterpart) ------------
  * Queued gates are executed as fused passes (one HBM round trip applies many gates to LDS-resident
  * tiles); in modes -1, 0 and 1 results are bit-identical to the per-gate kernels.  Every call that observes the state
- * flushes the queue; qcx_flush does so explicitly.
+ * flushes the queue; qcx_flush does so explicitly.  Behind reset_register + the front of quantum_computation (Hadamard layer,
+ * multiply ladder) a flush may run on a COMPACT copy of the state -- only the M-register values of the ladder's orbit can hold
+ * anything but +0 -- and a whole-circuit entry point may leave its result in that form: qcx_measure_state reads it there,
+ * every other observer (qcx_flush included) first expands it into the register.  Same bits either way.
  *   enable =  0 (default): a gate call launches its own kernel; the whole-circuit entry points
  *                (qcx_inverse_QFT, qcx_quantum_computation) hand their complete gate list to the pass scheduler
  *   enable =  1: every gate call is queued

@@ -1301,7 +1301,7 @@ extern "C" int qcx_gen_cols_stats(qcx_register *r, unsigned long *by_columns)
 extern "C" int qcx_compact_stats(qcx_register *r, unsigned long *compact_chains)
 {
     if (!r || !compact_chains) return QCX_BAD_ARGUMENTS;
-    *compact_chains = (!r->sh && r->queue) ? r->queue->compact_chains : 0;
+    *compact_chains = r->sh ? r->sh->compact_circuits : (r->queue ? r->queue->compact_chains : 0);
     return QCX_NO_ERROR;
 }
 

@@ -2613,6 +2613,31 @@ __global__ __launch_bounds__(256) void k_basis_front_big(amp_t *__restrict__ amp
     }
 }
 
+// the circuit front written straight in the COMPACT form of a compact chain ([L register][orbit column], cb column bits): one
+// thread per 2^M-block of the real register walks the block's residue chain and writes the block's 2^cb compact amplitudes
+// (the one at its residue's place in the orbit = +/- v, the others +0).  B.first = REAL global index of the shard's amplitude 0.
+__global__ __launch_bounds__(256) void k_basis_front_compact(amp_t *__restrict__ compact, unsigned n_local_compact, BasisFront B, ExpandParams E)
+{
+    const unsigned M = B.M, cb = E.cb;
+    const uint64_t nblocks = ((uint64_t)1 << n_local_compact) >> cb;
+    const unsigned lowmask = (1u << M) - 1u;
+    for (uint64_t blk = (uint64_t)blockIdx.x * 256 + threadIdx.x; blk < nblocks; blk += (uint64_t)gridDim.x * 256) {
+        const uint64_t bi = B.first + (blk << M);
+        unsigned f = (unsigned)(B.basis & lowmask);
+        for (unsigned g = 0; g < B.ncam; g++)
+            if (((bi >> B.ctl[g]) & 1u) && f < B.C[g]) f = (B.A[g] * f) % B.C[g];
+        unsigned col = 0xffu;
+        if ((bi & B.fixed_mask) == (B.basis & B.fixed_mask))
+            for (unsigned j = 0; j < E.ncols; j++) if (E.orbit[j] == f) col = j;
+        const double v = (__builtin_popcountll(bi & B.sign_mask) & 1) ? -B.v : B.v;
+        amp_t *to = compact + (blk << cb);
+        for (unsigned j = 0; j < (1u << cb); j++) {
+            amp_t a; a.x = (j == col) ? v : 0.0; a.y = 0.0;
+            to[j] = a;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // X1  local index-bit permutation (pack pass of the sharded qubit remap): dst[j] = src[j with the bit
 // pairs (a_m, b_m) exchanged].  Out of place, coalesced stores, gathered loads (runs of 2^min(a, b)).

@@ -71,6 +71,8 @@ struct ShardSet {
     bool     staged = false;                      // no peer access between some of the devices (or QCX_SHARD_FORCE_STAGED=1): a trade packs into the
                                                   // shard's OWN spare buffer and the chunks travel by hipMemcpyPeerAsync (no peer stores, no relays)
     bool     zeros_dirty = false;                 // the caller wrote amplitudes: one k_canon_zeros pass per shard before the next gate (Q:393-413)
+    ShardSet *comp = nullptr;                     // the COMPANION register of compact circuits (sh_compact): L + cb qubits on the same devices, created on first use
+    unsigned long compact_circuits = 0;
     int      fusion = 1;                          // 1: each shard's gate list goes through the fused-pass scheduler; -1/0: one launch per gate
     size_t   max_queue = 8192;
     std::string trace;
@@ -120,6 +122,7 @@ static void sh_drop_relays(ShardSet *sh)
 static void sh_free(ShardSet *sh)
 {
     if (!sh) return;
+    if (sh->comp) { sh_free(sh->comp); sh->comp = nullptr; }
     if (!sh->dry) {
         sh_drop_relays(sh);
         for (unsigned r = 0; r < sh->W; r++) {
@@ -593,8 +596,122 @@ static int sh_materialize_basis(ShardSet *sh)
     return QCX_NO_ERROR;
 }
 
+static int sh_flush(ShardSet *sh);
+static int sh_identity(ShardSet *sh);
+static int sh_set_relays(ShardSet *sh, unsigned nrelays, const int *devices);
+
+// Compact circuits on a sharded register (the sharded form of compact_chain, qcx_fuse.inc.h).  Behind the circuit front the M
+// register reads one of the residues of the multiply ladder's orbit, and when nothing else in the queue touches it the whole
+// queue runs on a COMPANION register of L + cb qubits -- [L register][orbit column], the same shards on the same devices,
+// 2^(M - cb) times smaller -- with the unchanged machinery (fused passes per shard, trades of the shard-id qubits: 2^(M - cb)
+// times fewer bytes over the links); every shard then expands its part into the real register.  The front is written in the
+// compact form directly (k_basis_front_compact).  *done = false: not applicable, nothing happened.
+static int sh_compact(ShardSet *sh, bool *done)
+{
+    *done = false;
+    const Tune tn = tune_now();
+    const unsigned M = sh->M, L = (unsigned)sh->L;
+    if (sh->dry || !tn.fuse_compact || !tn.fuse_front || sh->fusion <= 0 || sh->in_selfcheck || M < 4 || M > 12 || sh->n_local < M + 6) return QCX_NO_ERROR;
+    std::vector<QGate> qg;                          // (the layout is the identity: sh_reset set it)
+    for (const SGate &g : sh->queue) {
+        QGate q; memset(&q, 0, sizeof q);
+        if (g.type == FUSE_H) { q.type = FUSE_H; q.q = g.q; }
+        else if (g.type == FUSE_CAMODC && camodc_closed_form(sh->n, sh->M, g.C, g.A % g.C, g.q)) { q.type = FUSE_CAMODC; q.q = g.q; q.C = g.C; q.A = g.A; }
+        else break;
+        qg.push_back(q);
+    }
+    BasisFront B;
+    const size_t used = front_plan(sh->n, M, 1, tn, qg, &B);
+    if (!used || used >= sh->queue.size()) return QCX_NO_ERROR;
+    const uint32_t lowmask = (1u << M) - 1u;
+    if ((B.hmask & lowmask) != 0 || B.ncam > 64) return QCX_NO_ERROR;
+    for (size_t i = used; i < sh->queue.size(); i++) {
+        const SGate &g = sh->queue[i];
+        if (g.type == FUSE_H) { if (g.q < M) return QCX_NO_ERROR; }
+        else if (g.type == FUSE_PHASE) { if (g.q < M || g.q2 < M) return QCX_NO_ERROR; }
+        else return QCX_NO_ERROR;
+    }
+    const uint32_t Cn = B.ncam ? B.C[0] : 0u, f0 = (uint32_t)(B.basis & lowmask);
+    for (unsigned g = 0; g < B.ncam; g++) if (B.C[g] != Cn) return QCX_NO_ERROR;
+    std::vector<uint16_t> orbit;
+    if (!B.ncam) orbit.push_back((uint16_t)f0);
+    else {
+        if (Cn == 0 || Cn > 4096u || f0 >= Cn) return QCX_NO_ERROR;
+        std::vector<char> seen(Cn, 0);
+        std::vector<uint32_t> todo(1, f0);
+        seen[f0] = 1;
+        while (!todo.empty()) {
+            const uint32_t x = todo.back(); todo.pop_back();
+            for (unsigned g = 0; g < B.ncam; g++) { const uint32_t y = (uint32_t)(((uint64_t)x * (B.A[g] % Cn)) % Cn); if (!seen[y]) { seen[y] = 1; todo.push_back(y); } }
+        }
+        for (uint32_t x = 0; x < Cn; x++) if (seen[x]) { if (x > lowmask) return QCX_NO_ERROR; orbit.push_back((uint16_t)x); }
+    }
+    if (orbit.size() > 16) return QCX_NO_ERROR;
+    unsigned cb = 2;
+    while ((1u << cb) < orbit.size()) cb++;
+    if (cb + 2 > M) return QCX_NO_ERROR;
+    // the companion register
+    if (sh->comp && (sh->comp->M != cb || sh->comp->L != sh->L)) { sh_free(sh->comp); sh->comp = nullptr; }
+    if (!sh->comp) {
+        ShardSet *c = nullptr;
+        if (sh_create((int)L, (int)cb, sh->W, sh->dev.data(), &c, false) != QCX_NO_ERROR) { g_last_error[0] = 0; return QCX_NO_ERROR; }   // (too small for that many shards, no memory ...)
+        sh->comp = c;
+        sh->comp->in_selfcheck = true;                 // (never a compact circuit or a pre-flight check of its own)
+        if (!sh->relay_dev.empty() && sh_set_relays(sh->comp, (unsigned)sh->relay_dev.size(), sh->relay_dev.data()) != QCX_NO_ERROR) { g_last_error[0] = 0; sh_free(sh->comp); sh->comp = nullptr; return QCX_NO_ERROR; }
+    }
+    ShardSet *c = sh->comp;
+    c->fusion = sh->fusion;
+    c->queue.clear(); c->basis_pending = false; c->zeros_dirty = false;
+    sh_identity_perm(c);
+    ExpandParams E;
+    memset(&E, 0, sizeof E);
+    E.M = M; E.cb = cb; E.ncols = (unsigned)orbit.size();
+    for (size_t j = 0; j < orbit.size(); j++) E.orbit[j] = orbit[j];
+    const unsigned long ex0 = c->exchanges, pp0 = c->pack_passes, rb0 = c->relayed_bytes, og0 = c->overlapped_gates;
+    for (unsigned r = 0; r < sh->W; r++) {
+        SH_DEV(c, r);
+        B.first = (uint64_t)r << sh->n_local;
+        const uint64_t nblocks = (uint64_t)1 << (c->n_local - cb);
+        hipLaunchKernelGGL(k_basis_front_compact, dim3(grid_for(nblocks, 256, 65536)), dim3(256), 0, c->st[r], c->buf[c->cur][r], c->n_local, B, E);
+        HIP_TRY(hipGetLastError());
+    }
+    for (size_t i = used; i < sh->queue.size(); i++) {
+        SGate g = sh->queue[i];
+        g.q -= M - cb;
+        if (g.type == FUSE_PHASE) g.q2 -= M - cb;
+        c->queue.push_back(g);
+    }
+    QCX_TRY(sh_flush(c));
+    QCX_TRY(sh_identity(c));
+    const uint64_t nchunks = ((uint64_t)1 << (sh->n_local - M)) >> 6;
+    for (unsigned r = 0; r < sh->W; r++) {                  // every companion shard is complete (peers push into it; its streams are not the register's)
+        SH_DEV(c, r);
+        HIP_TRY(hipStreamSynchronize(c->st[r]));
+        HIP_TRY(hipStreamSynchronize(c->xs[r]));
+    }
+    for (size_t i = 0; i < c->relay_st.size(); i++) { HIP_TRY(hipSetDevice(c->relay_dev[i])); HIP_TRY(hipStreamSynchronize(c->relay_st[i])); }
+    for (unsigned r = 0; r < sh->W; r++) {
+        SH_DEV(sh, r);
+        hipLaunchKernelGGL(k_expand_compact, dim3(grid_for(nchunks, 1, 65536)), dim3(256), 0, sh->st[r], (const amp_t *)c->buf[c->cur][r], sh->buf[sh->cur][r], nchunks, E);
+        HIP_TRY(hipGetLastError());
+    }
+    sh->exchanges += c->exchanges - ex0; sh->pack_passes += c->pack_passes - pp0;
+    sh->relayed_bytes += c->relayed_bytes - rb0; sh->overlapped_gates += c->overlapped_gates - og0;
+    sh->basis_pending = false;
+    sh->queue.clear();
+    sh->fronts++;
+    sh->compact_circuits++;
+    *done = true;
+    return QCX_NO_ERROR;
+}
+
 static int sh_flush(ShardSet *sh)
 {
+    if (sh->basis_pending && !sh->queue.empty()) {
+        bool done = false;
+        QCX_TRY(sh_compact(sh, &done));
+        if (done) return QCX_NO_ERROR;
+    }
     if (sh->basis_pending) QCX_TRY(sh_materialize_basis(sh));
     if (sh->queue.empty()) return QCX_NO_ERROR;
     if (sh->zeros_dirty) {

@@ -57,6 +57,13 @@ def test_shor_circuit_and_measurement(qc, ob, shards, C, L, M, a):
             assert np.array_equal(bits(reg.read()), bits(want))          # collapsed the same way
         assert all(x == y for x, y in picks), picks
         k = shards.bit_length() - 1
+        # compact circuits (round 4): with a small orbit and room for the companion register the whole queue ran on [L register][orbit
+        # column] shards -- trades included -- and every shard expanded its part
+        import ctypes as Ct
+        cc = Ct.c_ulong(0)
+        qc.lib().qcx_compact_stats(reg._h, Ct.byref(cc))
+        if (C, L, M) in ((21, 12, 5), (33, 9, 6)):
+            assert cc.value == 4, cc.value
         if n - k >= M + 6 and M <= 12:
             # the circuit front (reset + Hadamard layer, shard-id qubits included + multiply ladder) went out as one write
             # pass per shard, without an exchange: one front per shot

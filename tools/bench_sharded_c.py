@@ -46,7 +46,10 @@ def main():
     ap.add_argument("--devices", default="", help="comma list; empty = shard r on device r")
     ap.add_argument("--what", default="sweep,shor,config4")
     ap.add_argument("--out", default="gpurun_out/bench_sharded_c.json")
+    ap.add_argument("--tune", default="", help="qcx_tune_set keys, k=v,k=v (e.g. fuse_compact=0)")
     a = ap.parse_args()
+    if a.tune:
+        qc.tune(**{k: int(v) for k, v in (kv.split("=") for kv in a.tune.split(","))})
     devs = [int(x) for x in a.devices.split(",")] if a.devices else None
     n, W = a.n, a.shards
     k = W.bit_length() - 1

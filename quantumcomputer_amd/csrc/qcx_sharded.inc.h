@@ -830,6 +830,7 @@ static int sh_sync(ShardSet *sh)
 static int sh_set_relays(ShardSet *sh, unsigned nrelays, const int *devices)
 {
     if (sh->dry) return QCX_NO_ERROR;
+    if (sh->comp) { sh_free(sh->comp); sh->comp = nullptr; }       // (the companion of compact circuits is rebuilt with the new relays on its next use)
     QCX_TRY(sh_identity(sh));                      // the trade zone moves with the slice geometry: identity layout, nothing queued
     QCX_TRY(sh_sync(sh));
     sh_drop_relays(sh);

@@ -271,6 +271,20 @@ int  qcx_fusion_plan_mode(int mode, unsigned n_local, unsigned M, unsigned count
 int  qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_t first_global,
                             uint64_t last_excluded, double cum_in, double r,
                             int *found, uint64_t *index, double *cum_out, void *stream);
+/* Compact circuits for a one-process-per-GPU host: behind the circuit front the M register reads one of the
+ * residues of the multiply ladder's orbit; when nothing else in the queue touches it, the queue can run on a register of
+ * L + cb qubits, [L register][orbit column], and every rank expands its part at the end.
+ * qcx_compact_plan (pure host; same answer on every rank): *used = gates of the closed-form front, *ncols > 0: the compact form
+ * exists, cb column bits, orbit16[0 .. *ncols) the populated M-register values ascending.
+ * qcx_shard_compact_front writes a rank's part of the front in the compact form (n_local_compact = n_local - M + cb;
+ * first_global = REAL global index of the rank's amplitude 0); qcx_shard_expand_compact turns a rank's compact part into its
+ * part of the real register (n_local - M >= 6). */
+int  qcx_compact_plan(unsigned n, unsigned M, uint64_t basis, unsigned count, const qcx_gate_desc *gates,
+                      unsigned *used, unsigned *cb, unsigned *ncols, uint16_t *orbit16);
+int  qcx_shard_compact_front(void *compact, unsigned n_local_compact, uint64_t first_global, unsigned n, unsigned M, uint64_t basis,
+                             unsigned count, const qcx_gate_desc *gates, unsigned cb, unsigned ncols, const uint16_t *orbit16, void *stream);
+int  qcx_shard_expand_compact(const void *compact, void *real, unsigned n_local, unsigned M, unsigned cb, unsigned ncols,
+                              const uint16_t *orbit16, void *stream);
 /* zero the shard; if 0 <= local_index < 2^n_local set that amplitude to (1,0) */
 int  qcx_shard_collapse(void *amp, unsigned n_local, int64_t local_index, void *stream);
 /* -0 components of the shard become +0: for amplitudes the caller wrote, before the first gate runs on them (the

@@ -87,6 +87,9 @@ SIGNATURES = {
     "qcx_shard_run_fused_mode": (_i, [_i, _p, _u, _u, _u, _p, _p]),
     "qcx_shard_release_stream": (_i, [_p]),
     "qcx_shard_basis_front": (_i, [_p, _u, _u64, _u, _u, _u64, _u, _p, C.POINTER(_u), _p]),
+    "qcx_compact_plan": (_i, [_u, _u, _u64, _u, _p, C.POINTER(_u), C.POINTER(_u), C.POINTER(_u), C.POINTER(C.c_uint16)]),
+    "qcx_shard_compact_front": (_i, [_p, _u, _u64, _u, _u, _u64, _u, _p, _u, _u, C.POINTER(C.c_uint16), _p]),
+    "qcx_shard_expand_compact": (_i, [_p, _p, _u, _u, _u, _u, C.POINTER(C.c_uint16), _p]),
     "qcx_state_save": (_i, [_p, C.c_char_p]),
     "qcx_state_load": (_i, [_p, C.c_char_p]),
     "qcx_fusion_plan": (_i, [_u, _u, _u, _p, _p, _u, C.POINTER(_u), _p, C.c_size_t, C.POINTER(C.c_size_t)]),

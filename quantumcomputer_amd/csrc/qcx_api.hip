@@ -1112,6 +1112,70 @@ static int descs_to_gates(unsigned n_local, unsigned M, unsigned count, const qc
     return QCX_NO_ERROR;
 }
 
+// ---- compact circuits for a one-process-per-GPU host (quantumcomputer_amd/sharded.py; the C host: sh_compact) ----------------
+// qcx_compact_plan: pure host.  The closed-form front of `gates` on basis state `basis` (as qcx_shard_basis_front consumes it)
+// and, when the M register stays on a small orbit behind it (compact_orbit), the compact form's column bits and the orbit.
+// *ncols = 0: no compact form.  Every rank calls it with the same arguments and gets the same answer.
+extern "C" int qcx_compact_plan(unsigned n, unsigned M, uint64_t basis, unsigned count, const qcx_gate_desc *gates,
+                                unsigned *used, unsigned *cb, unsigned *ncols, uint16_t *orbit16)
+{
+    if (!used || !cb || !ncols || !orbit16 || n == 0 || n > 40 || M > n || (count && !gates) || (basis >> n)) return QCX_BAD_ARGUMENTS;
+    *used = *cb = *ncols = 0;
+    std::vector<QGate> q;
+    for (unsigned k = 0; k < count; k++) {
+        std::vector<QGate> one;
+        if (gates[k].type == 1 || descs_to_gates(n, M, 1, gates + k, one) != QCX_NO_ERROR) break;
+        q.push_back(one[0]);
+    }
+    BasisFront B;
+    const Tune tn = tune_now();
+    const size_t k = (M <= 26) ? front_plan(n, M, basis, tn, q, &B) : 0;
+    *used = (unsigned)k;
+    std::vector<uint16_t> orbit;
+    unsigned c = 0;
+    if (!k || !tn.fuse_compact || !compact_orbit(B, M, orbit, &c)) return QCX_NO_ERROR;
+    *cb = c; *ncols = (unsigned)orbit.size();
+    for (size_t j = 0; j < orbit.size(); j++) orbit16[j] = orbit[j];
+    return QCX_NO_ERROR;
+}
+
+// this rank's part of the front, written in the compact form ([L register][orbit column]); count = the front's gates (*used of
+// qcx_compact_plan), first_global = REAL global index of the rank's amplitude 0, n_local_compact = n_local - M + cb
+extern "C" int qcx_shard_compact_front(void *compact, unsigned n_local_compact, uint64_t first_global, unsigned n, unsigned M, uint64_t basis,
+                                       unsigned count, const qcx_gate_desc *gates, unsigned cb, unsigned ncols, const uint16_t *orbit16, void *stream)
+{
+    if (!compact || !orbit16 || !count || !gates || n == 0 || n > 40 || M > n || ncols == 0 || ncols > 16 || cb < 2 || cb > 4 || (1u << cb) < ncols ||
+        n_local_compact <= cb || n_local_compact > 40) return QCX_BAD_ARGUMENTS;
+    std::vector<QGate> q;
+    QCX_TRY(descs_to_gates(n, M, count, gates, q));
+    BasisFront B;
+    if (front_plan(n, M, basis, tune_now(), q, &B) != count) return QCX_BAD_ARGUMENTS;
+    B.first = first_global;
+    ExpandParams E;
+    memset(&E, 0, sizeof E);
+    E.M = M; E.cb = cb; E.ncols = ncols;
+    for (unsigned j = 0; j < ncols; j++) E.orbit[j] = orbit16[j];
+    const uint64_t nblocks = (uint64_t)1 << (n_local_compact - cb);
+    hipLaunchKernelGGL(k_basis_front_compact, dim3(grid_for(nblocks, 256, 65536)), dim3(256), 0, (hipStream_t)stream, (amp_t *)compact, n_local_compact, B, E);
+    HIP_TRY(hipGetLastError());
+    return QCX_NO_ERROR;
+}
+
+// a rank's part of the real register from its compact form (n_local - M >= 6)
+extern "C" int qcx_shard_expand_compact(const void *compact, void *real, unsigned n_local, unsigned M, unsigned cb, unsigned ncols,
+                                        const uint16_t *orbit16, void *stream)
+{
+    if (!compact || !real || !orbit16 || n_local > 40 || M > 12 || n_local < M + 6 || ncols == 0 || ncols > 16 || cb < 2 || cb > 4 || (1u << cb) < ncols) return QCX_BAD_ARGUMENTS;
+    ExpandParams E;
+    memset(&E, 0, sizeof E);
+    E.M = M; E.cb = cb; E.ncols = ncols;
+    for (unsigned j = 0; j < ncols; j++) E.orbit[j] = orbit16[j];
+    const uint64_t nchunks = ((uint64_t)1 << (n_local - M)) >> 6;
+    hipLaunchKernelGGL(k_expand_compact, dim3(grid_for(nchunks, 1, 65536)), dim3(256), 0, (hipStream_t)stream, (const amp_t *)compact, (amp_t *)real, nchunks, E);
+    HIP_TRY(hipGetLastError());
+    return QCX_NO_ERROR;
+}
+
 extern "C" int qcx_shard_run_fused_mode(int mode, void *amp, unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates, void *stream);
 
 extern "C" int qcx_shard_run_fused(void *amp, unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates, void *stream)

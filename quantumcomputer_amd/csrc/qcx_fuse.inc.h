@@ -1195,6 +1195,37 @@ static int upload_ops(qcx_register *r, GateQueue *gq, const std::vector<FuseOp> 
 // compact buffers carved out of the register's second buffer), and k_expand_compact writes the real register once at the
 // end: 2^(M - cb) times less memory traffic in every pass but the last write.  Same arithmetic on the same amplitudes in the
 // same order: same bits.  *done = false: not applicable, nothing was launched.
+// The orbit a circuit front leaves the M register on, and whether a compact form pays: one modulus, f0 < C <= 4096, every residue
+// inside the register, at most 16 of them, and 2^cb columns (cb >= 2) at least four times fewer than 2^M.  The orbit is the
+// closure of f0 under every multiplier of the ladder -- a superset of the subset products the front can reach.
+static bool compact_orbit(const BasisFront &B, unsigned M, std::vector<uint16_t> &orbit, unsigned *cb_out)
+{
+    orbit.clear();
+    if (M < 4 || M > 12) return false;
+    const uint32_t lowmask = (1u << M) - 1u;
+    if ((B.hmask & lowmask) != 0 || B.ncam > 64) return false;
+    const uint32_t Cn = B.ncam ? B.C[0] : 0u, f0 = (uint32_t)(B.basis & lowmask);
+    for (unsigned g = 0; g < B.ncam; g++) if (B.C[g] != Cn) return false;
+    if (!B.ncam) orbit.push_back((uint16_t)f0);
+    else {
+        if (Cn == 0 || Cn > 4096u || f0 >= Cn) return false;
+        std::vector<char> seen(Cn, 0);
+        std::vector<uint32_t> todo(1, f0);
+        seen[f0] = 1;
+        while (!todo.empty()) {
+            const uint32_t x = todo.back(); todo.pop_back();
+            for (unsigned g = 0; g < B.ncam; g++) { const uint32_t y = (uint32_t)(((uint64_t)x * (B.A[g] % Cn)) % Cn); if (!seen[y]) { seen[y] = 1; todo.push_back(y); } }
+        }
+        for (uint32_t x = 0; x < Cn; x++) if (seen[x]) { if (x > lowmask) { orbit.clear(); return false; } orbit.push_back((uint16_t)x); }
+    }
+    if (orbit.size() > 16) { orbit.clear(); return false; }
+    unsigned cb = 2;
+    while ((1u << cb) < orbit.size()) cb++;
+    if (cb + 2 > M) { orbit.clear(); return false; }
+    *cb_out = cb;
+    return true;
+}
+
 // the real register from a pending compact form
 static int expand_pending(qcx_register *r)
 {
@@ -1224,26 +1255,10 @@ static int compact_chain(qcx_register *r, GateQueue *gq, const Tune &tn, const B
         else if (g.type == FUSE_PHASE) { if (g.mask & lowmask) return QCX_NO_ERROR; }
         else return QCX_NO_ERROR;
     }
-    // the orbit: closure of f0 under every multiplier (a superset of the subset products the front can reach)
-    const uint32_t Cn = Bf.ncam ? Bf.C[0] : 0u, f0 = (uint32_t)(Bf.basis & lowmask);
-    for (unsigned g = 0; g < Bf.ncam; g++) if (Bf.C[g] != Cn) return QCX_NO_ERROR;
     std::vector<uint16_t> orbit;
-    if (!Bf.ncam) orbit.push_back((uint16_t)f0);
-    else {
-        if (Cn == 0 || Cn > 4096u || f0 >= Cn) return QCX_NO_ERROR;
-        std::vector<char> seen(Cn, 0);
-        std::vector<uint32_t> todo(1, f0);
-        seen[f0] = 1;
-        while (!todo.empty()) {
-            const uint32_t x = todo.back(); todo.pop_back();
-            for (unsigned g = 0; g < Bf.ncam; g++) { const uint32_t y = (uint32_t)(((uint64_t)x * (Bf.A[g] % Cn)) % Cn); if (!seen[y]) { seen[y] = 1; todo.push_back(y); } }
-        }
-        for (uint32_t x = 0; x < Cn; x++) if (seen[x]) { if (x > lowmask) return QCX_NO_ERROR; orbit.push_back((uint16_t)x); }
-    }
-    if (orbit.size() > 16) return QCX_NO_ERROR;
-    unsigned cb = 2;
-    while ((1u << cb) < orbit.size()) cb++;
-    if (cb + 2 > M) return QCX_NO_ERROR;                            // less than 4 x smaller: the plain paths
+    unsigned cb = 0;
+    if (!compact_orbit(Bf, M, orbit, &cb)) return QCX_NO_ERROR;
+    const uint32_t Cn = Bf.ncam ? Bf.C[0] : 0u, f0 = (uint32_t)(Bf.basis & lowmask);
     const unsigned nv = L + cb;
     if (nv < 14 || L < 8) return QCX_NO_ERROR;
     // the virtual register's gate list

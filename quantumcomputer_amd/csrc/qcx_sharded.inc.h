@@ -631,25 +631,9 @@ static int sh_compact(ShardSet *sh, bool *done)
         else if (g.type == FUSE_PHASE) { if (g.q < M || g.q2 < M) return QCX_NO_ERROR; }
         else return QCX_NO_ERROR;
     }
-    const uint32_t Cn = B.ncam ? B.C[0] : 0u, f0 = (uint32_t)(B.basis & lowmask);
-    for (unsigned g = 0; g < B.ncam; g++) if (B.C[g] != Cn) return QCX_NO_ERROR;
     std::vector<uint16_t> orbit;
-    if (!B.ncam) orbit.push_back((uint16_t)f0);
-    else {
-        if (Cn == 0 || Cn > 4096u || f0 >= Cn) return QCX_NO_ERROR;
-        std::vector<char> seen(Cn, 0);
-        std::vector<uint32_t> todo(1, f0);
-        seen[f0] = 1;
-        while (!todo.empty()) {
-            const uint32_t x = todo.back(); todo.pop_back();
-            for (unsigned g = 0; g < B.ncam; g++) { const uint32_t y = (uint32_t)(((uint64_t)x * (B.A[g] % Cn)) % Cn); if (!seen[y]) { seen[y] = 1; todo.push_back(y); } }
-        }
-        for (uint32_t x = 0; x < Cn; x++) if (seen[x]) { if (x > lowmask) return QCX_NO_ERROR; orbit.push_back((uint16_t)x); }
-    }
-    if (orbit.size() > 16) return QCX_NO_ERROR;
-    unsigned cb = 2;
-    while ((1u << cb) < orbit.size()) cb++;
-    if (cb + 2 > M) return QCX_NO_ERROR;
+    unsigned cb = 0;
+    if (!compact_orbit(B, M, orbit, &cb)) return QCX_NO_ERROR;
     // the companion register
     if (sh->comp && (sh->comp->M != cb || sh->comp->L != sh->L)) { sh_free(sh->comp); sh->comp = nullptr; }
     if (!sh->comp) {

@@ -88,6 +88,29 @@ class HipEngine:
                                           C.byref(used), self._s()), "qcx_shard_basis_front")
         return int(used.value)
 
+    # compact circuits: the front's orbit, the front in the compact form, the expansion
+    def compact_plan(self, n, M, basis, descs):
+        """(gates of the closed-form front, column bits, orbit) -- orbit empty: no compact form"""
+        arr = (GateDesc * max(len(descs), 1))()
+        for i, d in enumerate(descs):
+            arr[i].type, arr[i].q, arr[i].mask, arr[i].c, arr[i].s, arr[i].C, arr[i].A = d
+        used, cb, ncols = C.c_uint(0), C.c_uint(0), C.c_uint(0)
+        orbit = (C.c_uint16 * 16)()
+        check(lib().qcx_compact_plan(n, M, basis, len(descs), C.cast(arr, C.c_void_p), C.byref(used), C.byref(cb), C.byref(ncols), orbit), "qcx_compact_plan")
+        return used.value, cb.value, [int(orbit[j]) for j in range(ncols.value)]
+
+    def compact_front(self, t, n_local_compact, first_global, n, M, basis, descs, cb, orbit):
+        arr = (GateDesc * max(len(descs), 1))()
+        for i, d in enumerate(descs):
+            arr[i].type, arr[i].q, arr[i].mask, arr[i].c, arr[i].s, arr[i].C, arr[i].A = d
+        ob = (C.c_uint16 * 16)(*orbit)
+        check(lib().qcx_shard_compact_front(self._p(t), n_local_compact, first_global, n, M, basis, len(descs), C.cast(arr, C.c_void_p),
+                                            cb, len(orbit), ob, self._s()), "qcx_shard_compact_front")
+
+    def expand_compact(self, tc, t, n_local, M, cb, orbit):
+        ob = (C.c_uint16 * 16)(*orbit)
+        check(lib().qcx_shard_expand_compact(self._p(tc), self._p(t), n_local, M, cb, len(orbit), ob, self._s()), "qcx_shard_expand_compact")
+
     def swap_bits(self, src, dst, n_local, pos_a, pos_b):
         m = len(pos_a)
         a = (C.c_uint * max(m, 1))(*pos_a)
@@ -176,6 +199,9 @@ class ShardedRegister:
         self.max_queue = max_queue
         self.exchanges = 0                # all-to-alls performed
         self.fronts = 0                   # circuit fronts written as one pass (qcx_shard_basis_front)
+        self.compact_circuits = 0         # flushes that ran on the companion register of compact circuits (_try_compact)
+        self._comp = None                 # that companion: L + cb qubits on the same ranks, created on first use
+        self._slices_log2 = slices_log2
         self._basis_pending = False
         self.pack_passes = 0              # local pack passes performed
         self.profile = None               # set to [] to collect (gate, ms, exchanged) per executed gate (cuda only)
@@ -404,7 +430,64 @@ class ShardedRegister:
         bit, nor a qubit of the rank id)"""
         return g[0] != "h" or self.perm[g[1]] < self.slice_bits
 
+    def _try_compact(self):
+        """Behind the circuit front the M register reads one of the residues of the multiply ladder's orbit; when nothing else
+        in the queue touches it the whole queue runs on a COMPANION register of L + cb qubits -- [L register][orbit column],
+        the same ranks, 2^(M - cb) times smaller: fused passes and all-to-alls alike -- and every rank expands its part into the
+        real register (the C host: sh_compact; one GPU: compact_chain).  Every rank takes the same decision from the same
+        queue.  True: done."""
+        eng = self.engine
+        if not (self.fusion and hasattr(eng, "compact_plan") and self.queue) or self.dry_run or os.environ.get("QCX_SHARD_COMPACT", "1") == "0":
+            return False
+        n, M = self.num_qubits, self.M_size
+        descs = []
+        for g in self.queue:
+            if g[0] == "h":
+                descs.append((0, g[1], 0, 0.0, 0.0, 0, 0))
+            elif g[0] == "c":
+                descs.append((2, g[3], 0, 0.0, 0.0, g[1], g[2]))
+            else:
+                break
+        if not descs or self.n_local < M + 6:
+            return False
+        used, cb, orbit = eng.compact_plan(n, M, 1, descs)
+        if not orbit or not used or used >= len(self.queue):
+            return False
+        rest = self.queue[used:]
+        for g in rest:
+            if not ((g[0] == "h" and g[1] >= M) or (g[0] == "p" and g[1] >= M and g[2] >= M)):
+                return False
+        comp = self._comp
+        if comp is None or comp.M_size != cb:
+            try:
+                comp = ShardedRegister(self.L_size, cb, device=self.device, group=self.group, engine=eng, max_queue=self.max_queue,
+                                       slices_log2=self._slices_log2, fusion=(2 if self.fusion_mode == 2 else True))
+            except ValueError:
+                return False                       # too small for this many ranks
+            comp._try_compact = lambda: False      # (never a compact circuit of its own)
+            self._comp = comp
+        comp.queue = []
+        comp.perm, comp.inv = list(range(comp.num_qubits)), list(range(comp.num_qubits))
+        comp._basis_pending = False
+        ex0, pp0, og0 = comp.exchanges, comp.pack_passes, comp.overlapped_gates
+        eng.compact_front(comp.shard, comp.n_local, self.rank << self.n_local, n, M, 1, descs[:used], cb, orbit)
+        sh = M - cb
+        comp.queue = [("h", g[1] - sh) if g[0] == "h" else ("p", g[1] - sh, g[2] - sh, g[3], g[4]) for g in rest]
+        comp.flush()
+        comp._identity()
+        eng.expand_compact(comp.shard, self.shard, self.n_local, M, cb, orbit)
+        self.exchanges += comp.exchanges - ex0
+        self.pack_passes += comp.pack_passes - pp0
+        self.overlapped_gates += comp.overlapped_gates - og0
+        self._basis_pending = False
+        self.queue = []
+        self.fronts += 1
+        self.compact_circuits += 1
+        return True
+
     def flush(self):
+        if getattr(self, "_basis_pending", False) and self._try_compact():
+            return
         if getattr(self, "_basis_pending", False):
             self._materialize_basis()
         if not self.queue:

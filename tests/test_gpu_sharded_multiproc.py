@@ -90,6 +90,16 @@ def test_shor_circuit_and_measurement_across_processes(world):
 
 
 @pytest.mark.parametrize("world", [2, 4])
+def test_compact_circuits_across_processes(world):
+    """the per-rank host runs the queue behind a circuit front on its companion register ([L register][orbit column]: fused
+    passes and all-to-alls 2^(M - cb) times smaller) and every rank expands its part: whole states and measured indices
+    against the oracle"""
+    same, picks, nrm, compact = run_gpu(world, G.sc_shor_compact)
+    assert same and all(a == b for a, b in picks), picks
+    assert compact == 6, compact
+
+
+@pytest.mark.parametrize("world", [2, 4])
 def test_mixed_gates_in_swapped_layout_across_processes(world):
     same, exchanges = run_gpu(world, G.sc_mixed_gates_in_swapped_layout)
     assert same and exchanges >= 1

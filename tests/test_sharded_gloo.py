@@ -164,6 +164,26 @@ def sc_shor(rank, world, ob, make):
     return same, picks, nrm, reg.exchanges
 
 
+def sc_shor_compact(rank, world, ob, make):
+    """a register large enough for the companion register of compact circuits (ShardedRegister._try_compact; GPU engine only):
+    Shor N = 21 with L = 12, M = 5 -- the orbit {1, 2, 4, 8, 11, 16} -> 8 columns"""
+    L, M, Cn, a = 12, 5, 21, 2
+    n = L + M
+    reg = make(L, M)
+    want = np.zeros(2 << n); ob.reset(want, n); ob.quantum_computation(want, n, M, Cn, a)
+    same, picks = True, []
+    rng = ob.Rng(777)
+    for _ in range(3):
+        reg.reset_register(); reg.quantum_computation(Cn, a)
+        same = same and bool(np.array_equal(bits(reg.gather()), bits(want)))
+        reg.reset_register(); reg.quantum_computation(Cn, a)
+        r = rng.uniform()
+        w = want.copy()
+        picks.append((reg.measure_state(r), ob.measure(w, n, r)))
+        same = same and bool(np.array_equal(bits(reg.gather()), bits(w)))
+    return same, picks, reg.norm2(), getattr(reg, "compact_circuits", 0)
+
+
 def sc_mixed_gates_in_swapped_layout(rank, world, ob, make):
     """controlled phases and modular multiplies whose control/target sit on global bits, issued
     while the qubit map is swapped (right after a global Hadamard)"""

@@ -1235,7 +1235,7 @@ static int expand_pending(qcx_register *r)
     E.M = (unsigned)r->M; E.cb = r->compact_cb; E.ncols = r->compact_ncols;
     for (unsigned j = 0; j < r->compact_ncols; j++) E.orbit[j] = r->compact_orbit[j];
     const uint64_t nchunks = ((uint64_t)1 << (r->n - (unsigned)r->M)) >> 6;  // 64 blocks per workgroup iteration (L >= 8)
-    hipLaunchKernelGGL(k_expand_compact, dim3(grid_for(nchunks, 1, 65536)), dim3(256), 0, r->stream, (const amp_t *)r->compact_amp, r->amp, nchunks, E);
+    hipLaunchKernelGGL(k_expand_compact, dim3(grid_for(nchunks, 1, 65536)), dim3(256), 0, r->stream, (const amp_t *)r->compact_amp, r->amp, nchunks, E, (int)tune_now().fuse_expand_direct);
     HIP_TRY(hipGetLastError());
     r->compact_pending = 0;
     return QCX_NO_ERROR;

@@ -676,7 +676,7 @@ static int sh_compact(ShardSet *sh, bool *done)
     for (size_t i = 0; i < c->relay_st.size(); i++) { HIP_TRY(hipSetDevice(c->relay_dev[i])); HIP_TRY(hipStreamSynchronize(c->relay_st[i])); }
     for (unsigned r = 0; r < sh->W; r++) {
         SH_DEV(sh, r);
-        hipLaunchKernelGGL(k_expand_compact, dim3(grid_for(nchunks, 1, 65536)), dim3(256), 0, sh->st[r], (const amp_t *)c->buf[c->cur][r], sh->buf[sh->cur][r], nchunks, E);
+        hipLaunchKernelGGL(k_expand_compact, dim3(grid_for(nchunks, 1, 65536)), dim3(256), 0, sh->st[r], (const amp_t *)c->buf[c->cur][r], sh->buf[sh->cur][r], nchunks, E, (int)tn.fuse_expand_direct);
         HIP_TRY(hipGetLastError());
     }
     sh->exchanges += c->exchanges - ex0; sh->pack_passes += c->pack_passes - pp0;

@@ -104,3 +104,42 @@ def test_front_respects_the_switch_and_the_table_form(qc):
         assert qc.front_plan(n, M, 1, descs)[0] == 0
     finally:
         qc.tune(fuse_front=old)
+
+
+def test_compact_plan_gives_the_orbit_of_the_ladder(qc):
+    """qcx_compact_plan (pure host): behind the front of a Shor circuit the M register reads a residue of the multiply ladder's
+    orbit; the compact form [L register][orbit column] exists when that orbit is small against 2^M"""
+    import ctypes as C
+    from quantumcomputer_amd._lib import GateDesc
+
+    def plan(n, M, descs, basis=1):
+        arr = (GateDesc * max(len(descs), 1))()
+        for i, d in enumerate(descs):
+            arr[i].type, arr[i].q, arr[i].mask, arr[i].c, arr[i].s, arr[i].C, arr[i].A = d
+        used, cb, ncols = C.c_uint(0), C.c_uint(0), C.c_uint(0)
+        orbit = (C.c_uint16 * 16)()
+        st = qc.lib().qcx_compact_plan(n, M, basis, len(descs), C.cast(arr, C.c_void_p), C.byref(used), C.byref(cb), C.byref(ncols), orbit)
+        assert st == 0
+        return used.value, cb.value, [int(orbit[j]) for j in range(ncols.value)]
+
+    def front(Cn, a, L, M):
+        n = L + M
+        d = [(0, l, 0, 0.0, 0.0, 0, 0) for l in range(M, n)]
+        x = a % Cn
+        for l in range(M, n):
+            d.append((2, l, 0, 0.0, 0.0, Cn, x)); x = (x * x) % Cn
+        return n, d + [(0, n - 1, 0, 0.0, 0.0, 0, 0)]
+
+    n, d = front(21, 2, 12, 5)
+    assert plan(n, 5, d) == (24, 3, [1, 2, 4, 8, 11, 16])
+    n, d = front(15, 7, 10, 4)
+    assert plan(n, 4, d) == (20, 2, [1, 4, 7, 13])
+    n, d = front(255, 2, 9, 8)
+    assert plan(n, 8, d) == (18, 3, [1, 2, 4, 8, 16, 32, 64, 128])
+    n, d = front(15, 2, 10, 4)                    # orbit {1, 2, 4, 8}: four columns of 16 values
+    assert plan(n, 4, d) == (20, 2, [1, 2, 4, 8])
+    n, d = front(31, 3, 10, 5)                    # 3 generates all 30 units mod 31: no compact form
+    assert plan(n, 5, d) == (20, 0, [])
+    n, d = front(21, 2, 12, 5)                    # a Hadamard on an M-register qubit in the front: its low bits are free, no compact form
+    assert plan(n, 5, [(0, 2, 0, 0.0, 0.0, 0, 0)] + d)[2] == []
+    assert plan(12, 4, [(1, 0, (1 << 5) | (1 << 7), 1.0, 0.0, 0, 0)]) == (0, 0, [])       # no front at all

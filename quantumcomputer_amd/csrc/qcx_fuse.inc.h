@@ -474,6 +474,8 @@ static bool launch_rounds_kernel(int occ, int tol_occ, unsigned grid, size_t lds
     }
 }
 
+static bool pass_tables_cover(const FusePass &P, unsigned n);
+
 // amp_in / amp_out: the buffer the pass reads / writes (the same for a pass that works in place; a chained pass goes from one of
 // the register's two buffers to the other)
 static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, const FuseOp *d_ops, bool nopipe, amp_t *amp_in, amp_t *amp_out)
@@ -482,6 +484,7 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
     FusePass P = P_in;
     if ((P.chained != 0) != (amp_in != amp_out)) { set_error("fused pass: chained flag and buffers disagree"); return QCX_UNKNOWN_ERROR; }
     const unsigned n = r->n;
+    if (!pass_tables_cover(P, n)) { set_error("fused pass: the addressing tables do not cover the %u tile-number bits", n - P.T); return QCX_UNKNOWN_ERROR; }
     const uint64_t ntiles = (uint64_t)1 << (n - P.T);
     const unsigned grid = grid_for(ntiles, 1, tn.fuse_grid_cap);
     const size_t lut_only = P.has_cam ? cam_lut_bytes((unsigned)r->M) : 16;        // scratch of the modular-multiply steps
@@ -610,6 +613,17 @@ static bool pass_tables_chained(FusePass &P, unsigned n, const std::vector<unsig
     std::vector<unsigned> pin, pout, plg;
     for (unsigned q : fq) { pin.push_back(lin[q]); pout.push_back(lout[q]); plg.push_back(q); }
     return make_segments(pin, P.seg_in, &P.nseg_in) && make_segments(pout, P.seg_out, &P.nseg_out) && make_segments(plg, P.seg_lg, &P.nseg_lg);
+}
+
+// do the segment lists of a pass deposit ALL n - T bits of the tile number?  (a list left short -- or stale from another
+// plan -- would send every tile to base 0: launch_pass refuses such a pass)
+static bool pass_tables_cover(const FusePass &P, unsigned n)
+{
+    auto total = [](const FuseSeg *seg, unsigned cnt) { unsigned t = 0; for (unsigned k = 0; k < cnt && k < QCX_MAX_SEG; k++) t += seg[k].len; return t; };
+    if (P.T > n || P.nseg_in > QCX_MAX_SEG || P.nseg_out > QCX_MAX_SEG || P.nseg_lg > QCX_MAX_SEG) return false;
+    if (total(P.seg_in, P.nseg_in) != n - P.T) return false;
+    if (!P.chained) return true;
+    return total(P.seg_out, P.nseg_out) == n - P.T && total(P.seg_lg, P.nseg_lg) == n - P.T;
 }
 
 // The planner: cut a gate list into actions (fused passes and stand-alone gates) and emit every pass's records.
@@ -949,19 +963,28 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
                 for (unsigned pos = 0; pos < n; pos++) lay[k + 1][order[pos]] = pos;
             }
             // the passes again, each with its tile ordered by where its input layout puts the qubits
+            // (the tables are built on COPIES, with the tile order the launch will use, and taken over only when every pass
+            //  of the chain has all three of its segment lists: a tile order whose free bits need more than QCX_MAX_SEG runs
+            //  -- by output position at n >= 30 on scattered Hadamard lists -- falls back to the input order, and a chain that
+            //  does not fit either way stays in place.  Round 4 validated one order and launched the other.)
             std::vector<PassShape> ns;
+            std::vector<FusePass> nt;
             bool ok = true;
             for (size_t k = 0; k < m && ok; k++) {
                 PassShape sh = shapes[shape_of[a0 + k]];
                 std::sort(sh.tl.begin(), sh.tl.end(), [&](unsigned x, unsigned y) { return lay[k][x] < lay[k][y]; });
-                FusePass Pt; memset(&Pt, 0, sizeof Pt);
-                ok = pass_tables_chained(Pt, n, sh.tl, lay[k], lay[k + 1], false);
+                FusePass Pt = acts[a0 + k].P;
+                const bool by_out = Pt.dg_slim != 0 && !store_whole;
+                ok = pass_tables_chained(Pt, n, sh.tl, lay[k], lay[k + 1], by_out);
+                if (!ok && by_out) { Pt = acts[a0 + k].P; ok = pass_tables_chained(Pt, n, sh.tl, lay[k], lay[k + 1], false); }
+                ok = ok && pass_tables_cover(Pt, n);
                 ns.push_back(sh);
+                nt.push_back(Pt);
             }
             if (ok) {
                 for (size_t k = 0; k < m; k++) {
                     shapes[shape_of[a0 + k]] = ns[k];
-                    (void)pass_tables_chained(acts[a0 + k].P, n, ns[k].tl, lay[k], lay[k + 1], acts[a0 + k].P.dg_slim != 0 && !store_whole);
+                    acts[a0 + k].P = nt[k];
                 }
                 any = true;
             }

@@ -418,3 +418,55 @@ def check_chain_addressing(n, actions):
             chained += 1
     assert np.array_equal(cur, np.arange(1 << n)), "a plan must leave the identity layout behind"
     return chained
+
+
+def _seg_map(segs, nseg):
+    """tile-number bit k -> index bit it is deposited at, from a run-length segment list"""
+    m = {}
+    for k in range(nseg):
+        src, dst, ln = segs[4 * k], segs[4 * k + 1], segs[4 * k + 2]
+        for j in range(ln):
+            assert src + j not in m, "a tile-number bit is deposited twice"
+            m[src + j] = dst + j
+    return m
+
+
+def check_chain_layouts(n, actions):
+    """check_chain_addressing for registers too large to enumerate: the same address arithmetic followed SYMBOLICALLY -- the
+    layout is a permutation qubit -> physical index bit, every table of a pass is one bit to one bit.  Every fused pass must
+    deposit all n - T tile-number bits (input, and for a chained pass output and logical base), find its tile's qubits where
+    the layout has them, store a bijection, and every chain must end on the identity.  Returns the number of chained passes."""
+    lay = list(range(n))                              # lay[q] = physical bit of qubit q in the current buffer
+    chained = 0
+    for act in actions:
+        if not act.fused:
+            assert lay == list(range(n)), "a stand-alone gate needs the identity layout"
+            continue
+        T = act.T
+        tl = [int(act.tl[j]) for j in range(T)]
+        m_in = _seg_map(bytes(act.seg_in), act.nseg_in)
+        assert sorted(m_in) == list(range(n - T)), ("seg_in covers", len(m_in), "of", n - T, "tile-number bits")
+        for j in range(T):
+            assert int(act.in_pos[j]) == lay[tl[j]], "tile-local bit j is not where the input layout has its qubit"
+        if not act.chained:
+            free = sorted(set(range(n)) - {lay[q] for q in tl})
+            assert sorted(m_in.values()) == free
+            assert lay == list(range(n)), "an in-place pass works on the identity layout"
+            continue
+        m_out = _seg_map(bytes(act.seg_out), act.nseg_out)
+        m_lg = _seg_map(bytes(act.seg_lg), act.nseg_lg)
+        assert sorted(m_out) == list(range(n - T)), ("seg_out covers", len(m_out), "of", n - T)
+        assert sorted(m_lg) == list(range(n - T)), ("seg_lg covers", len(m_lg), "of", n - T)
+        new = [None] * n
+        for k in range(n - T):
+            q = m_lg[k]                               # the qubit tile-number bit k stands for
+            assert q not in tl and lay[q] == m_in[k], "input and logical deposits of a tile-number bit disagree"
+            new[q] = m_out[k]
+        assert sorted(int(x) for x in act.st_loc[:T]) == list(range(T))
+        for j in range(T):
+            new[tl[int(act.st_loc[j])]] = int(act.st_pos[j])
+        assert sorted(new) == list(range(n)), "the stores of a chained pass are not a permutation of the index bits"
+        lay = new
+        chained += 1
+    assert lay == list(range(n)), "a plan must leave the identity layout behind"
+    return chained

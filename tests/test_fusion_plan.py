@@ -437,6 +437,41 @@ def test_chain_of_the_n30_sweep_and_the_n28_iqft(qc, chain_guard):
     assert [int(x) for x in actions[1].in_pos[:12]] == list(range(12)) and [int(x) for x in actions[2].in_pos[:12]] == list(range(12))
 
 
+@pytest.mark.parametrize("mode", [1, 2], ids=["exact", "tolerance"])
+def test_chained_tables_cover_every_tile_bit_at_full_size(qc, chain_guard, mode):
+    """round 4's advisor finding: at n >= 30 a scattered Hadamard list can need more than 16 run-length segments for the tile
+    number in the by-output order; the planner validated the by-input order and launched the other one with stale tables
+    (18 free bits never deposited -> every tile at base 0).  Random H-heavy lists at n = 30 ... 36: every fused action's
+    segment lists deposit all n - T bits and the layouts chain up to the identity (followed symbolically)."""
+    rs = np.random.RandomState(77 + mode)
+    total = 0
+    small_ok = 0
+    for trial in range(400):
+        n = int(rs.randint(30, 37))
+        cnt = int(rs.randint(20, 140))
+        descs = []
+        for _ in range(cnt):
+            if mode == 2 and rs.rand() < 0.2:
+                c, t = (int(x) for x in rs.choice(n, 2, replace=False))
+                th = float(rs.uniform(-3, 3))
+                descs.append((1, 0, (1 << c) | (1 << t), math.cos(th), math.sin(th), 0, 0))
+            else:
+                descs.append((0, int(rs.randint(0, n)), 0, 0.0, 0.0, 0, 0))
+        for tune in (dict(), dict(fuse_chain_dir=0), dict(fuse_chain_dir=1)):
+            qc.tune(fuse_chain_dir=-1)
+            qc.tune(**tune)
+            actions, recs, nrec = qc.fusion_plan(n, 0, descs, mode | 4)
+            total += emu.check_chain_layouts(n, actions)
+    assert total > 1000, total
+    # the symbolic check agrees with the enumerating one where both run
+    for n in (14, 16):
+        descs = sweep_descs(n, 2)
+        actions, recs, nrec = qc.fusion_plan(n, 0, descs, mode | 4)
+        assert emu.check_chain_layouts(n, actions) == emu.check_chain_addressing(n, actions)
+        small_ok += 1
+    assert small_ok == 2
+
+
 # ---- compact chains (round 4): the gate list of an inverse QFT on the VIRTUAL register [L register][orbit column] -------------
 @pytest.mark.parametrize("mode", [1, 2], ids=["exact", "tolerance"])
 @pytest.mark.parametrize("C,L,M,a", [(21, 9, 5, 2), (15, 10, 4, 7), (35, 8, 6, 2)])

@@ -172,12 +172,14 @@ def self_launch(ngpus, argv):
     return 0
 
 
-def exchange_selfcheck(make_reg, torch, dist):
+def exchange_selfcheck(make_reg, torch, dist, modes=("overlap", "sync", "pairwise")):
     """N > 1, before the timed region: H on a global qubit applied twice must give the state back (to rounding) --
-    run once through the overlapped, sliced exchange and, if that fails, once through the synchronous unsliced one.
-    Returns the mode that works; raises if neither does.  (A wrong exchange would still produce a plausible-looking
+    run once through the overlapped, sliced all-to-all exchange, if that fails once through the synchronous unsliced one,
+    and if that fails too through the PAIRWISE form (one rank bit per exchange: half a shard to rank ^ 2^j with
+    ncclSend/ncclRecv -- SURVEY s8(e)'s literal form, quantumcomputer_amd/sharded.py).  `modes` narrows the list.
+    Returns the mode that works; raises if none does.  (A wrong exchange would still produce a plausible-looking
     throughput number; this keeps such a number from being printed.)"""
-    for mode in ("overlap", "sync"):
+    for mode in modes:
         reg = make_reg(mode)
         reg.fill_random(5)
         reg.synchronize()
@@ -195,7 +197,7 @@ def exchange_selfcheck(make_reg, torch, dist):
         del reg, before
         if ok:
             return mode
-    raise RuntimeError("sharded exchange self-check failed in both modes (H.H != identity across ranks)")
+    raise RuntimeError(f"sharded exchange self-check failed in every mode tried {tuple(modes)} (H.H != identity across ranks)")
 
 
 def main():
@@ -322,18 +324,26 @@ def main():
             dist.init_process_group(backend, timeout=tmo)
 
         def make(mode, nq, **kw):
-            if mode == "sync":                                       # unsliced, no overlap, async_op=False
+            if mode in ("sync", "pairwise"):                         # unsliced, no overlap, async_op=False
                 kw = dict(kw, slices_log2=0)
+            if mode == "pairwise":                                   # one rank bit per exchange, half a shard to rank ^ 2^j
+                kw = dict(kw, exchange="pairwise")
             r = ShardedRegister(nq, 0, fusion=False, **kw)           # one launch per gate, like the N = 1 headline
-            if mode == "sync":
+            if mode in ("sync", "pairwise"):
                 r.overlap = r.async_exchange = False
             return r
 
         exchange_mode = "none (1 rank)"
         if args.gpus > 1:
-            want = "sync" if os.environ.get("QCX_SHARD_OVERLAP", "1") == "0" else None
+            # QCX_SHARD_EXCHANGE=pairwise / QCX_SHARD_OVERLAP=0 pin the mode (still self-checked); default: the first that works
+            if os.environ.get("QCX_SHARD_EXCHANGE", "").lower() == "pairwise":
+                modes = ("pairwise",)
+            elif os.environ.get("QCX_SHARD_OVERLAP", "1") == "0":
+                modes = ("sync", "pairwise")
+            else:
+                modes = ("overlap", "sync", "pairwise")
             nchk = min(args.n_local, 22) + k
-            exchange_mode = want or exchange_selfcheck(lambda m: make(m, nchk), torch, dist)
+            exchange_mode = exchange_selfcheck(lambda m: make(m, nchk), torch, dist, modes)
         reg = make(exchange_mode, n)
         reg.fill_random(1)
 
@@ -406,8 +416,11 @@ def main():
             try:
                 if args.n_local < 27:
                     raise RuntimeError("skipped: --n-local below 27 (rehearsal run)")
-                r5 = ShardedRegister(25, 5, fusion=True, **({"slices_log2": 0} if exchange_mode == "sync" else {}))
-                if exchange_mode == "sync":
+                kw5 = {"slices_log2": 0} if exchange_mode in ("sync", "pairwise") else {}
+                if exchange_mode == "pairwise":
+                    kw5["exchange"] = "pairwise"
+                r5 = ShardedRegister(25, 5, fusion=True, **kw5)
+                if exchange_mode in ("sync", "pairwise"):
                     r5.overlap = r5.async_exchange = False
 
                 def shor():
@@ -440,7 +453,9 @@ def main():
         if not sharded:
             par = "1 GPU"
         else:
-            par = (f"state sharded by top {k} qubits over {args.gpus} ranks, all-to-all qubit remap for global targets "
+            par = (f"state sharded by top {k} qubits over {args.gpus} ranks, "
+                   + ("pairwise half-shard swap (ncclSend/ncclRecv with rank ^ 2^j) per global target "
+                      if exchange_mode == "pairwise" else "all-to-all qubit remap for global targets ") +
                    f"({exchanges} exchanges in the {args.steps} timed sweeps, "
                    + (f"exchange overlapped with the neighbouring gates on {1 << sigma} slices)" if overlapped else "synchronous unsliced exchange)"))
         out = {
@@ -472,6 +487,7 @@ def main():
         }
         if sharded:
             out["exchange_mode"] = exchange_mode
+            out["exchange_form"] = "pairwise" if exchange_mode == "pairwise" else "alltoall"
             out["config4"] = config4
             out["config5"] = config5
             out["c_host"] = c_host

@@ -1548,7 +1548,15 @@ extern "C" int qcx_measure_state_r(qcx_register *r, double rnd, unsigned long *s
             if (r->compact_orbit[r->compact_ncols - 1] == (1u << M) - 1u) last_excl = ((((uint64_t)1 << (r->n - M)) - 1) << cb) | (r->compact_ncols - 1);
             uint64_t cidx = 0;
             QCX_TRY(qcx_shard_measure_scan(r->compact_amp, nv, 0, last_excl, 0.0, rnd, &found, &cidx, &cum, r->stream));
-            if (found) idx = ((cidx >> cb) << M) | r->compact_orbit[cidx & ((1u << cb) - 1u)];
+            const unsigned col = (unsigned)(cidx & ((1u << cb) - 1u));
+            if (found && col >= r->compact_ncols) {
+                // a hit in a PADDING column: those hold +0 through every gate and add nothing to the sum, so the scan cannot
+                // stop there -- unless the premise broke.  Do not map it through stale orbit slots: expand and scan the register.
+                QCX_TRY(expand_pending(r));
+                found = 0;
+                QCX_TRY(qcx_shard_measure_scan(r->amp, r->n, 0, r->dim - 1, 0.0, rnd, &found, &idx, &cum, r->stream));
+            }
+            else if (found) idx = ((cidx >> cb) << M) | r->compact_orbit[col];
         }
         r->compact_pending = 0;                                             // the collapse below replaces the whole state
     } else

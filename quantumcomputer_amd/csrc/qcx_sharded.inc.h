@@ -678,6 +678,13 @@ static int sh_compact(ShardSet *sh, bool *done)
         SH_DEV(sh, r);
         hipLaunchKernelGGL(k_expand_compact, dim3(grid_for(nchunks, 1, 65536)), dim3(256), 0, sh->st[r], (const amp_t *)c->buf[c->cur][r], sh->buf[sh->cur][r], nchunks, E, (int)tn.fuse_expand_direct);
         HIP_TRY(hipGetLastError());
+        // the expansion READS the companion's buffer on the register's stream: whatever the companion's own streams do next
+        // (the front of the next compact circuit overwrites that buffer) has to wait for it
+        if (r < c->ev_a.size() && c->ev_a[r]) {
+            HIP_TRY(hipEventRecord(c->ev_a[r], sh->st[r]));
+            HIP_TRY(hipStreamWaitEvent(c->st[r], c->ev_a[r], 0));
+            HIP_TRY(hipStreamWaitEvent(c->xs[r], c->ev_a[r], 0));
+        } else HIP_TRY(hipStreamSynchronize(sh->st[r]));
     }
     sh->exchanges += c->exchanges - ex0; sh->pack_passes += c->pack_passes - pp0;
     sh->relayed_bytes += c->relayed_bytes - rb0; sh->overlapped_gates += c->overlapped_gates - og0;

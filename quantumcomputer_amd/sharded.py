@@ -18,6 +18,12 @@ are r.  A logical->physical qubit permutation is kept on the host.
     the Shor circuit two in total.
   * measurement, norm and read-back flush the queue; measurement and read-back also restore the
     identity layout.
+  * PAIRWISE form of the exchange (`exchange="pairwise"` / QCX_SHARD_EXCHANGE=pairwise; SURVEY s8(e)'s literal
+    form, kept as the fallback should the all-to-all misbehave on a node): ONE rank bit j is traded for ONE
+    local bit.  The local bit is brought to the top of the (slice of the) shard by the pack pass, so that the
+    half to give away is contiguous; rank r sends it to r xor 2^j and receives the partner's matching half
+    (dist.batch_isend_irecv = ncclSend/ncclRecv in one group under RCCL; 2^(k-1) disjoint pairs run at once),
+    the qubit map is relabelled -- nothing is sent back.  Same gate kernels, same bits.
 
 All arithmetic runs in libqcx.so through the shard-level C ABI (`HipEngine`); torch only owns the
 device buffers, the stream and the collective.  The engine is injectable so that the host logic can be
@@ -142,12 +148,32 @@ class _Done:
 _DONE = _Done()
 
 
+class _PairWork:
+    """the send + receive of one pairwise half swap; wait() also moves the received half next to the kept one"""
+
+    def __init__(self, reqs, finish):
+        self.reqs, self.finish = reqs, finish
+
+    def wait(self):
+        for r in self.reqs:
+            r.wait()
+        if self.finish is not None:
+            self.finish()
+            self.finish = None
+        return True
+
+
 class ShardedRegister:
     """Register (qc_shor.c:194-203) sharded by its top log2(world) physical index bits."""
 
     def __init__(self, L_size, M_size, device=None, group=None, engine=None, max_queue=8192, slices_log2=None,
-                 dry_run=False, fusion=True):
+                 dry_run=False, fusion=True, exchange=None):
         self.group = group
+        # the form of the exchange step: "alltoall" (all k rank bits traded at once) or "pairwise" (one rank bit per swap)
+        self.exchange_form = (exchange or os.environ.get("QCX_SHARD_EXCHANGE", "alltoall")).lower()
+        if self.exchange_form not in ("alltoall", "pairwise"):
+            raise ValueError("exchange must be 'alltoall' or 'pairwise'")
+        self.pair_swaps = 0               # pairwise half-shard swaps performed
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         k = int(math.log2(self.world))
@@ -286,6 +312,70 @@ class ShardedRegister:
         self.exchanges += 1
         self.pack_passes += 1 if swaps else 0
 
+    # -- the pairwise form: rank bit j <-> the top bit of the slice --------------------------------------
+    def _plan_pair(self, give):
+        """the transposition (if any) that brings local position `give` to the top of the slice"""
+        top = self.slice_bits - 1
+        return [(give, top)] if give != top else []
+
+    def _book_pair(self, swaps, j):
+        for a, b in swaps:
+            la, lb = self.inv[a], self.inv[b]
+            self._set_phys(la, b); self._set_phys(lb, a)
+        top = self.slice_bits - 1
+        lt, lr = self.inv[top], self.inv[self.n_local + j]
+        self._set_phys(lt, self.n_local + j); self._set_phys(lr, top)
+
+    def _peer(self, j):
+        partner = self.rank ^ (1 << j)
+        return partner if self.group is None else dist.get_global_rank(self.group, partner)
+
+    def _swap_slice(self, sidx, swaps, src_buf, dst_buf, j, async_op):
+        """pack (optional) + half swap of one slice with rank ^ 2^j; returns (work, buffer holding the result).
+        With b = this rank's bit j and x = the slice's top bit: an amplitude (rank bit b, top bit x) belongs, after the
+        swap, to the rank whose bit j is x, at top bit b.  So the half x = 1 - b leaves for the partner, and the partner's
+        half x' = b arrives -- at top bit 1 - b (the partner's old rank bit), i.e. exactly where the half that left was."""
+        src, dst = self._views(src_buf)[sidx], self._views(dst_buf)[sidx]
+        if swaps:
+            rev = list(reversed(swaps))
+            self.engine.swap_bits(src, dst, self.slice_bits, [x[0] for x in rev], [x[1] for x in rev])
+            keep_buf, keep, other = dst_buf, dst, src
+        else:
+            keep_buf, keep, other = src_buf, src, dst
+        if self.dry_run:
+            return dist.pair_swap(keep, other, async_op), keep_buf
+        b = (self.rank >> j) & 1
+        w = 1 << self.slice_bits                    # doubles per half: 2 * 2^(slice_bits - 1)
+        lo = (1 - b) * w
+        send, recv = keep[lo:lo + w], other[lo:lo + w]
+        peer = self._peer(j)
+        if self._host_staged:                       # gloo with GPU tensors (rehearsals on one GPU): stage through the host
+            send_h = send.cpu()
+            recv_h = torch.empty_like(send_h)
+            for r in dist.batch_isend_irecv([dist.P2POp(dist.isend, send_h, peer, self.group), dist.P2POp(dist.irecv, recv_h, peer, self.group)]):
+                r.wait()
+            send.copy_(recv_h)
+            return _DONE, keep_buf
+        reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, send, peer, self.group), dist.P2POp(dist.irecv, recv, peer, self.group)])
+        work = _PairWork(reqs, lambda: send.copy_(recv))
+        if not async_op:
+            work.wait()
+        return work, keep_buf
+
+    def _pair_now(self, give, j):
+        """whole-shard pairwise swap without any overlap (restoring the identity layout)"""
+        swaps = self._plan_pair(give)
+        src_buf, dst_buf = self.bufs[self.cur], self.bufs[self.cur ^ 1]
+        out = src_buf
+        for sidx in range(1 << self.sigma):
+            _, out = self._swap_slice(sidx, swaps, src_buf, dst_buf, j, False)
+        if out is dst_buf:
+            self.cur ^= 1
+        self._book_pair(swaps, j)
+        self.exchanges += 1
+        self.pair_swaps += 1
+        self.pack_passes += 1 if swaps else 0
+
     def _local_permute(self, swaps):
         """transpositions among local positions on the whole shard (8 per out-of-place pass)"""
         for lo in range(0, len(swaps), 8):
@@ -305,11 +395,11 @@ class ShardedRegister:
                 return i
         return len(self.queue) + 1
 
-    def _choose_give(self, at):
-        """the k local positions (outside the spectator bits) whose qubits are H targets latest (Belady)"""
+    def _choose_give(self, at, count=None):
+        """the k (or `count`) local positions (outside the spectator bits) whose qubits are H targets latest (Belady)"""
         cand = list(range(self.min_evict, self.slice_bits))
         cand.sort(key=lambda p: (-self._next_use(self.inv[p], at), -p))
-        return sorted(cand[:self.k])
+        return sorted(cand[:self.k if count is None else count])
 
     def _identity(self):
         """restore logical == physical (the order measurement and read-back need)"""
@@ -318,7 +408,18 @@ class ShardedRegister:
         if self.perm == list(range(n)):
             return
         G = list(range(nl, n))
-        if k and any(self.perm[g] != g for g in G):
+        if k and self.exchange_form == "pairwise":
+            for j in range(k):
+                g = nl + j
+                if self.perm[g] == g:
+                    continue
+                if self.perm[g] >= nl:
+                    # the rightful owner of rank bit j sits in a later rank slot: bring it local first (the stranger that
+                    # goes there instead is dealt with when that slot's turn comes)
+                    cand = [p for p in range(self.slice_bits - 1, self.min_evict - 1, -1) if self.inv[p] not in G]
+                    self._pair_now(cand[0], self.perm[g] - nl)
+                self._pair_now(self.perm[g], j)
+        elif k and any(self.perm[g] != g for g in G):
             if any(self.perm[g] >= nl for g in G):
                 # some rightful rank-id qubits sit in the rank id but in the wrong slot / beside strangers:
                 # one trade brings the whole rank id local (giving up positions that hold none of G)
@@ -430,15 +531,12 @@ class ShardedRegister:
         bit, nor a qubit of the rank id)"""
         return g[0] != "h" or self.perm[g[1]] < self.slice_bits
 
-    def _try_compact(self):
-        """Behind the circuit front the M register reads one of the residues of the multiply ladder's orbit; when nothing else
-        in the queue touches it the whole queue runs on a COMPANION register of L + cb qubits -- [L register][orbit column],
-        the same ranks, 2^(M - cb) times smaller: fused passes and all-to-alls alike -- and every rank expands its part into the
-        real register (the C host: sh_compact; one GPU: compact_chain).  Every rank takes the same decision from the same
-        queue.  True: done."""
+    def _compact_local(self):
+        """this rank's own view of whether the queue can run on the companion register: None, or (used, cb, orbit, descs, rest)
+        with the companion in self._comp.  Never raises and runs no collective: the ranks compare notes in _try_compact."""
         eng = self.engine
-        if not (self.fusion and hasattr(eng, "compact_plan") and self.queue) or self.dry_run or os.environ.get("QCX_SHARD_COMPACT", "1") == "0":
-            return False
+        if os.environ.get("QCX_SHARD_COMPACT", "1") == "0":
+            return None
         n, M = self.num_qubits, self.M_size
         descs = []
         for g in self.queue:
@@ -449,27 +547,57 @@ class ShardedRegister:
             else:
                 break
         if not descs or self.n_local < M + 6:
-            return False
-        used, cb, orbit = eng.compact_plan(n, M, 1, descs)
+            return None
+        try:
+            used, cb, orbit = eng.compact_plan(n, M, 1, descs)
+        except Exception:
+            return None
         if not orbit or not used or used >= len(self.queue):
-            return False
+            return None
         rest = self.queue[used:]
         for g in rest:
             if not ((g[0] == "h" and g[1] >= M) or (g[0] == "p" and g[1] >= M and g[2] >= M)):
-                return False
+                return None
         comp = self._comp
         if comp is None or comp.M_size != cb:
             try:
                 comp = ShardedRegister(self.L_size, cb, device=self.device, group=self.group, engine=eng, max_queue=self.max_queue,
-                                       slices_log2=self._slices_log2, fusion=(2 if self.fusion_mode == 2 else True))
-            except ValueError:
-                return False                       # too small for this many ranks
+                                       slices_log2=self._slices_log2, fusion=(2 if self.fusion_mode == 2 else True),
+                                       exchange=self.exchange_form)
+            except Exception:                      # too small for this many ranks (ValueError), or no memory for its two buffers
+                return None
             comp._try_compact = lambda: False      # (never a compact circuit of its own)
             self._comp = comp
+        return used, cb, orbit, descs, rest
+
+    def _try_compact(self):
+        """Behind the circuit front the M register reads one of the residues of the multiply ladder's orbit; when nothing else
+        in the queue touches it the whole queue runs on a COMPANION register of L + cb qubits -- [L register][orbit column],
+        the same ranks, 2^(M - cb) times smaller: fused passes and all-to-alls alike -- and every rank expands its part into the
+        real register (the C host: sh_compact; one GPU: compact_chain).  The companion's flush runs collectives, so the ranks
+        must take the SAME decision: each forms its own (it depends on per-process state -- QCX_SHARD_COMPACT, the library's
+        tune values, whether the companion's buffers could be allocated) and one small all-reduce (min) makes it common; a
+        rank that cannot, vetoes for all.  True: done."""
+        eng = self.engine
+        if not (self.fusion and hasattr(eng, "compact_plan") and self.queue) or self.dry_run:
+            return False
+        plan = self._compact_local()
+        if self.world > 1:
+            cb = plan[1] if plan else 0
+            t = torch.tensor([1.0 if plan else 0.0, float(cb), -float(cb)], dtype=torch.float64, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            v = t.tolist()
+            if v[0] != 1.0 or v[1] != -v[2]:
+                return False
+        if not plan:
+            return False
+        used, cb, orbit, descs, rest = plan
+        n, M = self.num_qubits, self.M_size
+        comp = self._comp
         comp.queue = []
         comp.perm, comp.inv = list(range(comp.num_qubits)), list(range(comp.num_qubits))
         comp._basis_pending = False
-        ex0, pp0, og0 = comp.exchanges, comp.pack_passes, comp.overlapped_gates
+        ex0, pp0, og0, ps0 = comp.exchanges, comp.pack_passes, comp.overlapped_gates, comp.pair_swaps
         eng.compact_front(comp.shard, comp.n_local, self.rank << self.n_local, n, M, 1, descs[:used], cb, orbit)
         sh = M - cb
         comp.queue = [("h", g[1] - sh) if g[0] == "h" else ("p", g[1] - sh, g[2] - sh, g[3], g[4]) for g in rest]
@@ -479,6 +607,7 @@ class ShardedRegister:
         self.exchanges += comp.exchanges - ex0
         self.pack_passes += comp.pack_passes - pp0
         self.overlapped_gates += comp.overlapped_gates - og0
+        self.pair_swaps += comp.pair_swaps - ps0
         self._basis_pending = False
         self.queue = []
         self.fronts += 1
@@ -506,8 +635,14 @@ class ShardedRegister:
                     a -= 1
             self._run_ops([self._resolve(g) for g in q[i:a]], self.shard, nl, 0)
             pre_ops = [self._resolve(g) for g in q[a:x]]            # resolved under the layout before the trade
-            swaps = self._plan_give(self._choose_give(x))
-            self._book(swaps, True)
+            pair_j = -1
+            if self.exchange_form == "pairwise":                    # one rank bit: the one the Hadamard at x needs
+                pair_j = self.perm[q[x][1]] - nl
+                swaps = self._plan_pair(self._choose_give(x, 1)[0])
+                self._book_pair(swaps, pair_j)
+            else:
+                swaps = self._plan_give(self._choose_give(x))
+                self._book(swaps, True)
             # ... and a run after it, under the new layout
             b = x
             while b < len(q) and self._sliceable(q[b]) and not (q[b][0] == "h" and self.perm[q[b][1]] >= nl):
@@ -524,7 +659,10 @@ class ShardedRegister:
             works, outs = [None] * S, [None] * S
             for sidx in range(S):
                 self._run_ops(pre_ops, src_views[sidx], self.slice_bits, sidx)
-                works[sidx], outs[sidx] = self._move_slice(sidx, swaps, src_buf, dst_buf, self.async_exchange)
+                if pair_j >= 0:
+                    works[sidx], outs[sidx] = self._swap_slice(sidx, swaps, src_buf, dst_buf, pair_j, self.async_exchange)
+                else:
+                    works[sidx], outs[sidx] = self._move_slice(sidx, swaps, src_buf, dst_buf, self.async_exchange)
                 if sidx >= 1:
                     works[sidx - 1].wait()
                     view = self._views(outs[sidx - 1])[sidx - 1]
@@ -535,6 +673,7 @@ class ShardedRegister:
             if outs[0] is dst_buf:
                 self.cur ^= 1
             self.exchanges += 1
+            self.pair_swaps += 1 if pair_j >= 0 else 0
             self.pack_passes += 1 if swaps else 0
             self.overlapped_gates += len(pre_ops) + len(post_ops)
             i = b

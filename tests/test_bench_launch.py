@@ -72,3 +72,14 @@ def test_sync_exchange_switch_is_reported():
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
     assert out["exchange_mode"] == "sync" and "synchronous" in out["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+def test_pairwise_exchange_switch_is_reported():
+    """QCX_SHARD_EXCHANGE=pairwise: the sweep runs through half-shard swaps with rank ^ 2^j (send/recv), self-checked first"""
+    r = run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--n-local", "18", "--no-cpu-baseline", "--no-config4"],
+                  extra_env={"QCX_BENCH_BACKEND": "gloo", "QCX_FORCE_DEVICE": "0", "QCX_SHARD_EXCHANGE": "pairwise"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    assert out["exchange_mode"] == "pairwise" and out["exchange_form"] == "pairwise" and "pairwise" in out["config"]["parallelism"]
+    assert abs(out["total_probability_before"] - out["total_probability_after"]) < 1e-12

@@ -342,3 +342,124 @@ def sc_random_programs(rank, world, ob, make):
 def test_sharded_random_programs(world):
     res = run(world, sc_random_programs)
     assert all(ok for _, ok in res), res
+
+
+# ---- the pairwise form of the exchange (north_star's "RCCL pairwise swaps"; QCX_SHARD_EXCHANGE=pairwise) --------------------
+def sc_pairwise(rank, world, ob, make):
+    """every scenario above once more with exchange="pairwise": ONE rank bit per exchange, half a shard to rank ^ 2^j
+    (dist.batch_isend_irecv), relabel, nothing sent back -- H sweeps from permuted layouts, all gate kinds while the map is
+    swapped, slices 1 ... 8 with and without short queues, a Shor circuit with seeded measurements; always the oracle's bits"""
+    res = {}
+    k = world.bit_length() - 1
+    n = 9 + k
+    reg = make(n, 0, exchange="pairwise")
+    reg.fill_random(5)
+    want = ob.fill_random(n, 5)
+    for rep in range(2):
+        for qb in range(n):
+            reg.hadamard_gate(qb); ob.hadamard(want, n, qb)
+    reg.flush()
+    res["sweep_exchanges"], res["sweep_pairs"] = reg.exchanges, reg.pair_swaps
+    res["sweep"] = bool(np.array_equal(bits(reg.gather()), bits(want)))
+    res["identity_restored"] = reg.perm == list(range(n))
+    # all gate kinds, controls / targets on rank bits, right after global Hadamards
+    L, M, Cn = 6 + k, 3, 7
+    n = L + M
+    reg = make(L, M, exchange="pairwise")
+    reg.fill_random(11)
+    want = ob.fill_random(n, 11)
+    top = n - 1
+    prog = [("h", top), ("p", top, top - 1, 0.7), ("p", n - 4, top, math.pi / 8), ("c", 3, top), ("c", 5, top - 1),
+            ("h", 4), ("p", top - 2, 0, 1.1), ("h", top - 1), ("c", 2, 4), ("p", top, 1, -2.0), ("h", top - 3), ("c", 6, n - 4),
+            ("h", top), ("h", top - 1), ("h", top)]
+    for g in prog:
+        if g[0] == "h":
+            reg.hadamard_gate(g[1]); ob.hadamard(want, n, g[1])
+        elif g[0] == "p":
+            reg.c_phase_shift_gate(g[1], g[2], g[3]); ob.cphase(want, n, g[1], g[2], g[3])
+        else:
+            reg.c_amodc_gate(Cn, g[1], g[2]); ob.camodc(want, n, M, Cn, g[1], g[2])
+    res["mixed"] = bool(np.array_equal(bits(reg.gather()), bits(want)))
+    # slices and queue lengths
+    n = 11 + k
+    ok, overlapped = True, 0
+    for sl in (0, 1, 2, 3):
+        for max_queue in (8192, 5):
+            reg = make(n, 0, slices_log2=sl, max_queue=max_queue, exchange="pairwise")
+            reg.fill_random(40 + sl)
+            want = ob.fill_random(n, 40 + sl)
+            for rep in range(2):
+                for qb in list(range(n)) + [n - 1, 3, n - 2]:
+                    reg.hadamard_gate(qb); ob.hadamard(want, n, qb)
+                reg.c_phase_shift_gate(n - 1, 2, 0.3); ob.cphase(want, n, n - 1, 2, 0.3)
+            reg.flush()
+            overlapped += reg.overlapped_gates if reg.sigma >= 2 else 0
+            ok = ok and bool(np.array_equal(bits(reg.gather()), bits(want)))
+    res["slices"], res["overlapped"] = ok, overlapped
+    # Shor circuit + seeded measurements
+    L, M, Cn, a = 6 + k, 4, 15, 7
+    n = L + M
+    reg = make(L, M, exchange="pairwise")
+    reg.reset_register(); reg.quantum_computation(Cn, a)
+    want = np.zeros(2 << n); ob.reset(want, n); ob.quantum_computation(want, n, M, Cn, a)
+    res["shor_norm"] = reg.norm2()
+    res["shor"] = bool(np.array_equal(bits(reg.gather()), bits(want)))
+    rng = ob.Rng(12345)
+    picks = []
+    for _ in range(4):
+        reg.reset_register(); reg.quantum_computation(Cn, a)
+        r = rng.uniform()
+        w = want.copy()
+        picks.append((reg.measure_state(r), ob.measure(w, n, r)))
+        res["shor"] = res["shor"] and bool(np.array_equal(bits(reg.gather()), bits(w)))
+    res["picks"] = picks
+    return res
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_pairwise_exchange(world):
+    res = run(world, sc_pairwise)
+    k = world.bit_length() - 1
+    assert res["sweep"] and res["identity_restored"] and res["mixed"] and res["slices"] and res["shor"], res
+    assert all(g == w for g, w in res["picks"]), res["picks"]
+    assert abs(res["shor_norm"] - 1.0) < 1e-13
+    # one half-shard swap per global target per sweep -- k per sweep, against ONE all-to-all (of (W-1)/W of the shard)
+    assert res["sweep_pairs"] == res["sweep_exchanges"] == 2 * k, res
+    assert res["overlapped"] > 10                       # the sliced pipeline ran with the pairwise moves too
+
+
+def sc_pairwise_random(rank, world, ob, make):
+    res = []
+    for seed in range(6):
+        rs = np.random.RandomState(900 + seed)
+        L, M = int(rs.randint(8, 11)) + (world.bit_length() - 1), int(rs.randint(0, 4))
+        n = L + M
+        Cn = int(rs.randint(2, (1 << M) + 1)) if M else 2
+        reg = make(L, M, slices_log2=int(rs.randint(0, 3)), max_queue=int(rs.choice([7, 8192])), fusion=bool(seed % 2), exchange="pairwise")
+        reg.fill_random(seed)
+        want = ob.fill_random(n, seed)
+        for _ in range(70):
+            kind = rs.randint(0, 10)
+            if kind < 5:
+                qb = int(rs.randint(0, n)) if rs.randint(0, 2) else int(rs.randint(n - 3, n))
+                reg.hadamard_gate(qb); ob.hadamard(want, n, qb)
+            elif kind < 8 or M == 0:
+                c, t = (int(x) for x in rs.choice(n, 2, replace=False))
+                th = float(rs.uniform(-9, 9))
+                reg.c_phase_shift_gate(c, t, th); ob.cphase(want, n, c, t, th)
+            else:
+                atox, ctl = int(rs.randint(0, 1 << 16)), int(rs.randint(M, n))
+                reg.c_amodc_gate(Cn, atox, ctl); ob.camodc(want, n, M, Cn, atox, ctl)
+        same = bool(np.array_equal(bits(reg.gather()), bits(want)))
+        r = float(rs.uniform(0, 1))
+        w2 = want.copy()
+        same = same and reg.measure_state(r) == ob.measure(w2, n, r)
+        res.append((seed, same, reg.pair_swaps))
+    return res
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_pairwise_random_programs(world):
+    res = run(world, sc_pairwise_random)
+    assert all(ok for _, ok, _ in res), res
+    assert sum(p for _, _, p in res) > 0

@@ -67,6 +67,15 @@ class StubDist:
     def get_rank(self, group=None): return 0
     def all_to_all_single(self, dst, src, group=None, async_op=False):
         return self.tl.a2a(self.cur_bits, async_op)
+    def pair_swap(self, keep, other, async_op=False):
+        # the pairwise form (QCX_SHARD_EXCHANGE=pairwise): half of the slice over ONE link, both directions at once
+        tl = self.tl
+        dt = 16.0 * (1 << self.cur_bits) / 2 / (tl.link_gbs * 1e9) * 1e3 + 0.05
+        start = max(tl.compute, tl.comm)
+        tl.comm = start + dt; tl.a2a_ms += dt
+        if not async_op:
+            tl.compute = tl.comm
+        return Work(tl, tl.comm)
 
 
 def run(world, n_local, sweeps, gate_gbs, link_gbs, slices_log2, overlap):

@@ -10,16 +10,30 @@ while [ "$1" != "--" ] && [ $# -gt 0 ]; do WHAT+=("$1"); shift; done
 shift
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
+# the script path is given relative to the repo (see usage); rocprofv3 runs from /tmp, so make it absolute first
+SCRIPT=$1; shift
+case $SCRIPT in /*) ;; *) SCRIPT=$REPO/$SCRIPT ;; esac
+[ -f "$SCRIPT" ] || { echo "prof_cmd.sh: no such script: $SCRIPT" >&2; exit 2; }
+set -- "$SCRIPT" "$@"
+FAILED=0
 cd /tmp && export TMPDIR=/tmp
 for w in "${WHAT[@]}"; do
+rc=0
 case $w in
-trace) rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 "$@" > $OUT/trace.log 2> $OUT/trace.err ;;
-fetch) rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 "$@" > $OUT/fetch.log 2> $OUT/fetch.err ;;
-write) rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 "$@" > $OUT/write.log 2> $OUT/write.err ;;
-sq)    rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 "$@" > $OUT/sq.log 2> $OUT/sq.err ;;
-sq2)   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_sq2 -- python3 "$@" > $OUT/sq2.log 2> $OUT/sq2.err ;;
+trace) rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 "$@" > $OUT/trace.log 2> $OUT/trace.err; rc=$? ;;
+fetch) rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 "$@" > $OUT/fetch.log 2> $OUT/fetch.err; rc=$? ;;
+write) rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 "$@" > $OUT/write.log 2> $OUT/write.err; rc=$? ;;
+sq)    rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 "$@" > $OUT/sq.log 2> $OUT/sq.err; rc=$? ;;
+sq2)   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_sq2 -- python3 "$@" > $OUT/sq2.log 2> $OUT/sq2.err; rc=$? ;;
+*) echo "prof_cmd.sh: unknown pass '$w'" >&2; rc=2 ;;
 esac
-echo "$w done"
+if [ $rc -ne 0 ]; then
+  # a failed pass must not look like an empty profile: say so, show the end of its stderr, skip its summary, fail the script
+  echo "prof_cmd.sh: pass '$w' FAILED (exit $rc)" >&2; tail -n 15 $OUT/$w.err >&2; FAILED=1
+  [ $rc -ge 124 ] && { echo "prof_cmd.sh: stopping after a killed GPU step" >&2; break; }
+else
+  echo "$w done"
+fi
 done
 cd $REPO
 for w in "${WHAT[@]}"; do
@@ -28,5 +42,6 @@ for w in "${WHAT[@]}"; do
   cp profiles/${TAG}_$w.json $OUT/ 2>/dev/null
 done
 find $OUT -name "*.csv" -size +20M -delete
+[ $FAILED -eq 0 ] || { echo "prof_cmd.sh: at least one pass failed" >&2; du -sh $OUT; exit 1; }
 find $OUT -type f \( -name "*.db" -o -name "*.rocpd" \) -delete
 du -sh $OUT

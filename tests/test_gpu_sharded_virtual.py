@@ -21,6 +21,17 @@ class FakeDist:
 
     class ReduceOp:
         SUM = "sum"
+        MIN = "min"
+        MAX = "max"
+
+    class P2POp:
+        def __init__(self, op, tensor, peer, group=None):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    @staticmethod
+    def isend(*a, **k): raise AssertionError("P2P ops go through batch_isend_irecv")
+    @staticmethod
+    def irecv(*a, **k): raise AssertionError("P2P ops go through batch_isend_irecv")
 
     def __init__(self, world):
         import torch
@@ -57,8 +68,25 @@ class FakeDist:
         return _Work()
 
     def all_reduce(self, t, op=None, group=None):
-        vals = self._exchange(t.clone())
-        t.copy_(sum(v.to(t.device) for v in vals))
+        vals = [v.to(t.device) for v in self._exchange(t.clone())]
+        if op == "min":
+            t.copy_(self.torch.stack(vals).amin(dim=0))
+        elif op == "max":
+            t.copy_(self.torch.stack(vals).amax(dim=0))
+        else:
+            t.copy_(sum(vals))
+
+    def batch_isend_irecv(self, ops):
+        """the pairwise form of the exchange: every rank posts one send and one receive with its partner"""
+        sends = {o.peer: o.tensor for o in ops if o.op is FakeDist.isend}
+        allsends = self._exchange(sends)
+        r = self.tls.rank
+        for o in ops:
+            if o.op is FakeDist.irecv:
+                o.tensor.copy_(allsends[o.peer][r])
+        self._sync_all()
+        self.barrier_obj.wait()                      # nobody overwrites a source that is still being read
+        return [_Work()]
 
     def broadcast(self, t, src, group=None):
         vals = self._exchange(t.clone())
@@ -162,3 +190,43 @@ def test_virtual_ranks_shor_and_measurement(ob, world, fusion):
         assert abs(nrm - 1.0) < 1e-12
         assert idx == widx
         assert np.array_equal(bits(collapsed), bits(w2))
+
+
+@pytest.mark.parametrize("world,slices,fusion", [(2, 0, False), (4, 2, True), (8, 1, True)])
+def test_virtual_ranks_pairwise_exchange(ob, world, slices, fusion):
+    """exchange="pairwise" (one rank bit per exchange, half a shard to rank ^ 2^j) on the HIP engine: sweeps from permuted
+    layouts, phases on rank bits, and a Shor circuit with measurement -- the oracle's bits"""
+    n = 17
+    L, M, Cn, a = 13, 5, 21, 2
+    r = 0.4142135623
+
+    def body(rank, SR):
+        reg = SR(n, 0, slices_log2=slices, fusion=fusion, exchange="pairwise")
+        reg.fill_random(3)
+        for rep in range(2):
+            for q in range(n):
+                reg.hadamard_gate(q)
+            reg.c_phase_shift_gate(n - 1, 1, 0.7)
+            reg.c_phase_shift_gate(n - 2, n - 5, -0.2)
+        reg.flush()
+        stats = (reg.exchanges, reg.pair_swaps)
+        state = reg.gather()
+        sh = SR(L, M, fusion=fusion, exchange="pairwise")
+        sh.reset_register(); sh.quantum_computation(Cn, a)
+        final = sh.gather()
+        sh.reset_register(); sh.quantum_computation(Cn, a)
+        return state, stats, final, sh.measure_state(r)
+
+    outs = run_virtual(world, body)
+    want = ob.fill_random(n, 3)
+    for rep in range(2):
+        for q in range(n):
+            ob.hadamard(want, n, q, 8)
+        ob.cphase(want, n, n - 1, 1, 0.7, 8); ob.cphase(want, n, n - 2, n - 5, -0.2, 8)
+    w2 = np.zeros(2 << (L + M)); ob.reset(w2, L + M); ob.quantum_computation(w2, L + M, M, Cn, a, threads=8)
+    k = world.bit_length() - 1
+    for state, stats, final, idx in outs:
+        assert np.array_equal(bits(state), bits(want))
+        assert stats[0] == stats[1] == 2 * k             # one half-shard swap per global target per sweep
+        assert np.array_equal(bits(final), bits(w2))
+        assert idx == ob.measure(w2.copy(), L + M, r)

@@ -267,23 +267,173 @@ static void diag_tables(unsigned n, const std::vector<unsigned> &tl, const std::
     if (area.size() % 4) area.resize(area.size() + 2, 0.0);       // whole 32-byte records
 }
 
+// ---- k_fused_x8: the thread map of every round of a pass ------------------------------------------------------------------
+// LDS slot of tile-local element e in k_fused_x8 (the kernel's x8_swz): the two upper nibbles folded onto the lowest
+static inline unsigned x8_swz_host(unsigned e) { return e ^ ((e >> 4) & 15u) ^ ((e >> 8) & 15u); }
+
+// bank-conflict cost of a lane order (lane bit k rides on tile bit lanes[k]) for the 16-byte LDS accesses of a round: a wave's
+// ds_read_b128 is served in four groups of 16 lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32), each in one cycle
+// when the 16 slots fall on different 16-byte bank groups (slot mod 16); ds_write_b128 in eight groups of 8 consecutive lanes over
+// half the banks (slot mod 8).  Cost = sum over the groups of the worst multiplicity (12 = conflict-free).
+static unsigned x8_lane_cost(const unsigned *lanes)
+{
+    unsigned slot[64];
+    for (unsigned l = 0; l < 64; l++) {
+        unsigned e = 0;
+        for (unsigned k = 0; k < 6; k++) e |= ((l >> k) & 1u) << lanes[k];
+        slot[l] = x8_swz_host(e);
+    }
+    static const unsigned char rgroup[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+    unsigned cost = 0;
+    for (unsigned half = 0; half < 2; half++)
+        for (unsigned g = 0; g < 2; g++) {
+            unsigned cnt[16] = {0}, worst = 0;
+            for (unsigned k = 0; k < 16; k++) worst = std::max(worst, ++cnt[slot[32 * half + rgroup[g][k]] & 15u]);
+            cost += worst;
+        }
+    for (unsigned g = 0; g < 8; g++) {
+        unsigned cnt[8] = {0}, worst = 0;
+        for (unsigned k = 0; k < 8; k++) worst = std::max(worst, ++cnt[slot[8 * g + k] & 7u]);
+        cost += worst;
+    }
+    return cost;
+}
+
+// Who rides where, for every FUSE_ROUND8 round of the pass whose records start at out[first] (T - 3 thread bits: 6 lane bits, then
+// T - 9 wave bits):
+//  * the WAVE number rides on tile bits that no Hadamard of the coming rounds targets, and stays on them as long as that holds --
+//    a wave then owns its part of the tile through all those rounds: header bit 25 tells the kernel to skip the workgroup
+//    barrier in front of the round (the fillers of a pass with outside hot bits are passive for the whole pass: its waves never
+//    meet between fill and store).  Among equally long-lived bits the ones most gates of the round test come first: a gate whose
+//    tile-local condition sits on a wave bit is skipped by half of the waves with two instructions, on a lane bit it leaves half
+//    of every wave idle through its rotations;
+//  * the LANE number takes the other six non-register bits, in the order that costs the fewest LDS bank conflicts.
+// fuse_x8_map = 0: ascending order, a barrier in front of every round.
+static void x8_assign_maps(std::vector<FuseOp> &out, size_t first, unsigned T, const Tune &tn)
+{
+    struct Rd { size_t at; unsigned rb[3]; std::vector<unsigned> votes; };
+    std::vector<Rd> rounds;
+    for (size_t o = first; o < out.size() && (out[o].type & 0xffu) == FUSE_ROUND8; o += 1 + (size_t)out[o].mask) {
+        Rd r; r.at = o; r.votes.assign(T, 0);
+        r.rb[0] = out[o].a & 0xffu; r.rb[1] = (out[o].a >> 8) & 0xffu; r.rb[2] = (out[o].a >> 16) & 0xffu;
+        for (size_t k = 1; k <= (size_t)out[o].mask; k++)
+            if ((out[o + k].type & 0xffu) == FUSE_PHASE) for (unsigned b = 0; b < T; b++) r.votes[b] += (out[o + k].a >> b) & 1u;
+        rounds.push_back(r);
+    }
+    const unsigned nw = T - 9;
+    auto is_reg = [&](size_t r, unsigned b) { return b == rounds[r].rb[0] || b == rounds[r].rb[1] || b == rounds[r].rb[2]; };
+    std::vector<unsigned> W;
+    for (size_t r = 0; r < rounds.size(); r++) {
+        bool keep = tn.fuse_x8_map && r > 0 && W.size() == nw;
+        for (unsigned b : W) keep = keep && !is_reg(r, b);
+        std::vector<unsigned> free_bits;
+        for (unsigned b = 0; b < T; b++) if (!is_reg(r, b)) free_bits.push_back(b);
+        if (!keep) {
+            if (!tn.fuse_x8_map) W.assign(free_bits.end() - nw, free_bits.end());        // plain ascending order: the top free bits
+            else {
+                auto life = [&](unsigned b) { size_t q = r; while (q < rounds.size() && !is_reg(q, b)) q++; return q - r; };
+                std::vector<unsigned> cand(free_bits);
+                std::stable_sort(cand.begin(), cand.end(), [&](unsigned x, unsigned y) {
+                    const size_t lx = life(x), ly = life(y);
+                    if (lx != ly) return lx > ly;
+                    if (rounds[r].votes[x] != rounds[r].votes[y]) return rounds[r].votes[x] > rounds[r].votes[y];
+                    return x > y;
+                });
+                W.assign(cand.begin(), cand.begin() + nw);
+                std::sort(W.begin(), W.end());
+            }
+        }
+        unsigned lanes[6], best[6];
+        { unsigned k = 0; for (unsigned b : free_bits) if (std::find(W.begin(), W.end(), b) == W.end()) lanes[k++] = b; }
+        memcpy(best, lanes, sizeof best);
+        if (tn.fuse_x8_map) {
+            unsigned perm[6] = {0, 1, 2, 3, 4, 5}, best_cost = ~0u;
+            do {
+                unsigned cand[6];
+                for (unsigned k = 0; k < 6; k++) cand[k] = lanes[perm[k]];
+                const unsigned cst = x8_lane_cost(cand);
+                if (cst < best_cost) { best_cost = cst; memcpy(best, cand, sizeof best); }
+            } while (best_cost > 12u && std::next_permutation(perm, perm + 6));
+        }
+        uint64_t map = 0;
+        for (unsigned k = 0; k < 6; k++) map |= (uint64_t)best[k] << (4 * k);
+        for (unsigned k = 0; k < nw; k++) map |= (uint64_t)W[k] << (4 * (6 + k));
+        FuseOp &h = out[rounds[r].at];
+        memcpy(&h.c, &map, sizeof map);
+        h.a &= ~(1u << 25);
+        if (keep) h.a |= 1u << 25;
+    }
+}
+
 // ROUNDS form: group a pass's records into rounds of at most two distinct H bits (the round's register bits);
 // inside a round consecutive phases that rotate the same registers form runs (FUSE_PRUN)
 static void to_rounds(const Tune &tn, const std::vector<FuseOp> &legacy, unsigned T, std::vector<FuseOp> &out, std::vector<unsigned char> &blob,
-                      std::vector<unsigned> *kept_slots = nullptr, unsigned *generic_rounds = nullptr, unsigned maxrb = 2)
+                      std::vector<unsigned> *kept_slots = nullptr, unsigned *generic_rounds = nullptr, unsigned maxrb = 2, bool x8 = false)
 {
+    // x8 (with maxrb = 3): the EXACT walk on 8 amplitudes per thread (k_fused_x8, FUSE_ROUND8): rounds of up to three distinct
+    // Hadamard bits in the general form -- H items and phase runs -- with a run's registers named by a pattern instead of rsel
     // maxrb = 3: radix-8 fast rounds (k_fused_q3): up to three steps H(x) [D(x)] per round; a round of any other shape
     // counts as generic (the caller then plans the pass again in the radix-4 form)
     // tolerance mode (kept_slots != nullptr): a merged diagonal arrives as a FUSE_DIAG record followed by the phases it
     // stands for; a round of the shape H(x) [D(x)] [H(y) [D(y)]] keeps its diagonals (FUSE_QROUND, slots renumbered in the
     // order kept), every other round gets the phases back and is emitted exactly as in the bit-exact modes
     struct Item { FuseOp o; std::vector<FuseOp> alts; };
+    const size_t out_first = out.size();
     std::vector<Item> cur;
     std::vector<unsigned> rb;
     auto close_round = [&]() {
         if (cur.empty()) { rb.clear(); return; }
-        for (unsigned b = T; rb.size() < maxrb && b-- > 0;)
+        for (unsigned b = T; !x8 && rb.size() < maxrb && b-- > 0;)
             if (std::find(rb.begin(), rb.end(), b) == rb.end()) rb.push_back(b);
+        if (x8) {
+            // a round with fewer than three Hadamard bits: the free register bits go to tile-local TARGETS of the round's phases
+            // (a phase whose mask holds a register bit rotates whole waves; on a lane bit it leaves half of every wave idle) --
+            // the targets that most gates of the round name first
+            std::vector<unsigned> votes(T, 0);
+            for (const Item &it : cur) if (it.o.type == FUSE_PHASE) for (unsigned b = 0; b < T; b++) votes[b] += (it.o.a >> b) & 1u;
+            while (rb.size() < 3) {
+                int best = -1;
+                for (unsigned b = 0; b < T; b++) {
+                    if (std::find(rb.begin(), rb.end(), b) != rb.end()) continue;
+                    if (best < 0 || votes[b] >= votes[(unsigned)best]) best = (int)b;          // (ties: the higher bit)
+                }
+                rb.push_back((unsigned)best);
+            }
+            std::sort(rb.begin(), rb.end());
+            bool has_h = false;
+            for (const Item &it : cur) has_h |= (it.o.type == FUSE_H);
+            FuseOp hdr; memset(&hdr, 0, sizeof hdr);
+            hdr.type = FUSE_ROUND8; hdr.a = rb[0] | (rb[1] << 8) | (rb[2] << 16) | ((has_h ? 1u : 0u) << 24);
+            out.push_back(hdr);                                  // (the thread map and the barrier bit: x8_assign_maps, once the pass's rounds are all known)
+            const size_t hdr_at = out.size() - 1;
+            const uint32_t regmask = (1u << rb[0]) | (1u << rb[1]) | (1u << rb[2]);
+            size_t run_hdr = (size_t)-1; uint32_t run_pat = 0;
+            for (const Item &it : cur) {
+                FuseOp o = it.o;
+                if (o.type == FUSE_H) {
+                    const uint32_t j = o.a == rb[0] ? 0u : o.a == rb[1] ? 1u : 2u;
+                    o.a = j; o.type = FUSE_H | ((32u | j) << 8);
+                    run_hdr = (size_t)-1; out.push_back(o); continue;
+                }
+                const uint32_t S = ((o.a >> rb[0]) & 1u) | (((o.a >> rb[1]) & 1u) << 1) | (((o.a >> rb[2]) & 1u) << 2);
+                static const uint32_t pat_of[8] = {0, 1, 2, 4, 3, 5, 6, 7};          // 7: all three register bits -- a phase names at most two qubits
+                const uint32_t pat = pat_of[S];
+                o.a &= ~regmask;
+                o.type = FUSE_PHASE | (pat << 8);
+                if (run_hdr == (size_t)-1 || pat != run_pat || out[run_hdr].mask >= 63u) {
+                    FuseOp rh; memset(&rh, 0, sizeof rh);
+                    rh.type = FUSE_PRUN | ((pat | (has_h ? 0u : 16u)) << 8); rh.a = pat;     // bit 4: the run canonicalises its zeros
+                    run_hdr = out.size(); run_pat = pat;
+                    out.push_back(rh);
+                }
+                out[run_hdr].mask++;
+                out[run_hdr].type += 1u << 16;
+                out.push_back(o);
+            }
+            out[hdr_at].mask = out.size() - 1 - hdr_at;
+            cur.clear(); rb.clear();
+            return;
+        }
         std::sort(rb.begin(), rb.end());
         if (maxrb == 3) {
             uint32_t step[3] = {0, 0, 0};
@@ -436,6 +586,7 @@ static void to_rounds(const Tune &tn, const std::vector<FuseOp> &legacy, unsigne
         } else cur.push_back(Item{o, {}});
     }
     close_round();
+    if (x8) x8_assign_maps(out, out_first, T, tn);
 }
 
 // the rounds-only kernel, built for 6, 7 or 8 waves per SIMD; false when the geometry has no rounds form
@@ -492,6 +643,19 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
     P.xm_off = 0;
     P.dbg = (uint32_t)tn.fuse_dbg | (((uint32_t)tn.fuse_swz & 7u) << 8);
     if ((P.dg_cnt || P.dg_slim == 2) && !P.has_cam) { lut_bytes = 16; P.cam_ctl_local[3] = 16; }       // tolerance-mode pass without multiplies: no scratch
+    if (P.dg_slim == 3) {                 // the exact walk on 8 amplitudes per thread (k_fused_x8): the tile, then the records' outside-tile masks
+        if (P.T < 10 || P.T > 12 || P.has_cam || P.gen || P.zskip || !tn.fuse_ldsdma) { set_error("radix-8 exact pass: unsupported shape (T = %u)", P.T); return QCX_UNKNOWN_ERROR; }
+        P.xm_off = 0;
+        const size_t lds8 = ((size_t)16 << P.T) + 8 * ((size_t)P.xm_cnt + 66);
+        const unsigned grid8 = grid_for(ntiles, 1, tn.fuse_x8_cap);
+        switch (P.T) {
+        case 12: hipLaunchKernelGGL((k_fused_x8<512, 12>), dim3(grid8), dim3(512), lds8, r->stream, amp_in, amp_out, n, P, d_ops, ntiles, d_ops); break;
+        case 11: hipLaunchKernelGGL((k_fused_x8<256, 11>), dim3(grid8), dim3(256), lds8, r->stream, amp_in, amp_out, n, P, d_ops, ntiles, d_ops); break;
+        default: hipLaunchKernelGGL((k_fused_x8<128, 10>), dim3(grid8), dim3(128), lds8, r->stream, amp_in, amp_out, n, P, d_ops, ntiles, d_ops); break;
+        }
+        HIP_TRY(hipGetLastError());
+        return QCX_NO_ERROR;
+    }
     if (P.xm_cnt && !P.dg_slim) {                                                  // + the records' outside-tile masks (phase runs)
         P.xm_off = (uint32_t)((lut_bytes + 7) & ~(size_t)7);
         lut_bytes = P.xm_off + 8 * ((size_t)P.xm_cnt + 66);          // padded: lanes look up to 64 entries past a run
@@ -640,6 +804,7 @@ struct PassShape {
     std::vector<unsigned> hbits;        // the tile's qubits above the low c, ascending
     std::vector<unsigned> tl;           // the tile's qubits in local order
     bool want_q3;
+    bool want_x8;                       // the exact walk on 8 amplitudes per thread (k_fused_x8): phase-dominated bit-exact passes
     bool cols;                          // the generated first pass by columns (K6g): radix-4 rounds; merged diagonals expanded unless cols_tol
     bool cols_tol;
     size_t n_h, n_ph, n_other;
@@ -690,6 +855,7 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         std::vector<FuseOp> legacy;
         bool rounds = tn.fuse_rounds && act.P.T >= 10 && act.P.T <= 12;
         if (sh.want_q3 && !(rounds && act.P.T == 12 && sh.n_other == 0)) return 1;
+        if (sh.want_x8 && !(rounds && sh.n_other == 0 && !tol)) return 1;
         // (tolerance mode: merged diagonals exist in the rounds form only, at most 16 per pass -- their tables live in LDS;
         // otherwise the pass gets the plain phases they were merged from)
         std::vector<unsigned> pass_diags;
@@ -704,11 +870,11 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
             std::vector<unsigned char> blob;
             std::vector<unsigned> kept;                  // old slot numbers of the diagonals that stayed merged, in new-slot order
             unsigned generic_rounds = 0;
-            to_rounds(tn, legacy, act.P.T, all_ops, blob, keep_diags ? &kept : nullptr, &generic_rounds, sh.want_q3 ? 3u : 2u);
+            to_rounds(tn, legacy, act.P.T, all_ops, blob, keep_diags ? &kept : nullptr, &generic_rounds, (sh.want_q3 || sh.want_x8) ? 3u : 2u, sh.want_x8);
             if (sh.want_q3 && (generic_rounds || (n_diag > 0 && (!keep_diags || kept.empty())) || (n_diag == 0 && sh.n_ph + sh.n_other > 0))) {       // not all radix-8 fast rounds: plan this pass again, radix 4
                 all_ops.resize(act.op_off); return 1;
             }
-            act.P.dg_slim = sh.want_q3 ? 2u : (keep_diags && !kept.empty() && generic_rounds == 0) ? 1u : 0u;     // every round is a fast round (2: radix 8)
+            act.P.dg_slim = sh.want_x8 ? 3u : sh.want_q3 ? 2u : (keep_diags && !kept.empty() && generic_rounds == 0) ? 1u : 0u;     // every round is a fast round (2: radix 8); 3: the exact walk on 8 amplitudes per thread
             act.P.tol_scale = 1.0;
             if (sh.want_q3) for (size_t k = 0; k < sh.n_h; k++) act.P.tol_scale *= QCX_SQRT1_2;
             if (keep_diags) {
@@ -724,9 +890,13 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
                 lds = ((size_t)16 << act.P.T) + (sh.n_other ? (size_t)act.P.cam_ctl_local[3] : 16) + blob.size() + 64 + 8 * (nrec + 66) + 16 * 49 * pass_diags.size();
                 limit = (size_t)80 * 1024;
             }
+            if (sh.want_x8) {            // one tile + the records' masks; two workgroups of 2^12 (four of 2^11, eight of 2^10) per CU
+                lds = ((size_t)16 << act.P.T) + 8 * (nrec + 66);
+                limit = (size_t)160 * 1024 / (act.P.T == 12 ? 2 : act.P.T == 11 ? 4 : 8);
+            }
             if (lds > limit) {
                 all_ops.resize(act.op_off); rounds = false;
-                if (sh.want_q3) return 1;                                       // radix-8 records mean nothing to the plain gate list: plan again
+                if (sh.want_q3 || sh.want_x8) return 1;                                       // radix-8 records mean nothing to the plain gate list: plan again
                 act.P.dg_slim = 0; act.P.tol_scale = 1.0;                       // (launch_pass looks at dg_slim first)
                 if (keep_diags) {        // the plain gate list has no diagonal interpreter: back to the phases
                     legacy.clear(); pass_diags.clear(); keep_diags = false;
@@ -876,9 +1046,18 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         // fewer hot bits per pass; and never on the pipelined kernel.
         const unsigned colb = std::min(4u, (unsigned)r->M);       // column bits of the by-columns pass: the lowest M-register bits (a compact chain's virtual register: all of them)
         const unsigned Tp = cols_pass ? colb + 8u : (unsigned)tn.fuse_T_phase;
+        bool want_x8 = false;
         if (!want_q3 && Tp >= 9 && Tp <= 12 && Tp <= n && tn.fuse_rounds && n_other == 0 &&
             (cols_pass || n_ph >= (size_t)tn.fuse_phase_ratio * std::max<size_t>(n_h, 1))) {
-            c = cols_pass ? colb : std::min((unsigned)tn.fuse_c_phase, Tp); budget = Tp - c;
+            // bit-exact phase passes (round 5): the walk on 8 amplitudes per thread (k_fused_x8) -- a tile of 2^12 amplitudes on 512
+            // threads holds 8 hot bits next to c = 4 instead of 6: a pass less for the n = 28 inverse QFT, half the rounds
+            const unsigned Tx = (unsigned)tn.fuse_x8_T;
+            if (!tol && !cols_pass && q3_allowed && tn.fuse_x8 && Tx >= 10 && Tx <= 12 && Tx <= n && tn.fuse_ldsdma && tn.fuse_rounds_occ >= 6) {
+                c = std::min((unsigned)tn.fuse_x8_c, Tx - 1); budget = Tx - c;
+                want_x8 = true;
+            } else {
+                c = cols_pass ? colb : std::min((unsigned)tn.fuse_c_phase, Tp); budget = Tp - c;
+            }
             grow(c, budget);
             act.nopipe = 1;
         }
@@ -892,7 +1071,7 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
             const unsigned top = *std::max_element(hbits.begin(), hbits.end()) + 1;
             // (bit-exact passes only up to 2^11: the 1024-thread form of the exact rounds kernel loses more than the contiguous
             // tile gains -- n = 30 Shor circuit 36.9 -> 40.2 ms when its last pass went to 2^12; the tolerance mode's passes gain: 24.6 -> 23.7)
-            if (top <= (tol ? 12u : 11u) && top <= n && top >= 10 && top > c + hbits.size()) {
+            if (top <= ((tol || want_x8) ? 12u : 11u) && top <= n && top >= 10 && top > c + hbits.size()) {
                 hbits.clear();
                 for (unsigned b = c; b < top; b++) hbits.push_back(b);
                 budget = top - c;
@@ -904,7 +1083,7 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         std::sort(hbits.begin(), hbits.end());
 
         PassShape sh;
-        sh.first = first; sh.last = i; sh.c = c; sh.hbits = hbits; sh.want_q3 = want_q3; sh.cols = cols_pass; sh.cols_tol = cols_pass && first_cols == 2;
+        sh.first = first; sh.last = i; sh.c = c; sh.hbits = hbits; sh.want_q3 = want_q3; sh.want_x8 = want_x8; sh.cols = cols_pass; sh.cols_tol = cols_pass && first_cols == 2;
         sh.n_h = n_h; sh.n_ph = n_ph; sh.n_other = n_other; sh.nopipe = act.nopipe;
         for (unsigned b = 0; b < c; b++) sh.tl.push_back(b);
         for (unsigned b : hbits) sh.tl.push_back(b);
@@ -942,7 +1121,7 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
             // 21.6 ms, tolerance Shor 18.9 vs 20.3); chains of the exact phase walk when a pass STORES whole tiles and the next one
             // gathers (n = 30 Shor circuit 30.9 -> 29.7 ms: its third pass 7.6 -> 6.7)
             bool slim_any = false;
-            for (size_t k = 0; k < m; k++) slim_any |= acts[a0 + k].P.dg_slim != 0;
+            for (size_t k = 0; k < m; k++) slim_any |= acts[a0 + k].P.dg_slim == 1 || acts[a0 + k].P.dg_slim == 2;       // (3 = the exact walk on 8 amplitudes: FP64-bound like the radix-4 walk)
             const bool store_whole = tn.fuse_chain_dir < 0 ? !slim_any : tn.fuse_chain_dir != 0;
             for (size_t k = 0; k + 1 < m; k++) {
                 const PassShape &cur = shapes[shape_of[a0 + k]], &nxt = shapes[shape_of[a0 + k + 1]];
@@ -974,7 +1153,7 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
                 PassShape sh = shapes[shape_of[a0 + k]];
                 std::sort(sh.tl.begin(), sh.tl.end(), [&](unsigned x, unsigned y) { return lay[k][x] < lay[k][y]; });
                 FusePass Pt = acts[a0 + k].P;
-                const bool by_out = Pt.dg_slim != 0 && !store_whole;
+                const bool by_out = (Pt.dg_slim == 1 || Pt.dg_slim == 2) && !store_whole;
                 ok = pass_tables_chained(Pt, n, sh.tl, lay[k], lay[k + 1], by_out);
                 if (!ok && by_out) { Pt = acts[a0 + k].P; ok = pass_tables_chained(Pt, n, sh.tl, lay[k], lay[k + 1], false); }
                 ok = ok && pass_tables_cover(Pt, n);
@@ -1099,7 +1278,7 @@ static int basis_front(qcx_register *r, const std::vector<QGate> &gates, size_t 
 static bool gen_front_build(unsigned n, unsigned M, const BasisFront &B, const FuseAction &act, GenFront *G)
 {
     const FusePass &P = act.P;
-    if (!act.fused || P.has_cam || P.cam_ctl_local[0] != 1 || P.T < 10 || P.T > 12 || M > 12 || B.first != 0 || n > 40) return false;
+    if (!act.fused || P.has_cam || P.cam_ctl_local[0] != 1 || P.T < 10 || P.T > 12 || M > 12 || B.first != 0 || n > 40 || P.dg_slim == 3) return false;
     memset(G, 0, sizeof *G);
     const uint32_t lowmask = (1u << M) - 1u;
     const uint32_t f0 = (uint32_t)(B.basis & lowmask);
@@ -1154,7 +1333,7 @@ static void zskip_setup(std::vector<FuseAction> &acts, std::vector<FuseOp> &all_
 {
     for (FuseAction &a : acts) {
         if (skip_first && &a == &acts[0]) continue;
-        if (!a.fused || a.P.cam_ctl_local[0] != 1 || a.P.has_cam || a.P.dg_slim == 2 || a.P.T < 10 || a.P.T > 12) continue;
+        if (!a.fused || a.P.cam_ctl_local[0] != 1 || a.P.has_cam || a.P.dg_slim >= 2 || a.P.T < 10 || a.P.T > 12) continue;
         const unsigned W = a.P.T - 8;                          // waves per workgroup = 2^W (4 amplitudes per thread)
         std::vector<unsigned> passive;                         // tile-local positions of M-register bits, by ascending qubit
         for (unsigned q = 0; q < M; q++)

@@ -2509,6 +2509,320 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// K6x  the EXACT walk on 8 amplitudes per thread (round 5; bit-exact).  Same records, same per-amplitude arithmetic in the same
+// order as the radix-4 rounds of k_fused_rounds -- a phase is the four products and two sums of rotate_amp without FMA, an H the
+// butterfly of h_butterfly, the canonical "+ 0.0" once per round / run -- but a round carries THREE register bits: a thread keeps
+// the 8 amplitudes that differ in them, three Hadamards and their phase runs cost one LDS round trip and one barrier, and a tile
+// of 2^12 amplitudes needs 512 threads instead of 1024 (8 hot bits per pass next to c = 4: the n = 28 inverse QFT in 3 passes
+// instead of 4).  Round 3 tried this in C++ and lost to the compiler's register copies (21 ms against 12); here the WHOLE round
+// -- the eight LDS reads, the item loop, every rotation, the LDS writes -- is ONE asm statement on FIXED registers:
+//     v[32:63]   the 8 amplitudes: register r (bit j of r = the round's register bit j) is x = v[32+4r : 33+4r], y = v[34+4r : 35+4r]
+//     v[24:31]   four temporaries; v[20:21] / v[22:23] this lane's outside-tile mask of the current / next item; v18, v19 scratch
+//     s[72:79] / s[80:87]  the two record blocks (one s_load_dwordx8 per gate, the next gate's in flight); s[88:89] the item
+//     pointer; s[90:91] live gates of the run; s[92:93] saved EXEC; s94 scratch; s95 / s96 header of this / the next item;
+//     s97 records left in the round; s98 gates of the item
+// all named on the clobber list (the kernel is built for 4 waves per SIMD -- what its LDS tile allows anyway -- so they lie
+// inside the allocator's budget).  Records of a round:
+//   FUSE_ROUND8  a = rb0 | rb1 << 8 | rb2 << 16 | (round contains an H) << 24 | (no barrier needed in front of it) << 25,  mask = records that follow,
+//                c (as 64 bits) = the tile-local bit that thread bit i rides on, 4 bits each (the lane and wave numbers are laid
+//                over the non-register bits in the order the host likes best)
+//   item H       type = FUSE_H | (32 | j) << 8                        H on register bit j
+//   item run     type = FUSE_PRUN | (pat | canon << 4) << 8 | gates << 16   1..63 gates that rotate the same registers:
+//                pat 0 = all eight; 1 / 2 / 3 = those with register bit 0 / 1 / 2 set; 4 / 5 / 6 = with bits {0,1} / {0,2} / {1,2} set
+//   gate of run  as in the radix-4 form: a = tile-local mask without the register bits, mask = outside-tile bits, c, s
+// ---------------------------------------------------------------------------
+enum : uint32_t { FUSE_ROUND8 = 9 };
+
+#define X8X0 "v[32:33]"
+#define X8Y0 "v[34:35]"
+#define X8X1 "v[36:37]"
+#define X8Y1 "v[38:39]"
+#define X8X2 "v[40:41]"
+#define X8Y2 "v[42:43]"
+#define X8X3 "v[44:45]"
+#define X8Y3 "v[46:47]"
+#define X8X4 "v[48:49]"
+#define X8Y4 "v[50:51]"
+#define X8X5 "v[52:53]"
+#define X8Y5 "v[54:55]"
+#define X8X6 "v[56:57]"
+#define X8Y6 "v[58:59]"
+#define X8X7 "v[60:61]"
+#define X8Y7 "v[62:63]"
+#define X8T0 "v[24:25]"
+#define X8T1 "v[26:27]"
+#define X8T2 "v[28:29]"
+#define X8T3 "v[30:31]"
+// two rotations interleaved on the four temporaries (the same sequence as QCX_ROT2)
+#define X8_ROT2(C, S, XA, YA, XB, YB)                                \
+    "v_mul_f64 " X8T0 ", " C ", " XA "\n\t"                          \
+    "v_mul_f64 " X8T1 ", " S ", " YA "\n\t"                          \
+    "v_mul_f64 " X8T2 ", " C ", " YA "\n\t"                          \
+    "v_mul_f64 " X8T3 ", " S ", " XA "\n\t"                          \
+    "v_add_f64 " XA ", " X8T0 ", -" X8T1 "\n\t"                      \
+    "v_mul_f64 " X8T0 ", " C ", " XB "\n\t"                          \
+    "v_mul_f64 " X8T1 ", " S ", " YB "\n\t"                          \
+    "v_add_f64 " YA ", " X8T2 ", " X8T3 "\n\t"                       \
+    "v_mul_f64 " X8T2 ", " C ", " YB "\n\t"                          \
+    "v_mul_f64 " X8T3 ", " S ", " XB "\n\t"                          \
+    "v_add_f64 " XB ", " X8T0 ", -" X8T1 "\n\t"                      \
+    "v_add_f64 " YB ", " X8T2 ", " X8T3 "\n\t"
+#define X8_R2(C, S, i, j) X8_ROT2(C, S, X8X##i, X8Y##i, X8X##j, X8Y##j)
+#define X8_ROTS_0(C, S) X8_R2(C, S, 0, 1) X8_R2(C, S, 2, 3) X8_R2(C, S, 4, 5) X8_R2(C, S, 6, 7)
+#define X8_ROTS_1(C, S) X8_R2(C, S, 1, 3) X8_R2(C, S, 5, 7)
+#define X8_ROTS_2(C, S) X8_R2(C, S, 2, 3) X8_R2(C, S, 6, 7)
+#define X8_ROTS_3(C, S) X8_R2(C, S, 4, 5) X8_R2(C, S, 6, 7)
+#define X8_ROTS_4(C, S) X8_R2(C, S, 3, 7)
+#define X8_ROTS_5(C, S) X8_R2(C, S, 5, 7)
+#define X8_ROTS_6(C, S) X8_R2(C, S, 6, 7)
+#define X8_Z1(i) "v_add_f64 " X8X##i ", " X8X##i ", 0\n\t" "v_add_f64 " X8Y##i ", " X8Y##i ", 0\n\t"
+#define X8_ZERO_0 X8_Z1(0) X8_Z1(1) X8_Z1(2) X8_Z1(3) X8_Z1(4) X8_Z1(5) X8_Z1(6) X8_Z1(7)
+#define X8_ZERO_1 X8_Z1(1) X8_Z1(3) X8_Z1(5) X8_Z1(7)
+#define X8_ZERO_2 X8_Z1(2) X8_Z1(3) X8_Z1(6) X8_Z1(7)
+#define X8_ZERO_3 X8_Z1(4) X8_Z1(5) X8_Z1(6) X8_Z1(7)
+#define X8_ZERO_4 X8_Z1(3) X8_Z1(7)
+#define X8_ZERO_5 X8_Z1(5) X8_Z1(7)
+#define X8_ZERO_6 X8_Z1(6) X8_Z1(7)
+// H between registers A and B (A: the bit clear), without the final "+ 0.0" (the round canonicalises once at its end)
+#define X8_HBF(A, B)                                                 \
+    "v_mul_f64 " X8T0 ", %[hs], " X8X##A "\n\t"                      \
+    "v_mul_f64 " X8T1 ", %[hs], " X8Y##A "\n\t"                      \
+    "v_mul_f64 " X8T2 ", %[hs], " X8X##B "\n\t"                      \
+    "v_mul_f64 " X8T3 ", %[hs], " X8Y##B "\n\t"                      \
+    "v_add_f64 " X8X##A ", " X8T0 ", " X8T2 "\n\t"                   \
+    "v_add_f64 " X8Y##A ", " X8T1 ", " X8T3 "\n\t"                   \
+    "v_add_f64 " X8X##B ", " X8T0 ", -" X8T2 "\n\t"                  \
+    "v_add_f64 " X8Y##B ", " X8T1 ", -" X8T3 "\n\t"
+#define X8_LOADREC(BLK)                                              \
+    "s_ff1_i32_b64 s94, s[90:91]\n\t"                                \
+    "s_bitset0_b64 s[90:91], s94\n\t"                                \
+    "s_lshl_b32 s94, s94, 5\n\t"                                     \
+    "s_load_dwordx8 " BLK ", s[88:89], s94 offset:0x20\n\t"
+// one gate: a tile-local mask word of 0 (the usual case: the target lies outside the tile or on a register bit) skips the lane
+// mask and the EXEC round trip
+#define X8_GATE(M, ROTS)                                             \
+    "s_cmp_eq_u32 " M ", 0\n\t"                                      \
+    "s_cbranch_scc1 6f\n\t"                                          \
+    "v_and_b32 v18, " M ", %[p]\n\t"                                 \
+    "v_cmpx_eq_u32_e32 vcc, " M ", v18\n\t"                          \
+    "s_cbranch_execz 1f\n\t"                                         \
+    ROTS                                                             \
+    "1:\n\t"                                                         \
+    "s_mov_b64 exec, s[92:93]\n\t"                                   \
+    "s_branch 7f\n\t"                                                \
+    "6:\n\t"                                                         \
+    ROTS                                                             \
+    "7:\n\t"
+#define X8_RUN_BODY(R)                                               \
+    X8_LOADREC("s[72:79]")                                           \
+    "2:\n\t"                                                         \
+    "s_waitcnt lgkmcnt(0)\n\t"                                       \
+    "s_cmp_eq_u64 s[90:91], 0\n\t"                                   \
+    "s_cbranch_scc1 3f\n\t"                                          \
+    X8_LOADREC("s[80:87]")                                           \
+    X8_GATE("s73", X8_ROTS_##R("s[76:77]", "s[78:79]"))              \
+    "s_waitcnt lgkmcnt(0)\n\t"                                       \
+    "s_cmp_eq_u64 s[90:91], 0\n\t"                                   \
+    "s_cbranch_scc1 4f\n\t"                                          \
+    X8_LOADREC("s[72:79]")                                           \
+    X8_GATE("s81", X8_ROTS_##R("s[84:85]", "s[86:87]"))              \
+    "s_branch 2b\n\t"                                                \
+    "3:\n\t"                                                         \
+    X8_GATE("s73", X8_ROTS_##R("s[76:77]", "s[78:79]"))              \
+    "s_branch 5f\n\t"                                                \
+    "4:\n\t"                                                         \
+    X8_GATE("s81", X8_ROTS_##R("s[84:85]", "s[86:87]"))              \
+    "5:\n\t"                                                         \
+    "s_bitcmp1_b32 s95, 12\n\t"                                      \
+    "s_cbranch_scc0 99f\n\t"                                         \
+    X8_ZERO_##R                                                      \
+    "s_branch 99f\n\t"
+// address of register r's amplitude: a0 XOR the deltas of its set register bits (v19) -- XOR, not +: the tile sits in LDS under the
+// swizzle x8_swz, which is linear over XOR
+#define X8_ADDR1(D)        "v_xor_b32 v19, " D ", %[a0]\n\t"
+#define X8_ADDR2(D, E)     "v_xor_b32 v19, " D ", %[a0]\n\t" "v_xor_b32 v19, " E ", v19\n\t"
+#define X8_ADDR3(D, E, F)  "v_xor_b32 v19, " D ", %[a0]\n\t" "v_xor_b32 v19, " E ", v19\n\t" "v_xor_b32 v19, " F ", v19\n\t"
+#define X8_ROUND_ALL                                                 \
+    "s_mov_b64 s[88:89], %[item]\n\t"                                \
+    "s_mov_b32 s97, %[cnt]\n\t"                                      \
+    "s_load_dword s95, s[88:89], 0x0\n\t"                            \
+    "ds_read_b64 v[20:21], %[xa]\n\t"                                \
+    "ds_read_b128 v[32:35], %[a0]\n\t"                               \
+    X8_ADDR1("%[d0]") "ds_read_b128 v[36:39], v19\n\t"               \
+    X8_ADDR1("%[d1]") "ds_read_b128 v[40:43], v19\n\t"               \
+    X8_ADDR2("%[d0]", "%[d1]") "ds_read_b128 v[44:47], v19\n\t"      \
+    X8_ADDR1("%[d2]") "ds_read_b128 v[48:51], v19\n\t"               \
+    X8_ADDR2("%[d0]", "%[d2]") "ds_read_b128 v[52:55], v19\n\t"      \
+    X8_ADDR2("%[d1]", "%[d2]") "ds_read_b128 v[56:59], v19\n\t"      \
+    X8_ADDR3("%[d0]", "%[d1]", "%[d2]") "ds_read_b128 v[60:63], v19\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t"                                       \
+    /* ---- one item ---- */                                         \
+    "90:\n\t"                                                        \
+    "s_lshr_b32 s98, s95, 16\n\t"                                    \
+    /* what the NEXT item needs first: its header dword and this lane's entry of its outside-tile masks */ \
+    "s_add_u32 s94, s98, 1\n\t"                                      \
+    "s_lshl_b32 s96, s94, 5\n\t"                                     \
+    "s_load_dword s96, s[88:89], s96\n\t"                            \
+    "v_lshl_add_u32 %[xa], s94, 3, %[xa]\n\t"                        \
+    "ds_read_b64 v[22:23], %[xa]\n\t"                                \
+    /* the run's live gates: lane l tests gate l's outside-tile controls against the tile's base */ \
+    "v_and_b32 v18, %[blo], v20\n\t"                                 \
+    "v_and_b32 v19, %[bhi], v21\n\t"                                 \
+    "v_cmp_eq_u64_e64 s[90:91], v[18:19], v[20:21]\n\t"              \
+    "s_bfm_b64 s[92:93], s98, 0\n\t"                                 \
+    "s_and_b64 s[90:91], s[90:91], s[92:93]\n\t"                     \
+    "s_mov_b64 s[92:93], exec\n\t"                                   \
+    "s_bitcmp1_b32 s95, 13\n\t"                                      \
+    "s_cbranch_scc1 50f\n\t"                                         \
+    "s_cmp_eq_u64 s[90:91], 0\n\t"                                   \
+    "s_cbranch_scc1 99f\n\t"                                         \
+    "s_bfe_u32 s94, s95, 0x30008\n\t"                                \
+    "s_cmp_lt_u32 s94, 4\n\t s_cbranch_scc1 40f\n\t"                 \
+    "s_cmp_lt_u32 s94, 6\n\t s_cbranch_scc1 41f\n\t s_branch 26f\n\t" \
+    "41:\n\t s_cmp_eq_u32 s94, 4\n\t s_cbranch_scc1 24f\n\t s_branch 25f\n\t" \
+    "40:\n\t s_cmp_lt_u32 s94, 2\n\t s_cbranch_scc1 42f\n\t s_cmp_eq_u32 s94, 2\n\t s_cbranch_scc1 22f\n\t s_branch 23f\n\t" \
+    "42:\n\t s_cmp_eq_u32 s94, 0\n\t s_cbranch_scc1 20f\n\t s_branch 21f\n\t" \
+    "20:\n\t" X8_RUN_BODY(0) "21:\n\t" X8_RUN_BODY(1) "22:\n\t" X8_RUN_BODY(2) "23:\n\t" X8_RUN_BODY(3) \
+    "24:\n\t" X8_RUN_BODY(4) "25:\n\t" X8_RUN_BODY(5) "26:\n\t" X8_RUN_BODY(6) \
+    "50:\n\t"                                                        \
+    "s_bfe_u32 s94, s95, 0x20008\n\t"                                \
+    "s_cmp_eq_u32 s94, 0\n\t s_cbranch_scc1 51f\n\t"                 \
+    "s_cmp_eq_u32 s94, 1\n\t s_cbranch_scc1 52f\n\t"                 \
+    X8_HBF(0, 4) X8_HBF(1, 5) X8_HBF(2, 6) X8_HBF(3, 7)              \
+    "s_branch 99f\n\t"                                               \
+    "51:\n\t"                                                        \
+    X8_HBF(0, 1) X8_HBF(2, 3) X8_HBF(4, 5) X8_HBF(6, 7)              \
+    "s_branch 99f\n\t"                                               \
+    "52:\n\t"                                                        \
+    X8_HBF(0, 2) X8_HBF(1, 3) X8_HBF(4, 6) X8_HBF(5, 7)              \
+    "99:\n\t"                                                        \
+    "s_waitcnt lgkmcnt(0)\n\t"                                       \
+    /* on to the next item */                                        \
+    "s_add_u32 s94, s98, 1\n\t"                                      \
+    "s_sub_u32 s97, s97, s94\n\t"                                    \
+    "s_lshl_b32 s94, s94, 5\n\t"                                     \
+    "s_add_u32 s88, s88, s94\n\t"                                    \
+    "s_addc_u32 s89, s89, 0\n\t"                                     \
+    "s_mov_b32 s95, s96\n\t"                                         \
+    "v_mov_b32 v20, v22\n\t"                                         \
+    "v_mov_b32 v21, v23\n\t"                                         \
+    "s_cmp_lg_u32 s97, 0\n\t"                                        \
+    "s_cbranch_scc1 90b\n\t"                                         \
+    /* ---- end of the round: canonical zeros if it held an H, then the eight LDS writes ---- */ \
+    "s_bitcmp1_b32 %[fl], 0\n\t"                                     \
+    "s_cbranch_scc0 98f\n\t"                                         \
+    X8_ZERO_0                                                        \
+    "98:\n\t"                                                        \
+    "ds_write_b128 %[a0], v[32:35]\n\t"                              \
+    X8_ADDR1("%[d0]") "ds_write_b128 v19, v[36:39]\n\t"              \
+    X8_ADDR1("%[d1]") "ds_write_b128 v19, v[40:43]\n\t"              \
+    X8_ADDR2("%[d0]", "%[d1]") "ds_write_b128 v19, v[44:47]\n\t"     \
+    X8_ADDR1("%[d2]") "ds_write_b128 v19, v[48:51]\n\t"              \
+    X8_ADDR2("%[d0]", "%[d2]") "ds_write_b128 v19, v[52:55]\n\t"     \
+    X8_ADDR2("%[d1]", "%[d2]") "ds_write_b128 v19, v[56:59]\n\t"     \
+    X8_ADDR3("%[d0]", "%[d1]", "%[d2]") "ds_write_b128 v19, v[60:63]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t"
+
+// The tile's LDS layout: element e lives in slot e ^ (bits 4-7 of e) ^ (bits 8-11 of e) -- the two upper nibbles folded onto the
+// lowest.  A wave's 64 lanes ride on whatever six tile bits the host picked for the round (x8_assign_maps: bits that few gates of
+// the round test), seldom the lowest six; unswizzled, lanes that differ only in high bits would share their 16-byte bank group
+// (measured: 74 % of the LDS cycles of the first build were bank conflicts).  The map is an involution and linear over XOR, so
+// the fill (LDS-DMA: slot s receives element x8_swz(s)), the rounds and the store all address through XOR of per-bit terms.
+__device__ __forceinline__ uint32_t x8_swz(uint32_t e) { return e ^ ((e >> 4) & 15u) ^ ((e >> 8) & 15u); }
+
+// one whole round of the exact walk on this thread's 8 amplitudes (see K6x above).  a0 = LDS byte address of the slot of element p;
+// d0..d2 = what a set register bit XORs onto it; xaddr = LDS byte address of this lane's entry of the first item's outside-tile masks;
+// item = the first item's record; cnt = records of the round; base = the tile's LOGICAL base index
+__device__ __forceinline__ void fuse_round8(uint32_t a0, unsigned p, uint32_t xaddr, uint64_t base, const FuseOp *item, uint32_t cnt,
+                                            uint32_t d0, uint32_t d1, uint32_t d2, uint32_t has_h)
+{
+    const double hs = QCX_SQRT1_2;
+    const uint32_t blo = (uint32_t)base, bhi = (uint32_t)(base >> 32);
+    asm volatile(X8_ROUND_ALL
+        : [xa] "+v"(xaddr)
+        : [a0] "v"(a0), [p] "v"(p), [blo] "s"(blo), [bhi] "s"(bhi), [item] "s"(item), [cnt] "s"(cnt),
+          [d0] "s"(d0), [d1] "s"(d1), [d2] "s"(d2), [fl] "s"(has_h), [hs] "s"(hs)
+        : "memory", "vcc", "scc",
+          "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31",
+          "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",
+          "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
+          "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87",
+          "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98");
+}
+
+template <int BLOCK, int TT, bool GEN = false>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void k_fused_x8(
+    const amp_t *amp, amp_t *amp_out, unsigned n, FusePass P, const FuseOp *__restrict__ ops, uint64_t ntiles, const FuseOp *ops_asm)
+{
+    static_assert((1u << TT) == 8u * BLOCK, "the exact walk on 8 amplitudes per thread");
+    extern __shared__ __attribute__((aligned(16))) unsigned char qcx_lds_raw[];
+    amp_t *tile = reinterpret_cast<amp_t *>(qcx_lds_raw);
+    constexpr unsigned tsize = 1u << TT;
+    uint64_t *xm = reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(tile + tsize) + P.xm_off);
+    for (unsigned b = threadIdx.x; b < P.xm_cnt + 66u; b += BLOCK) xm[b] = b < P.xm_cnt ? ops[b].mask : 0;    // + padding (a lane looks up to 64 entries past a run)
+    __syncthreads();
+    // fill: slot s = k * BLOCK + thread (what the LDS-DMA writes linearly) receives element x8_swz(s); spread and swizzle are both
+    // linear over XOR, so the thread part and the k part are computed once and combined with XOR
+    const uint64_t off_t = fuse_spread(x8_swz(threadIdx.x), P.in_pos, TT);
+    uint64_t off_k[8], st_k[8];
+    unsigned ld_k[8];
+#pragma unroll
+    for (unsigned k = 0; k < 8; k++) {
+        off_k[k] = fuse_spread(x8_swz(k * BLOCK), P.in_pos, TT);
+        st_k[k] = fuse_spread(k * BLOCK, P.st_pos, TT);
+        ld_k[k] = x8_swz((unsigned)fuse_spread(k * BLOCK, P.st_loc, TT));
+    }
+    const uint64_t st_t = fuse_spread(threadIdx.x, P.st_pos, TT);
+    const unsigned ld_t = x8_swz((unsigned)fuse_spread(threadIdx.x, P.st_loc, TT));
+    const unsigned wbase = (threadIdx.x >> 6) * 64, lane = threadIdx.x & 63u;
+    const uint32_t tile_lds = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) amp_t *)tile;
+    const uint32_t xm_lds = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint64_t *)xm;
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const uint64_t base_in = fuse_deposit(t, P.seg_in, P.nseg_in);
+        uint64_t base = base_in, base_out = base_in;               // logical base (gate records), output base
+        if (P.chained) { base = fuse_deposit(t, P.seg_lg, P.nseg_lg); base_out = fuse_deposit(t, P.seg_out, P.nseg_out); }
+        const amp_t *g = amp + base_in;
+        amp_t *go = amp_out + (base_out | st_t);
+        if (!(P.dbg & 4u)) {
+#pragma unroll
+            for (unsigned k = 0; k < 8; k++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + (off_t ^ off_k[k])),
+                                                 (__attribute__((address_space(3))) void *)(tile + k * BLOCK + wbase), 16, 0, 2);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (!(P.dbg & 1u)) {
+            for (unsigned i = 0; i < P.nops;) {
+                const uint32_t a = ops[i].a;
+                const unsigned rb0 = a & 0xffu, rb1 = (a >> 8) & 0xffu, rb2 = (a >> 16) & 0xffu;
+                const uint32_t cnt = (uint32_t)ops[i].mask;
+                uint64_t map; memcpy(&map, &ops[i].c, sizeof map);
+                unsigned p = 0;
+#pragma unroll
+                for (unsigned k = 0; k < (unsigned)TT - 3u; k++) p |= ((threadIdx.x >> k) & 1u) << ((unsigned)(map >> (4u * k)) & 15u);
+                // bit 25 of the header: this round's waves sit on the same tile bits as the previous round's -- every wave finds
+                // its own amplitudes where it left them (its LDS accesses are served in order) and nobody else's: no barrier
+                if (i != 0 && !((a >> 25) & 1u)) __syncthreads();
+                // the walk reads the records through ops_asm (see fuse_apply_rounds: `ops` itself must not be captured by an asm)
+                fuse_round8(tile_lds + 16u * x8_swz(p), p, xm_lds + 8u * (i + 2u + lane), base, ops_asm + i + 1, cnt,
+                            16u * x8_swz(1u << rb0), 16u * x8_swz(1u << rb1), 16u * x8_swz(1u << rb2), (a >> 24) & 1u);
+                i += 1 + cnt;
+            }
+            __syncthreads();
+        }
+        amp_t v[8];
+#pragma unroll
+        for (unsigned k = 0; k < 8; k++) v[k] = tile[ld_k[k] ^ ld_t];          // (store order: ascending OUTPUT positions; slots under the swizzle)
+        if (!(P.dbg & 2u)) {
+#pragma unroll
+            for (unsigned k = 0; k < 8; k++) __builtin_nontemporal_store(v[k], go + st_k[k]);
+        }
+        __syncthreads();
+    }
+}
+
 // (A persistent, double-buffered form of the pass -- the LDS-DMA fill of tile i+1 in flight while tile i is processed and
 // stored, the wait before use a COUNTED s_waitcnt vmcnt(stores issued after the fill) -- existed in round 1 and is gone:
 // measured slower than this kernel, and the counted wait is not safe on gfx950.  A wave's loads and stores do not

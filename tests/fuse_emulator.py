@@ -13,7 +13,7 @@ import struct
 
 import numpy as np
 
-FUSE_H, FUSE_PHASE, FUSE_CAMODC, FUSE_ROUND, FUSE_PRUN, FUSE_CAMRUN, FUSE_DIAG, FUSE_QROUND, FUSE_QROUND3 = 0, 1, 2, 3, 4, 5, 6, 7, 8
+FUSE_H, FUSE_PHASE, FUSE_CAMODC, FUSE_ROUND, FUSE_PRUN, FUSE_CAMRUN, FUSE_DIAG, FUSE_QROUND, FUSE_QROUND3, FUSE_ROUND8 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 SQRT1_2 = 0.70710678118654752440
 
 
@@ -250,6 +250,57 @@ def apply_pass(state, n, act, recs):
                 if has_h:
                     re += 0.0; im += 0.0
                 i += 1 + cnt
+            elif t == FUSE_ROUND8:
+                # the exact walk on 8 amplitudes per thread (k_fused_x8): three register bits, runs name their registers by pattern
+                rb = [r.a & 0xFF, (r.a >> 8) & 0xFF, (r.a >> 16) & 0xFF]
+                has_h, cnt = (r.a >> 24) & 1, int(r.mask)
+                assert rb[0] < rb[1] < rb[2] < P.T and cnt >= 1 and not nd
+                # the thread-bit map: the T - 3 non-register tile bits, each exactly once, lane bits first
+                tmap = struct.unpack("<Q", struct.pack("<d", r.c))[0]
+                tb = [(tmap >> (4 * k)) & 15 for k in range(P.T - 3)]
+                assert sorted(tb + rb) == list(range(P.T)), ("thread map", tb, rb)
+                # bit 25: no barrier in front of this round -- legal only when the wave number (thread bits 6 and up) rides on the same
+                # tile bits as in the previous round: every wave then reads what it wrote itself and nothing else
+                wave_bits = tuple(tb[6:])
+                if (r.a >> 25) & 1:
+                    assert i > 0 and getattr(P, "x8_wave_bits", None) == wave_bits, "a round without a barrier must keep the waves on their tile bits"
+                    stats["nobarrier"] = stats.get("nobarrier", 0) + 1
+                P.x8_wave_bits = wave_bits
+                stats.setdefault("maps", []).append((tuple(rb), tuple(tb)))
+                qreg = P.bit(rb[0]).astype(np.int64) | (P.bit(rb[1]).astype(np.int64) << 1) | (P.bit(rb[2]).astype(np.int64) << 2)
+                pat_bits = {0: 0, 1: 1, 2: 2, 3: 4, 4: 3, 5: 5, 6: 6}        # pattern -> the register bits a gate's mask held
+                stats["rounds"] += 1
+                saw_h = False
+                o, oend = i + 1, i + cnt
+                while o <= oend:
+                    it = R[o].type
+                    kind, code, rc = it & 0xFF, (it >> 8) & 0xFF, it >> 16
+                    if kind == FUSE_H:
+                        assert (code & 32) and rc == 0 and (code & 3) < 3
+                        _h(re, im, P.gbit(rb[code & 3]), False)
+                        saw_h = True; stats["h"] += 1
+                        o += 1
+                    elif kind == FUSE_PRUN:
+                        pat, canon = code & 7, bool(code & 16)
+                        assert 1 <= rc <= 63 and pat in pat_bits and not (code & 32)
+                        assert canon == (not has_h), "a run canonicalises its own zeros exactly when its round has no H"
+                        need = pat_bits[pat]
+                        held = (qreg & need) == need                     # the registers of the pattern
+                        for g in range(rc):
+                            gr = R[o + 1 + g]
+                            assert (gr.type & 0xFF) == FUSE_PHASE and ((gr.type >> 8) & 7) == pat
+                            assert not (gr.a & ((1 << rb[0]) | (1 << rb[1]) | (1 << rb[2]))), "register bits stay out of the lane mask"
+                            _rotate(re, im, P.outside_all_set(gr.mask) & P.local_all_set(gr.a) & held, gr.c, gr.s, False)
+                        if canon:
+                            re[held] += 0.0; im[held] += 0.0
+                        stats["runs"] += 1; stats["run_gates"] += rc
+                        o += 1 + rc
+                    else:
+                        raise AssertionError(f"item kind {kind} inside a radix-8 exact round")
+                assert o == oend + 1 and saw_h == bool(has_h)
+                if has_h:
+                    re += 0.0; im += 0.0
+                i += 1 + cnt
             elif t == FUSE_QROUND and nd:
                 # tolerance mode fast round: H(x) [D(x)] [H(y) [D(y)]] on the two register bits, two step words in the next record
                 rb0, rb1, ns = r.a & 0xFF, (r.a >> 8) & 0xFF, (r.a >> 16) & 0xFF
@@ -331,7 +382,12 @@ def run_plan(state, n, M, descs, actions, recs, ob):
             st = apply_pass(state, n, act, recs)
             totals["passes"] += 1
             for k, v in st.items():
-                totals[k] += v
+                if k == "maps":
+                    totals.setdefault("maps", []).extend(v)
+                elif k == "nobarrier":
+                    totals["nobarrier"] = totals.get("nobarrier", 0) + v
+                else:
+                    totals[k] += v
         else:
             typ, q, mask, c, s, Cn, A = descs[act.first_gate]
             totals["standalone"] += 1
@@ -470,3 +526,23 @@ def check_chain_layouts(n, actions):
         chained += 1
     assert lay == list(range(n)), "a plan must leave the identity layout behind"
     return chained
+
+
+def x8_swz(e):
+    """LDS slot of tile-local element e in k_fused_x8 (csrc/qcx_kernels.h): the two upper nibbles folded onto the lowest"""
+    return e ^ ((e >> 4) & 15) ^ ((e >> 8) & 15)
+
+
+def x8_lane_conflicts(tb):
+    """worst multiplicity of a 16-byte bank group among the lane groups the LDS serves together, for a round whose lane bit k rides
+    on tile bit tb[k]: (reads, writes); (1, 1) = conflict-free.  Groups as in the MI355X guide's LDS table."""
+    slot = []
+    for l in range(64):
+        e = 0
+        for k in range(6):
+            e |= ((l >> k) & 1) << tb[k]
+        slot.append(x8_swz(e))
+    rg = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    worst_r = max(max(np.bincount([slot[32 * h + l] & 15 for l in g], minlength=16)) for h in range(2) for g in rg)
+    worst_w = max(max(np.bincount([slot[8 * g + k] & 7 for k in range(8)], minlength=8)) for g in range(8))
+    return int(worst_r), int(worst_w)

@@ -14,7 +14,8 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 
 
-TUNE_KEYS = ("fuse_T", "fuse_c", "fuse_rounds", "fuse_camruns", "fuse_T_phase", "fuse_c_phase", "fuse_phase_ratio", "fuse_tol_T", "fuse_q3")
+TUNE_KEYS = ("fuse_T", "fuse_c", "fuse_rounds", "fuse_camruns", "fuse_T_phase", "fuse_c_phase", "fuse_phase_ratio", "fuse_tol_T", "fuse_q3",
+             "fuse_x8", "fuse_x8_T", "fuse_x8_c", "fuse_x8_map")
 
 
 @pytest.fixture()
@@ -65,7 +66,11 @@ def oracle_run(ob, state, n, M, Cn, steps):
 
 CASES = [(12, 0, 1), (13, 4, 15), (14, 5, 21), (11, 4, 15), (12, 6, 35)]
 TUNES = [dict(), dict(fuse_T=10, fuse_c=4), dict(fuse_T=12, fuse_c=3), dict(fuse_T=9, fuse_c=4), dict(fuse_rounds=0),
-         dict(fuse_T_phase=10, fuse_phase_ratio=1), dict(fuse_T_phase=12, fuse_c_phase=2, fuse_phase_ratio=1), dict(fuse_camruns=0)]
+         dict(fuse_T_phase=10, fuse_phase_ratio=1), dict(fuse_T_phase=12, fuse_c_phase=2, fuse_phase_ratio=1), dict(fuse_camruns=0),
+         # round 5: phase-dominated bit-exact passes take the walk on 8 amplitudes per thread (FUSE_ROUND8) by default; the
+         # radix-4 walk stays selectable
+         dict(fuse_x8=0, fuse_phase_ratio=1), dict(fuse_x8_T=11, fuse_x8_c=3, fuse_phase_ratio=1), dict(fuse_x8_T=10, fuse_phase_ratio=1),
+         dict(fuse_x8_map=0, fuse_phase_ratio=1), dict(fuse_x8_T=12, fuse_x8_c=2, fuse_phase_ratio=0)]
 
 
 @pytest.mark.parametrize("tune", TUNES, ids=lambda t: ",".join(f"{k}={v}" for k, v in t.items()) or "default")
@@ -96,12 +101,28 @@ def iqft_descs(qc, n, M):
 
 
 def test_plan_of_the_n28_iqft(qc, tune_guard):
-    """config 3: 28 H + 378 phases -> 4 passes; the three phase-dominated ones on 2^10 tiles, one tile per workgroup"""
+    """config 3: 28 H + 378 phases.  Round 5: 3 passes of the exact walk on 8 amplitudes per thread (2^12 tiles, 8 hot bits next to
+    c = 4; the last one the contiguous low tile with 12 Hadamards); with fuse_x8 = 0 the radix-4 plan of rounds 2-4: 4 passes,
+    the three phase-dominated ones on 2^10 tiles"""
     n = 28
     descs = iqft_descs(qc, n, 0)
     actions, recs, nrec = qc.fusion_plan(n, 0, descs)
-    assert len(descs) == 406 and [a.fused for a in actions] == [1, 1, 1, 1]
+    assert len(descs) == 406 and [a.fused for a in actions] == [1, 1, 1]
     assert sum(a.ngates for a in actions) == 406
+    assert [(a.T, a.c, a.nopipe) for a in actions] == [(12, 4, 1), (12, 4, 1), (12, 4, 1)]
+    hot = [[a.hbit[j] for j in range(a.nh)] for a in actions]
+    assert hot[0] == list(range(20, 28)) and hot[1] == list(range(12, 20)) and hot[2] == list(range(4, 12))
+    for a in actions:
+        assert a.rounds_form == 1
+        R = [recs[a.rec_off + k] for k in range(a.nops)]
+        assert all((r.type & 0xFF) in (emu.FUSE_ROUND8, emu.FUSE_H, emu.FUSE_PRUN, emu.FUSE_PHASE) for r in R)
+        assert sum(1 for r in R if (r.type & 0xFF) == emu.FUSE_ROUND8) == (4 if a is actions[2] else 3)     # three Hadamards per round
+        runs = [r.type >> 16 for r in R if (r.type & 0xFF) == emu.FUSE_PRUN]
+        assert runs and max(runs) <= 63
+        assert sum(runs) + sum(1 for r in R if (r.type & 0xFF) == emu.FUSE_H) == a.ngates
+    qc.tune(fuse_x8=0)
+    actions, recs, nrec = qc.fusion_plan(n, 0, descs)
+    assert [a.fused for a in actions] == [1, 1, 1, 1]
     assert [(a.T, a.c, a.nopipe) for a in actions] == [(10, 4, 1), (10, 4, 1), (10, 4, 1), (11, 4, 0)]
     hot = [[a.hbit[j] for j in range(a.nh)] for a in actions]
     assert hot[0] == [22, 23, 24, 25, 26, 27] and hot[1] == [16, 17, 18, 19, 20, 21] and hot[2] == [10, 11, 12, 13, 14, 15]
@@ -111,6 +132,58 @@ def test_plan_of_the_n28_iqft(qc, tune_guard):
         runs = [r.type >> 16 for r in R if (r.type & 0xFF) == emu.FUSE_PRUN]
         assert runs and max(runs) <= 64
         assert sum(runs) + sum(1 for r in R if (r.type & 0xFF) == emu.FUSE_H) == a.ngates
+
+
+@pytest.mark.parametrize("n,M", [(12, 0), (14, 0), (15, 4), (16, 5)])
+@pytest.mark.parametrize("tune", [dict(), dict(fuse_x8_map=0), dict(fuse_x8_T=11, fuse_x8_c=3), dict(fuse_x8_T=10)],
+                         ids=lambda t: ",".join(f"{k}={v}" for k, v in t.items()) or "default")
+def test_radix8_exact_rounds_on_the_iqft_schedule(qc, ob, tune_guard, n, M, tune):
+    """the schedule of Q:678-690 through FUSE_ROUND8 records against the oracle, bit for bit; every round's thread map is a
+    permutation of its non-register tile bits, and phases whose target is a register bit of the round run on whole waves"""
+    qc.tune(**tune)
+    descs = iqft_descs(qc, n, M)
+    steps = []
+    for l in range(n - 1, M - 1, -1):
+        steps.append(("h", l))
+        for k in range(l - 1, M - 1, -1):
+            steps.append(("p", l, k, math.pi / float(1 << (l - k))))
+    actions, recs, nrec = qc.fusion_plan(n, M, descs)
+    kinds = {recs[a.rec_off + k].type & 0xFF for a in actions if a.fused for k in range(a.nops)}
+    assert emu.FUSE_ROUND8 in kinds
+    state = ob.random_state(n, 9)
+    want = state.copy()
+    oracle_run(ob, want, n, M, 1, steps)
+    totals = emu.run_plan(state, n, M, descs, actions, recs, ob)
+    assert np.array_equal(bits(state), bits(want)), totals
+    assert totals["h"] == n - M and totals["maps"]
+
+
+def test_radix8_thread_maps_of_the_n28_iqft(qc, tune_guard):
+    """the three passes of config 3: in the two passes with outside hot bits the wave number rides on three of the four filler
+    bits for the WHOLE pass (no barrier between rounds: header bit 25), in the last pass (12 Hadamards on the tile's own 12
+    bits) it moves once; every round's lane order is free of LDS bank conflicts under the kernel's swizzle; and the lanes
+    take the bits that fewest gates test"""
+    n = 28
+    descs = iqft_descs(qc, n, 0)
+    actions, recs, nrec = qc.fusion_plan(n, 0, descs)
+    nobar = []
+    for a in actions:
+        R = [recs[a.rec_off + k] for k in range(a.nops)]
+        heads = [r for r in R if (r.type & 0xFF) == emu.FUSE_ROUND8]
+        nobar.append([(h.a >> 25) & 1 for h in heads])
+        for h in heads:
+            import struct
+            tmap = struct.unpack("<Q", struct.pack("<d", h.c))[0]
+            tb = [(tmap >> (4 * k)) & 15 for k in range(9)]
+            assert emu.x8_lane_conflicts(tb[:6]) == (1, 1), (tb, emu.x8_lane_conflicts(tb[:6]))
+        if a is not actions[2]:
+            for h in heads:
+                tmap = struct.unpack("<Q", struct.pack("<d", h.c))[0]
+                assert all(((tmap >> (4 * k)) & 15) < 4 for k in (6, 7, 8)), "the waves of a pass with outside hot bits sit on its fillers"
+    assert nobar[0] == [0, 1, 1] and nobar[1] == [0, 1, 1] and sum(nobar[2]) >= 2, nobar
+    qc.tune(fuse_x8_map=0)
+    actions, recs, nrec = qc.fusion_plan(n, 0, descs)
+    assert not any((recs[a.rec_off + k].a >> 25) & 1 for a in actions for k in range(a.nops) if (recs[a.rec_off + k].type & 0xFF) == emu.FUSE_ROUND8)
 
 
 def test_plan_of_the_n30_shor_circuit(qc, tune_guard):

@@ -34,7 +34,6 @@ def main():
             continue
         T = a.T
         R = [recs[a.rec_off + k] for k in range(a.nops)]
-        waves_per_tile = (1 << T) // 256
         ntiles = 1 << (n - T)
         i = 0
         p_issue = p_ideal = p_mask = p_h = 0.0
@@ -43,10 +42,18 @@ def main():
         while i < a.nops:
             r = R[i]
             t = r.type & 0xFF
-            assert t == emu.FUSE_ROUND, t
+            assert t in (emu.FUSE_ROUND, emu.FUSE_ROUND8), t
+            x8 = t == emu.FUSE_ROUND8
             rb0, rb1, cnt = r.a & 0xFF, (r.a >> 8) & 0xFF, int(r.mask)
             nrounds += 1
-            rest = [j for j in range(T) if j not in (rb0, rb1)]
+            if x8:              # the exact walk on 8 amplitudes per thread: three register bits, the thread map in the header
+                import struct
+                tmap = struct.unpack("<Q", struct.pack("<d", r.c))[0]
+                rest = [(tmap >> (4 * k)) & 15 for k in range(T - 3)]
+                waves_per_tile = (1 << T) // 512
+            else:
+                rest = [j for j in range(T) if j not in (rb0, rb1)]
+                waves_per_tile = (1 << T) // 256
             lane_bits, wave_bits = rest[:6], rest[6:]
             lane_m = sum(1 << j for j in lane_bits)
             wave_m = sum(1 << j for j in wave_bits)
@@ -55,17 +62,18 @@ def main():
                 it = R[o].type
                 kind, code, rc = it & 0xFF, (it >> 8) & 0xFF, it >> 16
                 if kind == emu.FUSE_H:
-                    p_h += 8 * waves_per_tile * ntiles           # 4 products + 4 sums per pair of registers, two pairs
+                    p_h += (32 if x8 else 16) * waves_per_tile * ntiles           # 4 products + 4 sums per pair of registers
                     o += 1
                     continue
                 assert kind == emu.FUSE_PRUN
                 rsel = code & 15
+                nreg_run = {0: 8, 1: 4, 2: 4, 3: 4, 4: 2, 5: 2, 6: 2}[code & 7] if x8 else popcount(rsel)
                 for g in range(rc):
                     gr = R[o + 1 + g]
                     nl = popcount(gr.a & lane_m)
                     nw = popcount(gr.a & wave_m)
                     no = popcount(int(gr.mask))
-                    nreg = popcount(rsel)
+                    nreg = nreg_run
                     waves = waves_per_tile * ntiles / (1 << (nw + no))        # waves that issue the gate
                     p_issue += waves * 6 * nreg
                     p_mask += waves * 2 * (1 if nl else 0)

@@ -16,7 +16,7 @@ from collections import defaultdict
 
 NAMES = ("k_h_pair", "k_h_wave", "k_phase_lines", "k_phase", "k_camodc_table", "k_camodc_oop", "k_camodc", "k_measure", "k_meas_onepass", "k_meas_groups",
          "k_meas_walk", "k_meas_blocksum", "k_meas_composite", "k_meas_chain", "k_meas_prefix", "k_basis_front", "k_norm",
-         "k_fill_random", "k_set_one", "k_fused_rounds", "k_fused", "k_swap_bits", "k_pack")
+         "k_fill_random", "k_set_one", "k_fused_rounds", "k_fused_x8", "k_fused_q3", "k_gen_cols", "k_expand_compact", "k_fused", "k_swap_bits", "k_pack")
 
 
 def short(name):

@@ -362,6 +362,14 @@ static void x8_assign_maps(std::vector<FuseOp> &out, size_t first, unsigned T, c
         memcpy(&h.c, &map, sizeof map);
         h.a &= ~(1u << 25);
         if (keep) h.a |= 1u << 25;
+        // a gate's conditions on the wave bits are wave-uniform: they move from the lane mask into bits 48 .. of the outside mask,
+        // which the kernel tests against base | wave number << 48 in the per-item ballot -- a gate this wave skips costs nothing
+        for (size_t k = 1; k <= (size_t)h.mask; k++) {
+            FuseOp &g = out[rounds[r].at + k];
+            if ((g.type & 0xffu) != FUSE_PHASE) continue;
+            for (unsigned w = 0; w < nw; w++)
+                if ((g.a >> W[w]) & 1u) { g.a &= ~(1u << W[w]); g.mask |= (uint64_t)1 << (48 + w); }
+        }
     }
 }
 

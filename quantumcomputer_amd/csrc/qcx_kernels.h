@@ -2519,7 +2519,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
 // instead of 4).  Round 3 tried this in C++ and lost to the compiler's register copies (21 ms against 12); here the WHOLE round
 // -- the eight LDS reads, the item loop, every rotation, the LDS writes -- is ONE asm statement on FIXED registers:
 //     v[32:63]   the 8 amplitudes: register r (bit j of r = the round's register bit j) is x = v[32+4r : 33+4r], y = v[34+4r : 35+4r]
-//     v[24:31]   four temporaries; v[20:21] / v[22:23] this lane's outside-tile mask of the current / next item; v18, v19 scratch
+//     v[24:31]   four temporaries; v[20:21] this lane's outside-tile mask of the current item (the next item's is fetched into it
+//                as soon as the current one has been tested); v18, v19 scratch
 //     s[72:79] / s[80:87]  the two record blocks (one s_load_dwordx8 per gate, the next gate's in flight); s[88:89] the item
 //     pointer; s[90:91] live gates of the run; s[92:93] saved EXEC; s94 scratch; s95 / s96 header of this / the next item;
 //     s97 records left in the round; s98 gates of the item
@@ -2531,7 +2532,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
 //   item H       type = FUSE_H | (32 | j) << 8                        H on register bit j
 //   item run     type = FUSE_PRUN | (pat | canon << 4) << 8 | gates << 16   1..63 gates that rotate the same registers:
 //                pat 0 = all eight; 1 / 2 / 3 = those with register bit 0 / 1 / 2 set; 4 / 5 / 6 = with bits {0,1} / {0,2} / {1,2} set
-//   gate of run  as in the radix-4 form: a = tile-local mask without the register bits, mask = outside-tile bits, c, s
+//   gate of run  as in the radix-4 form: a = tile-local mask without the register bits, mask = outside-tile bits, c, s; conditions on
+//                the tile bits the round's wave number rides on sit in mask bits 48 .. (bit 48 + k: thread bit 6 + k)
 // ---------------------------------------------------------------------------
 enum : uint32_t { FUSE_ROUND8 = 9 };
 
@@ -2666,16 +2668,16 @@ enum : uint32_t { FUSE_ROUND8 = 9 };
     "s_lshl_b32 s96, s94, 5\n\t"                                     \
     "s_load_dword s96, s[88:89], s96\n\t"                            \
     "v_lshl_add_u32 %[xa], s94, 3, %[xa]\n\t"                        \
-    "ds_read_b64 v[22:23], %[xa]\n\t"                                \
+    "s_bitcmp1_b32 s95, 13\n\t"                                      \
+    "s_cbranch_scc1 50f\n\t"                                         \
     /* the run's live gates: lane l tests gate l's outside-tile controls against the tile's base */ \
     "v_and_b32 v18, %[blo], v20\n\t"                                 \
     "v_and_b32 v19, %[bhi], v21\n\t"                                 \
     "v_cmp_eq_u64_e64 s[90:91], v[18:19], v[20:21]\n\t"              \
+    "ds_read_b64 v[20:21], %[xa]\n\t"                                \
     "s_bfm_b64 s[92:93], s98, 0\n\t"                                 \
     "s_and_b64 s[90:91], s[90:91], s[92:93]\n\t"                     \
     "s_mov_b64 s[92:93], exec\n\t"                                   \
-    "s_bitcmp1_b32 s95, 13\n\t"                                      \
-    "s_cbranch_scc1 50f\n\t"                                         \
     "s_cmp_eq_u64 s[90:91], 0\n\t"                                   \
     "s_cbranch_scc1 99f\n\t"                                         \
     "s_bfe_u32 s94, s95, 0x30008\n\t"                                \
@@ -2687,6 +2689,7 @@ enum : uint32_t { FUSE_ROUND8 = 9 };
     "20:\n\t" X8_RUN_BODY(0) "21:\n\t" X8_RUN_BODY(1) "22:\n\t" X8_RUN_BODY(2) "23:\n\t" X8_RUN_BODY(3) \
     "24:\n\t" X8_RUN_BODY(4) "25:\n\t" X8_RUN_BODY(5) "26:\n\t" X8_RUN_BODY(6) \
     "50:\n\t"                                                        \
+    "ds_read_b64 v[20:21], %[xa]\n\t"                                \
     "s_bfe_u32 s94, s95, 0x20008\n\t"                                \
     "s_cmp_eq_u32 s94, 0\n\t s_cbranch_scc1 51f\n\t"                 \
     "s_cmp_eq_u32 s94, 1\n\t s_cbranch_scc1 52f\n\t"                 \
@@ -2706,8 +2709,6 @@ enum : uint32_t { FUSE_ROUND8 = 9 };
     "s_add_u32 s88, s88, s94\n\t"                                    \
     "s_addc_u32 s89, s89, 0\n\t"                                     \
     "s_mov_b32 s95, s96\n\t"                                         \
-    "v_mov_b32 v20, v22\n\t"                                         \
-    "v_mov_b32 v21, v23\n\t"                                         \
     "s_cmp_lg_u32 s97, 0\n\t"                                        \
     "s_cbranch_scc1 90b\n\t"                                         \
     /* ---- end of the round: canonical zeros if it held an H, then the eight LDS writes ---- */ \
@@ -2745,7 +2746,7 @@ __device__ __forceinline__ void fuse_round8(uint32_t a0, unsigned p, uint32_t xa
         : [a0] "v"(a0), [p] "v"(p), [blo] "s"(blo), [bhi] "s"(bhi), [item] "s"(item), [cnt] "s"(cnt),
           [d0] "s"(d0), [d1] "s"(d1), [d2] "s"(d2), [fl] "s"(has_h), [hs] "s"(hs)
         : "memory", "vcc", "scc",
-          "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31",
+          "v18", "v19", "v20", "v21", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31",
           "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",
           "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
           "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87",
@@ -2761,8 +2762,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     amp_t *tile = reinterpret_cast<amp_t *>(qcx_lds_raw);
     constexpr unsigned tsize = 1u << TT;
     uint64_t *xm = reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(tile + tsize) + P.xm_off);
-    for (unsigned b = threadIdx.x; b < P.xm_cnt + 66u; b += BLOCK) xm[b] = b < P.xm_cnt ? ops[b].mask : 0;    // + padding (a lane looks up to 64 entries past a run)
-    __syncthreads();
+    bool staged = false;
     // fill: slot s = k * BLOCK + thread (what the LDS-DMA writes linearly) receives element x8_swz(s); spread and swizzle are both
     // linear over XOR, so the thread part and the k part are computed once and combined with XOR
     const uint64_t off_t = fuse_spread(x8_swz(threadIdx.x), P.in_pos, TT);
@@ -2777,6 +2777,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     const uint64_t st_t = fuse_spread(threadIdx.x, P.st_pos, TT);
     const unsigned ld_t = x8_swz((unsigned)fuse_spread(threadIdx.x, P.st_loc, TT));
     const unsigned wbase = (threadIdx.x >> 6) * 64, lane = threadIdx.x & 63u;
+    const unsigned wave_id = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t tile_lds = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) amp_t *)tile;
     const uint32_t xm_lds = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint64_t *)xm;
     for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -2791,8 +2792,19 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + (off_t ^ off_k[k])),
                                                  (__attribute__((address_space(3))) void *)(tile + k * BLOCK + wbase), 16, 0, 2);
         }
+        if (!staged) {          // the records' outside-tile masks, once per workgroup -- behind the first tile's fill, not in front of it
+            staged = true;      // (a workgroup usually takes ONE tile: this latency used to be paid per tile, with nothing in flight)
+            for (unsigned b = threadIdx.x; b < P.xm_cnt + 66u; b += BLOCK) xm[b] = b < P.xm_cnt ? ops[b].mask : 0;    // + padding (a lane looks up to 64 entries past a run)
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        // Which part of the tile a wave takes through the rounds rotates with the tile number: gates whose condition sits on a
+        // wave bit are skipped by the waves whose bit is 0, so the parts differ in work (part 7 of a pass with three filler
+        // targets under the wave number runs 24 more gates than part 0), a wave sits on one SIMD for good, and a workgroup
+        // lasts as long as its slowest wave -- with a fixed assignment one SIMD of every CU would carry the heavy parts of
+        // BOTH resident workgroups.  (Fill and store go by the real thread number.)
+        const unsigned wave_eff = (wave_id ^ (unsigned)t ^ (unsigned)(t >> 3)) & ((BLOCK >> 6) - 1u);
+        const unsigned tid_eff = lane | (wave_eff << 6);
         if (!(P.dbg & 1u)) {
             for (unsigned i = 0; i < P.nops;) {
                 const uint32_t a = ops[i].a;
@@ -2801,12 +2813,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
                 uint64_t map; memcpy(&map, &ops[i].c, sizeof map);
                 unsigned p = 0;
 #pragma unroll
-                for (unsigned k = 0; k < (unsigned)TT - 3u; k++) p |= ((threadIdx.x >> k) & 1u) << ((unsigned)(map >> (4u * k)) & 15u);
+                for (unsigned k = 0; k < (unsigned)TT - 3u; k++) p |= ((tid_eff >> k) & 1u) << ((unsigned)(map >> (4u * k)) & 15u);
                 // bit 25 of the header: this round's waves sit on the same tile bits as the previous round's -- every wave finds
                 // its own amplitudes where it left them (its LDS accesses are served in order) and nobody else's: no barrier
                 if (i != 0 && !((a >> 25) & 1u)) __syncthreads();
                 // the walk reads the records through ops_asm (see fuse_apply_rounds: `ops` itself must not be captured by an asm)
-                fuse_round8(tile_lds + 16u * x8_swz(p), p, xm_lds + 8u * (i + 2u + lane), base, ops_asm + i + 1, cnt,
+                // (bits 48 .. of a gate's outside mask: conditions on the tile bits this round's WAVE number rides on -- the host moved
+                //  them there from the lane mask, x8_assign_maps -- so that the per-item ballot already drops the gates this wave skips)
+                fuse_round8(tile_lds + 16u * x8_swz(p), p, xm_lds + 8u * (i + 2u + lane), base | ((uint64_t)wave_eff << 48), ops_asm + i + 1, cnt,
                             16u * x8_swz(1u << rb0), 16u * x8_swz(1u << rb1), 16u * x8_swz(1u << rb2), (a >> 24) & 1u);
                 i += 1 + cnt;
             }

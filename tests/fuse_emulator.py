@@ -290,7 +290,14 @@ def apply_pass(state, n, act, recs):
                             gr = R[o + 1 + g]
                             assert (gr.type & 0xFF) == FUSE_PHASE and ((gr.type >> 8) & 7) == pat
                             assert not (gr.a & ((1 << rb[0]) | (1 << rb[1]) | (1 << rb[2]))), "register bits stay out of the lane mask"
-                            _rotate(re, im, P.outside_all_set(gr.mask) & P.local_all_set(gr.a) & held, gr.c, gr.s, False)
+                            # bits 48 .. of the outside mask: conditions on the tile bits the wave number rides on (thread bits 6 ..)
+                            wloc = 0
+                            for w in range(len(wave_bits)):
+                                if (int(gr.mask) >> (48 + w)) & 1:
+                                    wloc |= 1 << wave_bits[w]
+                            assert not (int(gr.mask) >> (48 + len(wave_bits))) and not (gr.a & sum(1 << b for b in wave_bits)), "wave-bit conditions live in the outside mask"
+                            ext = int(gr.mask) & ((1 << 48) - 1)
+                            _rotate(re, im, P.outside_all_set(ext) & P.local_all_set(gr.a | wloc) & held, gr.c, gr.s, False)
                         if canon:
                             re[held] += 0.0; im[held] += 0.0
                         stats["runs"] += 1; stats["run_gates"] += rc

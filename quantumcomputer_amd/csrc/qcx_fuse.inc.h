@@ -652,15 +652,20 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
     P.dbg = (uint32_t)tn.fuse_dbg | (((uint32_t)tn.fuse_swz & 7u) << 8);
     if ((P.dg_cnt || P.dg_slim == 2) && !P.has_cam) { lut_bytes = 16; P.cam_ctl_local[3] = 16; }       // tolerance-mode pass without multiplies: no scratch
     if (P.dg_slim == 3) {                 // the exact walk on 8 amplitudes per thread (k_fused_x8): the tile, then the records' outside-tile masks
-        if (P.T < 10 || P.T > 12 || P.has_cam || P.gen || P.zskip || !tn.fuse_ldsdma) { set_error("radix-8 exact pass: unsupported shape (T = %u)", P.T); return QCX_UNKNOWN_ERROR; }
+        if (P.T < 10 || P.T > 12 || P.has_cam || P.gen > 1 || P.zskip || !tn.fuse_ldsdma) { set_error("radix-8 exact pass: unsupported shape (T = %u)", P.T); return QCX_UNKNOWN_ERROR; }
         P.xm_off = 0;
-        const size_t lds8 = ((size_t)16 << P.T) + 8 * ((size_t)P.xm_cnt + 66);
+        size_t lds8 = ((size_t)16 << P.T) + 8 * ((size_t)P.xm_cnt + 66);
+        if (P.gen) { P.gen_lds_off = (uint32_t)((8 * ((size_t)P.xm_cnt + 66) + 15) & ~(size_t)15); lds8 = ((size_t)16 << P.T) + P.gen_lds_off + 2 * 1024 * sizeof(unsigned short); }
         const unsigned grid8 = grid_for(ntiles, 1, tn.fuse_x8_cap);
+#define QCX_X8_LAUNCH(B, TTv) do { \
+        if (P.gen) hipLaunchKernelGGL((k_fused_x8<B, TTv, true>), dim3(grid8), dim3(B), lds8, r->stream, amp_in, amp_out, n, P, d_ops, ntiles, d_ops); \
+        else hipLaunchKernelGGL((k_fused_x8<B, TTv, false>), dim3(grid8), dim3(B), lds8, r->stream, amp_in, amp_out, n, P, d_ops, ntiles, d_ops); } while (0)
         switch (P.T) {
-        case 12: hipLaunchKernelGGL((k_fused_x8<512, 12>), dim3(grid8), dim3(512), lds8, r->stream, amp_in, amp_out, n, P, d_ops, ntiles, d_ops); break;
-        case 11: hipLaunchKernelGGL((k_fused_x8<256, 11>), dim3(grid8), dim3(256), lds8, r->stream, amp_in, amp_out, n, P, d_ops, ntiles, d_ops); break;
-        default: hipLaunchKernelGGL((k_fused_x8<128, 10>), dim3(grid8), dim3(128), lds8, r->stream, amp_in, amp_out, n, P, d_ops, ntiles, d_ops); break;
+        case 12: QCX_X8_LAUNCH(512, 12); break;
+        case 11: QCX_X8_LAUNCH(256, 11); break;
+        default: QCX_X8_LAUNCH(128, 10); break;
         }
+#undef QCX_X8_LAUNCH
         HIP_TRY(hipGetLastError());
         return QCX_NO_ERROR;
     }
@@ -1286,7 +1291,7 @@ static int basis_front(qcx_register *r, const std::vector<QGate> &gates, size_t 
 static bool gen_front_build(unsigned n, unsigned M, const BasisFront &B, const FuseAction &act, GenFront *G)
 {
     const FusePass &P = act.P;
-    if (!act.fused || P.has_cam || P.cam_ctl_local[0] != 1 || P.T < 10 || P.T > 12 || M > 12 || B.first != 0 || n > 40 || P.dg_slim == 3) return false;
+    if (!act.fused || P.has_cam || P.cam_ctl_local[0] != 1 || P.T < 10 || P.T > 12 || M > 12 || B.first != 0 || n > 40) return false;
     memset(G, 0, sizeof *G);
     const uint32_t lowmask = (1u << M) - 1u;
     const uint32_t f0 = (uint32_t)(B.basis & lowmask);
@@ -1307,7 +1312,7 @@ static bool gen_front_build(unsigned n, unsigned M, const BasisFront &B, const F
         if (q < M) G->lowbit[j] = (uint8_t)q;
         else { slot_of[q] = (int)h; G->slotbit[j] = (uint8_t)h; h++; }
     }
-    if (h > (P.dg_slim == 2 ? 9u : 10u)) return false;              // the slot tables' room in LDS
+    if (h > (P.dg_slim == 2 ? 9u : 10u)) return false;              // the slot tables' room in LDS (k_fused_x8, dg_slim 3: 1024 slots like the radix-4 kernel)
     G->h = h;
     for (unsigned q = M; q < n; q++)
         if (slot_of[q] >= 0 && ((B.fixed_mask >> q) & 1u)) { G->sfm |= 1u << slot_of[q]; G->sbv |= (uint32_t)((B.basis >> q) & 1u) << slot_of[q]; }

@@ -2421,9 +2421,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
     constexpr unsigned tsize = 1u << TT;
     amp_t *dg = reinterpret_cast<amp_t *>(reinterpret_cast<unsigned char *>(tile + tsize) + P.dg_lds_off);
     const amp_t *dg_area = reinterpret_cast<const amp_t *>(ops + P.dg_rec_off);
-    if constexpr (!EXACT)
-        for (unsigned b = threadIdx.x; b < P.dg_cnt * 48u; b += BLOCK) dg[P.dg_cnt + b] = dg_area[3u * P.dg_cnt + b];
-    __syncthreads();
+    bool staged = EXACT;                 // (the diagonals' G tables are staged once per workgroup, behind the first tile's fill: see below)
     const amp_t *gtab = dg + P.dg_cnt;
     const uint64_t off_t = fuse_spread(threadIdx.x, P.in_pos, TT);
     uint64_t off_k[8], st_k[8];
@@ -2461,6 +2459,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
             for (unsigned k = 0; k < 8; k++)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + off_k[k]),
                                                  (__attribute__((address_space(3))) void *)(tile + k * BLOCK + wbase), 16, 0, 2);
+        }
+        if (!staged) {          // round 5: a workgroup usually takes ONE tile -- the table staging used to sit in front of its fill, a
+            staged = true;      // memory latency per tile with nothing else in flight (the tables are read after the barrier below)
+            for (unsigned b = threadIdx.x; b < P.dg_cnt * 48u; b += BLOCK) dg[P.dg_cnt + b] = dg_area[3u * P.dg_cnt + b];
         }
         if (!EXACT && threadIdx.x < P.dg_cnt) {           // E_out of this tile for every diagonal of the pass, while the fill is in flight
             const DiagInfo *info = reinterpret_cast<const DiagInfo *>(dg_area) + threadIdx.x;
@@ -2780,13 +2782,27 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     const unsigned wave_id = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t tile_lds = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) amp_t *)tile;
     const uint32_t xm_lds = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint64_t *)xm;
+    // GEN: the tiles are generated (the circuit front on a basis state that was never written, GenFront), not read: slot s holds
+    // element x8_swz(s), and the per-element words of the generated fill are linear over XOR like everything else here
+    const GenFront *GF = reinterpret_cast<const GenFront *>(ops + P.gen_rec_off);
+    unsigned short *gen_phot = reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(tile + tsize) + P.gen_lds_off);
+    unsigned short *gen_res = gen_phot + 1024;
+    uint32_t packT = 0, packK[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (GEN) {
+        gen_setup<BLOCK>(GF, gen_phot);
+        packT = gen_pack(x8_swz(threadIdx.x), GF, TT);
+#pragma unroll
+        for (unsigned k = 0; k < 8; k++) packK[k] = gen_pack(x8_swz(k * BLOCK), GF, TT);
+        __syncthreads();
+    }
     for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const uint64_t base_in = fuse_deposit(t, P.seg_in, P.nseg_in);
         uint64_t base = base_in, base_out = base_in;               // logical base (gate records), output base
         if (P.chained) { base = fuse_deposit(t, P.seg_lg, P.nseg_lg); base_out = fuse_deposit(t, P.seg_out, P.nseg_out); }
         const amp_t *g = amp + base_in;
         amp_t *go = amp_out + (base_out | st_t);
-        if (!(P.dbg & 4u)) {
+        if constexpr (GEN) gen_tile<BLOCK, 8>(GF, tile, gen_phot, gen_res, base, packT, packK);
+        else if (!(P.dbg & 4u)) {
 #pragma unroll
             for (unsigned k = 0; k < 8; k++)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + (off_t ^ off_k[k])),

@@ -182,6 +182,28 @@ def test_walk_record_registers_are_private_to_the_walk():
     assert seen == 9
 
 
+def test_exact_walk_on_8_amplitudes_declares_its_fixed_registers():
+    """k_fused_x8 (round 5) runs a whole round as ONE asm statement on fixed registers -- v[18:63], s[72:98] on its clobber
+    list.  They must lie INSIDE the kernel's declared budget (no "reserved register" games: the kernel is built for 4 waves
+    per SIMD, where the allocator's own budget reaches past them), the kernel must not spill, and it must stay free of FMA."""
+    s_path = os.path.join(ROOT, "quantumcomputer_amd", "libqcx.gfx950.s")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "quantumcomputer_amd", "csrc"), "-s", "isa"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert not re.search(r"k_fused_x8[^\n]*\n[^\n]*reserved registers", r.stderr), "the walk's registers must be inside the allocator's budget"
+    txt = open(s_path).read()
+    meta = {m.group(1): (int(m.group(2)), int(m.group(3)), int(m.group(4)))
+            for m in re.finditer(r"\.name:\s*(\S*k_fused_x8\S*)\s.*?\.private_segment_fixed_size:\s*(\d+).*?\.sgpr_count:\s*(\d+).*?\.vgpr_count:\s*(\d+)", txt, re.S)}
+    assert len(meta) == 6, sorted(meta)                       # 2^10, 2^11, 2^12 tiles, each read or generated
+    funcs = {m.group(1): txt[m.start():txt.find(".Lfunc_end", m.start())] for m in re.finditer(r"^(_Z\w+):", txt, re.M)}
+    for name, (scratch, sgpr, vgpr) in meta.items():
+        assert scratch == 0 and sgpr >= 99 and 64 <= vgpr <= 128, (name, scratch, sgpr, vgpr)
+        body = funcs[name]
+        assert not re.search(r"v_fma_f64|v_fmac_f64", body)
+        assert body.count("ds_read_b128 v[32:35]") >= 1 and body.count("s_load_dwordx8 s[72:79], s[88:89]") >= 14
+        assert "v_xor_b32" in body and "global_load_lds_dwordx4" in body or "ELb1EE" in name
+
+
 def test_product_rng_matches_oracle_and_known_answers(qc, ob):
     r = qc.Rng(5489)
     v = [r.get() for _ in range(10000)]

@@ -313,7 +313,8 @@ static void x8_assign_maps(std::vector<FuseOp> &out, size_t first, unsigned T, c
 {
     struct Rd { size_t at; unsigned rb[3]; std::vector<unsigned> votes; };
     std::vector<Rd> rounds;
-    for (size_t o = first; o < out.size() && (out[o].type & 0xffu) == FUSE_ROUND8; o += 1 + (size_t)out[o].mask) {
+    // (FUSE_QROUND3: the tolerance mode's radix-8 fast rounds, run by the same kernel shell -- same maps, the barrier bit is bit 28)
+    for (size_t o = first; o < out.size() && ((out[o].type & 0xffu) == FUSE_ROUND8 || (out[o].type & 0xffu) == FUSE_QROUND3); o += 1 + (size_t)out[o].mask) {
         Rd r; r.at = o; r.votes.assign(T, 0);
         r.rb[0] = out[o].a & 0xffu; r.rb[1] = (out[o].a >> 8) & 0xffu; r.rb[2] = (out[o].a >> 16) & 0xffu;
         for (size_t k = 1; k <= (size_t)out[o].mask; k++)
@@ -360,8 +361,10 @@ static void x8_assign_maps(std::vector<FuseOp> &out, size_t first, unsigned T, c
         for (unsigned k = 0; k < nw; k++) map |= (uint64_t)W[k] << (4 * (6 + k));
         FuseOp &h = out[rounds[r].at];
         memcpy(&h.c, &map, sizeof map);
-        h.a &= ~(1u << 25);
-        if (keep) h.a |= 1u << 25;
+        const unsigned nobar = (h.type & 0xffu) == FUSE_QROUND3 ? 28u : 25u;
+        h.a &= ~(1u << nobar);
+        if (keep) h.a |= 1u << nobar;
+        if ((h.type & 0xffu) == FUSE_QROUND3) continue;
         // a gate's conditions on the wave bits are wave-uniform: they move from the lane mask into bits 48 .. of the outside mask,
         // which the kernel tests against base | wave number << 48 in the per-item ballot -- a gate this wave skips costs nothing
         for (size_t k = 1; k <= (size_t)h.mask; k++) {
@@ -594,7 +597,7 @@ static void to_rounds(const Tune &tn, const std::vector<FuseOp> &legacy, unsigne
         } else cur.push_back(Item{o, {}});
     }
     close_round();
-    if (x8) x8_assign_maps(out, out_first, T, tn);
+    if (x8 || (maxrb == 3 && T == 12)) x8_assign_maps(out, out_first, T, tn);
 }
 
 // the rounds-only kernel, built for 6, 7 or 8 waves per SIMD; false when the geometry has no rounds form
@@ -706,6 +709,13 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
         else hipLaunchKernelGGL((k_fused<B, TTv, false>), dim3(grid), dim3(B), lds, r->stream, amp_in, n, P, d_ops, ntiles, d_ops); } while (0)
     if (P.dg_slim == 2) {                 // tolerance mode, radix-8 fast rounds only
         if (P.T != 12) { set_error("radix-8 pass on a tile of 2^%u amplitudes", P.T); return QCX_UNKNOWN_ERROR; }
+        if (P.dg_cnt && !P.gen && tn.fuse_x8t) {              // round 5: the hand-written round on the k_fused_x8 shell (K6x-t)
+            P.dg_lds_off = 0;
+            const size_t lds8 = ((size_t)16 << P.T) + 16 * (size_t)P.dg_cnt * 49;
+            hipLaunchKernelGGL((k_fused_x8<512, 12, false, true>), dim3(grid_for(ntiles, 1, tn.fuse_x8_cap)), dim3(512), lds8, r->stream, amp_in, amp_out, n, P, d_ops, ntiles, d_ops);
+            HIP_TRY(hipGetLastError());
+            return QCX_NO_ERROR;
+        }
         // (a few workgroups per CU that walk the tiles: 2048 workgroups 6.3 ms, 24576 7.0 ms, one per tile 8.3 ms at n = 28)
         // (the Hadamard-only exact form likes more of them: n = 30 sweep 23.5 ms with 8192, 23.9 with 3072)
         const unsigned grid3 = grid_for(ntiles, 1, P.dg_cnt ? tn.fuse_q3_cap : tn.fuse_q3_cap_exact);
@@ -1060,12 +1070,17 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         const unsigned colb = std::min(4u, (unsigned)r->M);       // column bits of the by-columns pass: the lowest M-register bits (a compact chain's virtual register: all of them)
         const unsigned Tp = cols_pass ? colb + 8u : (unsigned)tn.fuse_T_phase;
         bool want_x8 = false;
+        // (the walk on 8 amplitudes takes a pass as soon as it holds fuse_x8_ratio phases per Hadamard -- far fewer than what makes
+        //  a radix-4 pass "phase-dominated": the tail of an inverse QFT, 9 Hadamards with 36 phases, is then ONE pass of 8 hot bits
+        //  instead of two of 7)
+        const bool x8_ok = !tol && !cols_pass && q3_allowed && tn.fuse_x8 && tn.fuse_x8_T >= 10 && tn.fuse_x8_T <= 12 && (unsigned)tn.fuse_x8_T <= n &&
+                           tn.fuse_ldsdma && tn.fuse_rounds_occ >= 6 && n_ph >= 1 && n_ph >= (size_t)tn.fuse_x8_ratio * std::max<size_t>(n_h, 1);
         if (!want_q3 && Tp >= 9 && Tp <= 12 && Tp <= n && tn.fuse_rounds && n_other == 0 &&
-            (cols_pass || n_ph >= (size_t)tn.fuse_phase_ratio * std::max<size_t>(n_h, 1))) {
+            (cols_pass || x8_ok || n_ph >= (size_t)tn.fuse_phase_ratio * std::max<size_t>(n_h, 1))) {
             // bit-exact phase passes (round 5): the walk on 8 amplitudes per thread (k_fused_x8) -- a tile of 2^12 amplitudes on 512
             // threads holds 8 hot bits next to c = 4 instead of 6: a pass less for the n = 28 inverse QFT, half the rounds
             const unsigned Tx = (unsigned)tn.fuse_x8_T;
-            if (!tol && !cols_pass && q3_allowed && tn.fuse_x8 && Tx >= 10 && Tx <= 12 && Tx <= n && tn.fuse_ldsdma && tn.fuse_rounds_occ >= 6) {
+            if (x8_ok) {
                 c = std::min((unsigned)tn.fuse_x8_c, Tx - 1); budget = Tx - c;
                 want_x8 = true;
             } else {

@@ -2479,7 +2479,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
             for (unsigned i = 0; i < P.nops; i += 2) {
                 const uint32_t a = ops[i].a;
                 const unsigned rb[3] = {a & 0xffu, (a >> 8) & 0xffu, (a >> 16) & 0xffu};
-                const unsigned nsteps = a >> 24;
+                const unsigned nsteps = (a >> 24) & 3u;
                 const uint32_t sA = ops[i + 1].type, sB = ops[i + 1].a, sC = (uint32_t)ops[i + 1].mask;
                 const unsigned p = (unsigned)insert_zero(insert_zero(insert_zero(threadIdx.x, rb[0]), rb[1]), rb[2]);
                 // (which register bit each step works on is a compile-time fact of the variant: see qround_run)
@@ -2755,15 +2755,296 @@ __device__ __forceinline__ void fuse_round8(uint32_t a0, unsigned p, uint32_t xa
           "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98");
 }
 
-template <int BLOCK, int TT, bool GEN = false>
+
+// ---------------------------------------------------------------------------
+// K6x-t  TOLERANCE MODE on the same shell (round 5; opt-in, NOT bit-exact -- the arithmetic of K6t-8 / k_fused_q3, whose records it
+// reads: FUSE_QROUND3 rounds of up to three steps H(x) [D(x)]).  k_fused_q3 is C++ and the compiler's version of a round copies the
+// eight amplitudes between register sets (44 % of its vector instructions were moves: the pass was bound by them, 4.3 ms of
+// arithmetic next to 4.6 ms of memory for the n = 28 inverse QFT).  Here a round is one asm statement on fixed registers:
+//     v[32:63]   the 8 amplitudes; the unscaled butterfly of a pair works in place as a' = a + b, b' = a' - 2 b (an add and an FMA)
+//     v[64:67]   F = E_out(tile) x the G-table entries of this thread's tile bits;  v[68:79] the entries, then F w1, F w2, F w1 w2
+//     v[24:31]   w1, w2: the factors of the step's other two register bits ((1, 0) where the diagonal does not target them)
+//     v[20:23]   temporaries, v19 an address
+// The header of a round carries what FUSE_ROUND8 carries: the thread map in c (x8_assign_maps) and -- bit 28 of a -- "no barrier
+// needed in front of this round".
+// ---------------------------------------------------------------------------
+// (generated by a small script: the butterflies of a step per register bit -- in place: a' = a + b, b' = a' - 2 b, one rounding
+//  each, no second register set --, the diagonal of a step per register bit, F times a table entry)
+#define X8T_H_0 \
+    "v_add_f64 v[32:33], v[32:33], v[36:37]\n\t" \
+    "v_fma_f64 v[36:37], -2.0, v[36:37], v[32:33]\n\t" \
+    "v_add_f64 v[34:35], v[34:35], v[38:39]\n\t" \
+    "v_fma_f64 v[38:39], -2.0, v[38:39], v[34:35]\n\t" \
+    "v_add_f64 v[40:41], v[40:41], v[44:45]\n\t" \
+    "v_fma_f64 v[44:45], -2.0, v[44:45], v[40:41]\n\t" \
+    "v_add_f64 v[42:43], v[42:43], v[46:47]\n\t" \
+    "v_fma_f64 v[46:47], -2.0, v[46:47], v[42:43]\n\t" \
+    "v_add_f64 v[48:49], v[48:49], v[52:53]\n\t" \
+    "v_fma_f64 v[52:53], -2.0, v[52:53], v[48:49]\n\t" \
+    "v_add_f64 v[50:51], v[50:51], v[54:55]\n\t" \
+    "v_fma_f64 v[54:55], -2.0, v[54:55], v[50:51]\n\t" \
+    "v_add_f64 v[56:57], v[56:57], v[60:61]\n\t" \
+    "v_fma_f64 v[60:61], -2.0, v[60:61], v[56:57]\n\t" \
+    "v_add_f64 v[58:59], v[58:59], v[62:63]\n\t" \
+    "v_fma_f64 v[62:63], -2.0, v[62:63], v[58:59]\n\t"
+#define X8T_H_1 \
+    "v_add_f64 v[32:33], v[32:33], v[40:41]\n\t" \
+    "v_fma_f64 v[40:41], -2.0, v[40:41], v[32:33]\n\t" \
+    "v_add_f64 v[34:35], v[34:35], v[42:43]\n\t" \
+    "v_fma_f64 v[42:43], -2.0, v[42:43], v[34:35]\n\t" \
+    "v_add_f64 v[36:37], v[36:37], v[44:45]\n\t" \
+    "v_fma_f64 v[44:45], -2.0, v[44:45], v[36:37]\n\t" \
+    "v_add_f64 v[38:39], v[38:39], v[46:47]\n\t" \
+    "v_fma_f64 v[46:47], -2.0, v[46:47], v[38:39]\n\t" \
+    "v_add_f64 v[48:49], v[48:49], v[56:57]\n\t" \
+    "v_fma_f64 v[56:57], -2.0, v[56:57], v[48:49]\n\t" \
+    "v_add_f64 v[50:51], v[50:51], v[58:59]\n\t" \
+    "v_fma_f64 v[58:59], -2.0, v[58:59], v[50:51]\n\t" \
+    "v_add_f64 v[52:53], v[52:53], v[60:61]\n\t" \
+    "v_fma_f64 v[60:61], -2.0, v[60:61], v[52:53]\n\t" \
+    "v_add_f64 v[54:55], v[54:55], v[62:63]\n\t" \
+    "v_fma_f64 v[62:63], -2.0, v[62:63], v[54:55]\n\t"
+#define X8T_H_2 \
+    "v_add_f64 v[32:33], v[32:33], v[48:49]\n\t" \
+    "v_fma_f64 v[48:49], -2.0, v[48:49], v[32:33]\n\t" \
+    "v_add_f64 v[34:35], v[34:35], v[50:51]\n\t" \
+    "v_fma_f64 v[50:51], -2.0, v[50:51], v[34:35]\n\t" \
+    "v_add_f64 v[36:37], v[36:37], v[52:53]\n\t" \
+    "v_fma_f64 v[52:53], -2.0, v[52:53], v[36:37]\n\t" \
+    "v_add_f64 v[38:39], v[38:39], v[54:55]\n\t" \
+    "v_fma_f64 v[54:55], -2.0, v[54:55], v[38:39]\n\t" \
+    "v_add_f64 v[40:41], v[40:41], v[56:57]\n\t" \
+    "v_fma_f64 v[56:57], -2.0, v[56:57], v[40:41]\n\t" \
+    "v_add_f64 v[42:43], v[42:43], v[58:59]\n\t" \
+    "v_fma_f64 v[58:59], -2.0, v[58:59], v[42:43]\n\t" \
+    "v_add_f64 v[44:45], v[44:45], v[60:61]\n\t" \
+    "v_fma_f64 v[60:61], -2.0, v[60:61], v[44:45]\n\t" \
+    "v_add_f64 v[46:47], v[46:47], v[62:63]\n\t" \
+    "v_fma_f64 v[62:63], -2.0, v[62:63], v[46:47]\n\t"
+#define X8T_D_0 \
+    "v_mul_f64 v[20:21], v[26:27], v[66:67]\n\t" \
+    "v_mul_f64 v[70:71], v[26:27], v[64:65]\n\t" \
+    "v_fma_f64 v[68:69], v[24:25], v[64:65], -v[20:21]\n\t" \
+    "v_fma_f64 v[70:71], v[24:25], v[66:67], v[70:71]\n\t" \
+    "v_mul_f64 v[20:21], v[30:31], v[66:67]\n\t" \
+    "v_mul_f64 v[74:75], v[30:31], v[64:65]\n\t" \
+    "v_fma_f64 v[72:73], v[28:29], v[64:65], -v[20:21]\n\t" \
+    "v_fma_f64 v[74:75], v[28:29], v[66:67], v[74:75]\n\t" \
+    "v_mul_f64 v[20:21], v[30:31], v[70:71]\n\t" \
+    "v_mul_f64 v[78:79], v[30:31], v[68:69]\n\t" \
+    "v_fma_f64 v[76:77], v[28:29], v[68:69], -v[20:21]\n\t" \
+    "v_fma_f64 v[78:79], v[28:29], v[70:71], v[78:79]\n\t" \
+    "v_mul_f64 v[20:21], v[66:67], v[38:39]\n\t" \
+    "v_mul_f64 v[22:23], v[66:67], v[36:37]\n\t" \
+    "v_fma_f64 v[36:37], v[64:65], v[36:37], -v[20:21]\n\t" \
+    "v_fma_f64 v[38:39], v[64:65], v[38:39], v[22:23]\n\t" \
+    "v_mul_f64 v[20:21], v[70:71], v[46:47]\n\t" \
+    "v_mul_f64 v[22:23], v[70:71], v[44:45]\n\t" \
+    "v_fma_f64 v[44:45], v[68:69], v[44:45], -v[20:21]\n\t" \
+    "v_fma_f64 v[46:47], v[68:69], v[46:47], v[22:23]\n\t" \
+    "v_mul_f64 v[20:21], v[74:75], v[54:55]\n\t" \
+    "v_mul_f64 v[22:23], v[74:75], v[52:53]\n\t" \
+    "v_fma_f64 v[52:53], v[72:73], v[52:53], -v[20:21]\n\t" \
+    "v_fma_f64 v[54:55], v[72:73], v[54:55], v[22:23]\n\t" \
+    "v_mul_f64 v[20:21], v[78:79], v[62:63]\n\t" \
+    "v_mul_f64 v[22:23], v[78:79], v[60:61]\n\t" \
+    "v_fma_f64 v[60:61], v[76:77], v[60:61], -v[20:21]\n\t" \
+    "v_fma_f64 v[62:63], v[76:77], v[62:63], v[22:23]\n\t"
+#define X8T_D_1 \
+    "v_mul_f64 v[20:21], v[26:27], v[66:67]\n\t" \
+    "v_mul_f64 v[70:71], v[26:27], v[64:65]\n\t" \
+    "v_fma_f64 v[68:69], v[24:25], v[64:65], -v[20:21]\n\t" \
+    "v_fma_f64 v[70:71], v[24:25], v[66:67], v[70:71]\n\t" \
+    "v_mul_f64 v[20:21], v[30:31], v[66:67]\n\t" \
+    "v_mul_f64 v[74:75], v[30:31], v[64:65]\n\t" \
+    "v_fma_f64 v[72:73], v[28:29], v[64:65], -v[20:21]\n\t" \
+    "v_fma_f64 v[74:75], v[28:29], v[66:67], v[74:75]\n\t" \
+    "v_mul_f64 v[20:21], v[30:31], v[70:71]\n\t" \
+    "v_mul_f64 v[78:79], v[30:31], v[68:69]\n\t" \
+    "v_fma_f64 v[76:77], v[28:29], v[68:69], -v[20:21]\n\t" \
+    "v_fma_f64 v[78:79], v[28:29], v[70:71], v[78:79]\n\t" \
+    "v_mul_f64 v[20:21], v[66:67], v[42:43]\n\t" \
+    "v_mul_f64 v[22:23], v[66:67], v[40:41]\n\t" \
+    "v_fma_f64 v[40:41], v[64:65], v[40:41], -v[20:21]\n\t" \
+    "v_fma_f64 v[42:43], v[64:65], v[42:43], v[22:23]\n\t" \
+    "v_mul_f64 v[20:21], v[70:71], v[46:47]\n\t" \
+    "v_mul_f64 v[22:23], v[70:71], v[44:45]\n\t" \
+    "v_fma_f64 v[44:45], v[68:69], v[44:45], -v[20:21]\n\t" \
+    "v_fma_f64 v[46:47], v[68:69], v[46:47], v[22:23]\n\t" \
+    "v_mul_f64 v[20:21], v[74:75], v[58:59]\n\t" \
+    "v_mul_f64 v[22:23], v[74:75], v[56:57]\n\t" \
+    "v_fma_f64 v[56:57], v[72:73], v[56:57], -v[20:21]\n\t" \
+    "v_fma_f64 v[58:59], v[72:73], v[58:59], v[22:23]\n\t" \
+    "v_mul_f64 v[20:21], v[78:79], v[62:63]\n\t" \
+    "v_mul_f64 v[22:23], v[78:79], v[60:61]\n\t" \
+    "v_fma_f64 v[60:61], v[76:77], v[60:61], -v[20:21]\n\t" \
+    "v_fma_f64 v[62:63], v[76:77], v[62:63], v[22:23]\n\t"
+#define X8T_D_2 \
+    "v_mul_f64 v[20:21], v[26:27], v[66:67]\n\t" \
+    "v_mul_f64 v[70:71], v[26:27], v[64:65]\n\t" \
+    "v_fma_f64 v[68:69], v[24:25], v[64:65], -v[20:21]\n\t" \
+    "v_fma_f64 v[70:71], v[24:25], v[66:67], v[70:71]\n\t" \
+    "v_mul_f64 v[20:21], v[30:31], v[66:67]\n\t" \
+    "v_mul_f64 v[74:75], v[30:31], v[64:65]\n\t" \
+    "v_fma_f64 v[72:73], v[28:29], v[64:65], -v[20:21]\n\t" \
+    "v_fma_f64 v[74:75], v[28:29], v[66:67], v[74:75]\n\t" \
+    "v_mul_f64 v[20:21], v[30:31], v[70:71]\n\t" \
+    "v_mul_f64 v[78:79], v[30:31], v[68:69]\n\t" \
+    "v_fma_f64 v[76:77], v[28:29], v[68:69], -v[20:21]\n\t" \
+    "v_fma_f64 v[78:79], v[28:29], v[70:71], v[78:79]\n\t" \
+    "v_mul_f64 v[20:21], v[66:67], v[50:51]\n\t" \
+    "v_mul_f64 v[22:23], v[66:67], v[48:49]\n\t" \
+    "v_fma_f64 v[48:49], v[64:65], v[48:49], -v[20:21]\n\t" \
+    "v_fma_f64 v[50:51], v[64:65], v[50:51], v[22:23]\n\t" \
+    "v_mul_f64 v[20:21], v[70:71], v[54:55]\n\t" \
+    "v_mul_f64 v[22:23], v[70:71], v[52:53]\n\t" \
+    "v_fma_f64 v[52:53], v[68:69], v[52:53], -v[20:21]\n\t" \
+    "v_fma_f64 v[54:55], v[68:69], v[54:55], v[22:23]\n\t" \
+    "v_mul_f64 v[20:21], v[74:75], v[58:59]\n\t" \
+    "v_mul_f64 v[22:23], v[74:75], v[56:57]\n\t" \
+    "v_fma_f64 v[56:57], v[72:73], v[56:57], -v[20:21]\n\t" \
+    "v_fma_f64 v[58:59], v[72:73], v[58:59], v[22:23]\n\t" \
+    "v_mul_f64 v[20:21], v[78:79], v[62:63]\n\t" \
+    "v_mul_f64 v[22:23], v[78:79], v[60:61]\n\t" \
+    "v_fma_f64 v[60:61], v[76:77], v[60:61], -v[20:21]\n\t" \
+    "v_fma_f64 v[62:63], v[76:77], v[62:63], v[22:23]\n\t"
+#define X8T_FMUL_0 \
+    "v_mul_f64 v[20:21], v[70:71], v[66:67]\n\t" \
+    "v_mul_f64 v[22:23], v[70:71], v[64:65]\n\t" \
+    "v_fma_f64 v[64:65], v[68:69], v[64:65], -v[20:21]\n\t" \
+    "v_fma_f64 v[66:67], v[68:69], v[66:67], v[22:23]\n\t"
+#define X8T_FMUL_1 \
+    "v_mul_f64 v[20:21], v[74:75], v[66:67]\n\t" \
+    "v_mul_f64 v[22:23], v[74:75], v[64:65]\n\t" \
+    "v_fma_f64 v[64:65], v[72:73], v[64:65], -v[20:21]\n\t" \
+    "v_fma_f64 v[66:67], v[72:73], v[66:67], v[22:23]\n\t"
+#define X8T_FMUL_2 \
+    "v_mul_f64 v[20:21], v[78:79], v[66:67]\n\t" \
+    "v_mul_f64 v[22:23], v[78:79], v[64:65]\n\t" \
+    "v_fma_f64 v[64:65], v[76:77], v[64:65], -v[20:21]\n\t" \
+    "v_fma_f64 v[66:67], v[76:77], v[66:67], v[22:23]\n\t"
+#define X8T_STEP(K1, SW, NEXT)                                  \
+    "s_cmp_lt_u32 %[ns], " #K1 "\n\t"                               \
+    "s_cbranch_scc1 " NEXT "\n\t"                                    \
+    "s_and_b32 s94, " SW ", 3\n\t"                                   \
+    "s_bitcmp1_b32 " SW ", 2\n\t"                                    \
+    "s_cbranch_scc0 60f\n\t"                                         \
+    /* the diagonal's table reads, issued in front of the butterflies */ \
+    "s_bfe_u32 s95, " SW ", 0x80008\n\t"                             \
+    "s_lshl_b32 s96, s95, 4\n\t"                                     \
+    "s_add_u32 s96, s96, %[dg]\n\t"                                  \
+    "v_mov_b32 v19, s96\n\t"                                         \
+    "ds_read_b128 v[64:67], v19\n\t"                                 \
+    "s_mulk_i32 s95, 0x300\n\t"                                      \
+    "s_add_u32 s95, s95, %[gt]\n\t"                                  \
+    "s_bitcmp1_b32 " SW ", 16\n\t"                                   \
+    "s_cbranch_scc0 61f\n\t"                                         \
+    "v_add_u32 v19, s95, %[n0]\n\t"                                  \
+    "ds_read_b128 v[68:71], v19\n\t"                               \
+    "61:\n\t"                                                        \
+    "s_bitcmp1_b32 " SW ", 17\n\t"                                   \
+    "s_cbranch_scc0 62f\n\t"                                         \
+    "v_add_u32 v19, s95, %[n1]\n\t"                                  \
+    "ds_read_b128 v[72:75], v19\n\t"                               \
+    "62:\n\t"                                                        \
+    "s_bitcmp1_b32 " SW ", 18\n\t"                                   \
+    "s_cbranch_scc0 63f\n\t"                                         \
+    "v_add_u32 v19, s95, %[n2]\n\t"                                  \
+    "ds_read_b128 v[76:79], v19\n\t"                               \
+    "63:\n\t"                                                        \
+    /* the other two register bits of the step: O1 = (R == 0 ? bit 1 : bit 0), O2 = (R == 2 ? bit 1 : bit 2) */ \
+    "s_cmp_eq_u32 s94, 0\n\t"                                        \
+    "s_cselect_b32 s97, %[o1], %[o0]\n\t"                            \
+    "s_cmp_eq_u32 s94, 2\n\t"                                        \
+    "s_cselect_b32 s98, %[o1], %[o2]\n\t"                            \
+    "v_mov_b64 v[24:25], 1.0\n\t"                                    \
+    "v_mov_b64 v[26:27], 0\n\t"                                      \
+    "s_bitcmp1_b32 " SW ", 19\n\t"                                   \
+    "s_cbranch_scc0 64f\n\t"                                         \
+    "s_add_u32 s97, s97, s95\n\t"                                    \
+    "v_mov_b32 v19, s97\n\t"                                         \
+    "ds_read_b128 v[24:27], v19\n\t"                                 \
+    "64:\n\t"                                                        \
+    "v_mov_b64 v[28:29], 1.0\n\t"                                    \
+    "v_mov_b64 v[30:31], 0\n\t"                                      \
+    "s_bitcmp1_b32 " SW ", 20\n\t"                                   \
+    "s_cbranch_scc0 60f\n\t"                                         \
+    "s_add_u32 s98, s98, s95\n\t"                                    \
+    "v_mov_b32 v19, s98\n\t"                                         \
+    "ds_read_b128 v[28:31], v19\n\t"                                 \
+    "60:\n\t"                                                        \
+    /* the butterflies (unscaled: the pass multiplies by 1/sqrt 2 ^ Hadamards once, at the store) */ \
+    "s_cmp_eq_u32 s94, 0\n\t s_cbranch_scc1 70f\n\t"                 \
+    "s_cmp_eq_u32 s94, 1\n\t s_cbranch_scc1 71f\n\t"                 \
+    X8T_H_2 "s_branch 72f\n\t"                                       \
+    "70:\n\t" X8T_H_0 "s_branch 72f\n\t"                             \
+    "71:\n\t" X8T_H_1                                                \
+    "72:\n\t"                                                        \
+    "s_bitcmp1_b32 " SW ", 2\n\t"                                    \
+    "s_cbranch_scc0 " NEXT "\n\t"                                    \
+    "s_waitcnt lgkmcnt(0)\n\t"                                       \
+    "s_bitcmp1_b32 " SW ", 16\n\t s_cbranch_scc0 65f\n\t" X8T_FMUL_0 "65:\n\t" \
+    "s_bitcmp1_b32 " SW ", 17\n\t s_cbranch_scc0 66f\n\t" X8T_FMUL_1 "66:\n\t" \
+    "s_bitcmp1_b32 " SW ", 18\n\t s_cbranch_scc0 67f\n\t" X8T_FMUL_2 "67:\n\t" \
+    "s_cmp_eq_u32 s94, 0\n\t s_cbranch_scc1 73f\n\t"                 \
+    "s_cmp_eq_u32 s94, 1\n\t s_cbranch_scc1 74f\n\t"                 \
+    X8T_D_2 "s_branch " NEXT "\n\t"                                  \
+    "73:\n\t" X8T_D_0 "s_branch " NEXT "\n\t"                        \
+    "74:\n\t" X8T_D_1
+#define X8T_ROUND_ALL                                                \
+    "ds_read_b128 v[32:35], %[a0]\n\t"                               \
+    X8_ADDR1("%[d0]") "ds_read_b128 v[36:39], v19\n\t"               \
+    X8_ADDR1("%[d1]") "ds_read_b128 v[40:43], v19\n\t"               \
+    X8_ADDR2("%[d0]", "%[d1]") "ds_read_b128 v[44:47], v19\n\t"      \
+    X8_ADDR1("%[d2]") "ds_read_b128 v[48:51], v19\n\t"               \
+    X8_ADDR2("%[d0]", "%[d2]") "ds_read_b128 v[52:55], v19\n\t"      \
+    X8_ADDR2("%[d1]", "%[d2]") "ds_read_b128 v[56:59], v19\n\t"      \
+    X8_ADDR3("%[d0]", "%[d1]", "%[d2]") "ds_read_b128 v[60:63], v19\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t"                                       \
+    X8T_STEP(1, "%[sA]", "81f") "81:\n\t"                            \
+    X8T_STEP(2, "%[sB]", "82f") "82:\n\t"                            \
+    X8T_STEP(3, "%[sC]", "83f") "83:\n\t"                            \
+    "ds_write_b128 %[a0], v[32:35]\n\t"                              \
+    X8_ADDR1("%[d0]") "ds_write_b128 v19, v[36:39]\n\t"              \
+    X8_ADDR1("%[d1]") "ds_write_b128 v19, v[40:43]\n\t"              \
+    X8_ADDR2("%[d0]", "%[d1]") "ds_write_b128 v19, v[44:47]\n\t"     \
+    X8_ADDR1("%[d2]") "ds_write_b128 v19, v[48:51]\n\t"              \
+    X8_ADDR2("%[d0]", "%[d2]") "ds_write_b128 v19, v[52:55]\n\t"     \
+    X8_ADDR2("%[d1]", "%[d2]") "ds_write_b128 v19, v[56:59]\n\t"     \
+    X8_ADDR3("%[d0]", "%[d1]", "%[d2]") "ds_write_b128 v19, v[60:63]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t"
+
+// one fast round of the tolerance mode on this thread's 8 amplitudes.  n0..n2: byte offsets of this thread's entries in the three
+// 16-entry groups of a diagonal's G tables (from its tile-local index p); o0..o2: byte offsets of the single-bit entries of the
+// round's three register bits; dg / gt: LDS byte addresses of the E_out slots / the G tables
+__device__ __forceinline__ void fuse_round8t(uint32_t a0, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t n0, uint32_t n1, uint32_t n2,
+                                             uint32_t o0, uint32_t o1, uint32_t o2, uint32_t sA, uint32_t sB, uint32_t sC, uint32_t ns,
+                                             uint32_t dg, uint32_t gt)
+{
+    asm volatile(X8T_ROUND_ALL
+        :
+        : [a0] "v"(a0), [d0] "s"(d0), [d1] "s"(d1), [d2] "s"(d2), [n0] "v"(n0), [n1] "v"(n1), [n2] "v"(n2),
+          [o0] "s"(o0), [o1] "s"(o1), [o2] "s"(o2), [sA] "s"(sA), [sB] "s"(sB), [sC] "s"(sC), [ns] "s"(ns), [dg] "s"(dg), [gt] "s"(gt)
+        : "memory", "vcc", "scc", "v19", "v20", "v21", "v22", "v23",
+          "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31",
+          "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",
+          "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
+          "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
+          "s94", "s95", "s96", "s97", "s98");
+}
+
+template <int BLOCK, int TT, bool GEN = false, bool TOL = false>     // TOL: the pass holds FUSE_QROUND3 rounds (tolerance mode, K6x-t)
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void k_fused_x8(
     const amp_t *amp, amp_t *amp_out, unsigned n, FusePass P, const FuseOp *__restrict__ ops, uint64_t ntiles, const FuseOp *ops_asm)
 {
-    static_assert((1u << TT) == 8u * BLOCK, "the exact walk on 8 amplitudes per thread");
+    static_assert((1u << TT) == 8u * BLOCK, "the walk on 8 amplitudes per thread");
     extern __shared__ __attribute__((aligned(16))) unsigned char qcx_lds_raw[];
     amp_t *tile = reinterpret_cast<amp_t *>(qcx_lds_raw);
     constexpr unsigned tsize = 1u << TT;
     uint64_t *xm = reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(tile + tsize) + P.xm_off);
+    // tolerance mode: [E_out slot per diagonal][G tables, 48 entries per diagonal] behind the tile
+    amp_t *dg = reinterpret_cast<amp_t *>(reinterpret_cast<unsigned char *>(tile + tsize) + P.dg_lds_off);
+    const amp_t *dg_area = reinterpret_cast<const amp_t *>(ops + P.dg_rec_off);             // global: DiagInfo[], G tables, field tables
     bool staged = false;
     // fill: slot s = k * BLOCK + thread (what the LDS-DMA writes linearly) receives element x8_swz(s); spread and swizzle are both
     // linear over XOR, so the thread part and the k part are computed once and combined with XOR
@@ -2782,6 +3063,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     const unsigned wave_id = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t tile_lds = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) amp_t *)tile;
     const uint32_t xm_lds = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint64_t *)xm;
+    const uint32_t dg_lds = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) amp_t *)dg;
     // GEN: the tiles are generated (the circuit front on a basis state that was never written, GenFront), not read: slot s holds
     // element x8_swz(s), and the per-element words of the generated fill are linear over XOR like everything else here
     const GenFront *GF = reinterpret_cast<const GenFront *>(ops + P.gen_rec_off);
@@ -2808,9 +3090,24 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + (off_t ^ off_k[k])),
                                                  (__attribute__((address_space(3))) void *)(tile + k * BLOCK + wbase), 16, 0, 2);
         }
-        if (!staged) {          // the records' outside-tile masks, once per workgroup -- behind the first tile's fill, not in front of it
-            staged = true;      // (a workgroup usually takes ONE tile: this latency used to be paid per tile, with nothing in flight)
-            for (unsigned b = threadIdx.x; b < P.xm_cnt + 66u; b += BLOCK) xm[b] = b < P.xm_cnt ? ops[b].mask : 0;    // + padding (a lane looks up to 64 entries past a run)
+        if (!staged) {          // once per workgroup -- behind the first tile's fill, not in front of it (a workgroup usually takes ONE
+            staged = true;      // tile: this latency used to be paid per tile, with nothing in flight)
+            if constexpr (TOL) {
+                for (unsigned b = threadIdx.x; b < P.dg_cnt * 48u; b += BLOCK) dg[P.dg_cnt + b] = dg_area[3u * P.dg_cnt + b];
+            } else {            // the records' outside-tile masks (+ padding: a lane looks up to 64 entries past a run)
+                for (unsigned b = threadIdx.x; b < P.xm_cnt + 66u; b += BLOCK) xm[b] = b < P.xm_cnt ? ops[b].mask : 0;
+            }
+        }
+        if constexpr (TOL) {
+            if (threadIdx.x < P.dg_cnt) {           // E_out of this tile for every diagonal of the pass, while the fill is in flight
+                const DiagInfo *info = reinterpret_cast<const DiagInfo *>(dg_area) + threadIdx.x;
+                const uint32_t present = info->present;
+                amp_t E; E.x = info->kc; E.y = info->ks;
+#pragma unroll
+                for (unsigned f = 0; f < 5; f++)
+                    if ((present >> f) & 1u) cmul_tol(E, dg_area[info->field_off[f] + (unsigned)((base >> (8u * f)) & 255u)]);
+                dg[threadIdx.x] = E;
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -2819,7 +3116,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         // targets under the wave number runs 24 more gates than part 0), a wave sits on one SIMD for good, and a workgroup
         // lasts as long as its slowest wave -- with a fixed assignment one SIMD of every CU would carry the heavy parts of
         // BOTH resident workgroups.  (Fill and store go by the real thread number.)
-        const unsigned wave_eff = (wave_id ^ (unsigned)t ^ (unsigned)(t >> 3)) & ((BLOCK >> 6) - 1u);
+        const unsigned wave_eff = TOL ? wave_id : (wave_id ^ (unsigned)t ^ (unsigned)(t >> 3)) & ((BLOCK >> 6) - 1u);
         const unsigned tid_eff = lane | (wave_eff << 6);
         if (!(P.dbg & 1u)) {
             for (unsigned i = 0; i < P.nops;) {
@@ -2830,21 +3127,34 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
                 unsigned p = 0;
 #pragma unroll
                 for (unsigned k = 0; k < (unsigned)TT - 3u; k++) p |= ((tid_eff >> k) & 1u) << ((unsigned)(map >> (4u * k)) & 15u);
-                // bit 25 of the header: this round's waves sit on the same tile bits as the previous round's -- every wave finds
-                // its own amplitudes where it left them (its LDS accesses are served in order) and nobody else's: no barrier
-                if (i != 0 && !((a >> 25) & 1u)) __syncthreads();
-                // the walk reads the records through ops_asm (see fuse_apply_rounds: `ops` itself must not be captured by an asm)
-                // (bits 48 .. of a gate's outside mask: conditions on the tile bits this round's WAVE number rides on -- the host moved
-                //  them there from the lane mask, x8_assign_maps -- so that the per-item ballot already drops the gates this wave skips)
-                fuse_round8(tile_lds + 16u * x8_swz(p), p, xm_lds + 8u * (i + 2u + lane), base | ((uint64_t)wave_eff << 48), ops_asm + i + 1, cnt,
-                            16u * x8_swz(1u << rb0), 16u * x8_swz(1u << rb1), 16u * x8_swz(1u << rb2), (a >> 24) & 1u);
+                // "no barrier in front of this round" (bit 25 of an exact round's header, bit 28 of a tolerance round's): its waves sit
+                // on the same tile bits as the previous round's -- every wave finds its own amplitudes where it left them (its LDS
+                // accesses are served in order) and nobody else's
+                if (i != 0 && !((a >> (TOL ? 28 : 25)) & 1u)) __syncthreads();
+                if constexpr (TOL) {
+                    const uint32_t sA = ops[i + 1].type, sB = ops[i + 1].a, sC = (uint32_t)ops[i + 1].mask;
+                    auto single = [](unsigned rb) { return 16u * (16u * (rb >> 2) + (1u << (rb & 3u))); };     // G-table entry of one tile bit alone
+                    fuse_round8t(tile_lds + 16u * x8_swz(p), 16u * x8_swz(1u << rb0), 16u * x8_swz(1u << rb1), 16u * x8_swz(1u << rb2),
+                                 16u * (p & 15u), 16u * (16u + ((p >> 4) & 15u)), 16u * (32u + (p >> 8)), single(rb0), single(rb1), single(rb2),
+                                 sA, sB, sC, (a >> 24) & 3u, dg_lds, dg_lds + 16u * P.dg_cnt);
+                } else {
+                    // the walk reads the records through ops_asm (see fuse_apply_rounds: `ops` itself must not be captured by an asm)
+                    // (bits 48 .. of a gate's outside mask: conditions on the tile bits this round's WAVE number rides on -- the host moved
+                    //  them there from the lane mask, x8_assign_maps -- so that the per-item ballot already drops the gates this wave skips)
+                    fuse_round8(tile_lds + 16u * x8_swz(p), p, xm_lds + 8u * (i + 2u + lane), base | ((uint64_t)wave_eff << 48), ops_asm + i + 1, cnt,
+                                16u * x8_swz(1u << rb0), 16u * x8_swz(1u << rb1), 16u * x8_swz(1u << rb2), (a >> 24) & 1u);
+                }
                 i += 1 + cnt;
             }
             __syncthreads();
         }
         amp_t v[8];
+        const double sc = (TOL && !(P.dbg & 1u)) ? P.tol_scale : 1.0;        // tolerance mode: the Hadamards' 1/sqrt 2, once per pass
 #pragma unroll
-        for (unsigned k = 0; k < 8; k++) v[k] = tile[ld_k[k] ^ ld_t];          // (store order: ascending OUTPUT positions; slots under the swizzle)
+        for (unsigned k = 0; k < 8; k++) {
+            v[k] = tile[ld_k[k] ^ ld_t];          // (store order: ascending OUTPUT positions; slots under the swizzle)
+            if constexpr (TOL) { v[k].x *= sc; v[k].y *= sc; }
+        }
         if (!(P.dbg & 2u)) {
 #pragma unroll
             for (unsigned k = 0; k < 8; k++) __builtin_nontemporal_store(v[k], go + st_k[k]);

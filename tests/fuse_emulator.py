@@ -337,8 +337,19 @@ def apply_pass(state, n, act, recs):
             elif t == FUSE_QROUND3:
                 # tolerance mode, radix-8 fast round (k_fused_q3): up to three steps H(x) [D(x)] on three register bits
                 rb = [r.a & 0xFF, (r.a >> 8) & 0xFF, (r.a >> 16) & 0xFF]
-                ns = r.a >> 24
+                ns = (r.a >> 24) & 3
                 assert rb[0] < rb[1] < rb[2] < P.T and int(r.mask) == 1 and 1 <= ns <= 3
+                # round 5: the header also carries k_fused_x8's thread map (c) and "no barrier in front of this round" (bit 28 of a)
+                tmap = struct.unpack("<Q", struct.pack("<d", r.c))[0]
+                tb = [(tmap >> (4 * k)) & 15 for k in range(P.T - 3)]
+                if P.T == 12:
+                    assert sorted(tb + rb) == list(range(P.T)), ("thread map", tb, rb)
+                    wave_bits = tuple(tb[6:])
+                    if (r.a >> 28) & 1:
+                        assert i > 0 and getattr(P, "x8_wave_bits", None) == wave_bits, "a round without a barrier must keep the waves on their tile bits"
+                        stats["nobarrier"] = stats.get("nobarrier", 0) + 1
+                    P.x8_wave_bits = wave_bits
+                    stats.setdefault("maps", []).append((tuple(rb), tuple(tb)))
                 steps = [R[i + 1].type, R[i + 1].a, int(R[i + 1].mask) & 0xFFFFFFFF]
                 assert sorted(sw & 3 for sw in steps) == [0, 1, 2], "the three step words name the three register bits"
                 stats["rounds"] += 1

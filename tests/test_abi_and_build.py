@@ -128,7 +128,9 @@ def test_gate_kernels_have_no_fma():
     # among them), measurement, exchange -- is free of it
     funcs = {m.group(1): txt[m.start():txt.find(".Lfunc_end", m.start())] for m in re.finditer(r"^(_Z\w+):", txt, re.M)}
     with_fma = [name for name, body in funcs.items() if re.search(r"v_fma_f64|v_fmac_f64|v_pk_fma_f64", body)]
-    assert with_fma and all(re.match(r"_ZN3qcx14k_fused_roundsILi\d+ELi\d+ELi\d+ELb[01]ELi[12]ELb[01]EE|_ZN3qcx10k_fused_q3ILi\d+ELi\d+ELi\d+ELb0ELb[01]EE|_ZN3qcx10k_gen_colsILi\d+ELb1EE", name) for name in with_fma), with_fma
+    # (round 5: + k_fused_x8<.., TOL = true>, the tolerance mode's hand-written radix-8 round)
+    assert with_fma and all(re.match(r"_ZN3qcx14k_fused_roundsILi\d+ELi\d+ELi\d+ELb[01]ELi[12]ELb[01]EE|_ZN3qcx10k_fused_q3ILi\d+ELi\d+ELi\d+ELb0ELb[01]EE|_ZN3qcx10k_gen_colsILi\d+ELb1EE|_ZN3qcx10k_fused_x8ILi\d+ELi\d+ELb[01]ELb1EE", name) for name in with_fma), with_fma
+    assert any(re.match(r"_ZN3qcx10k_fused_x8ILi\d+ELi\d+ELb[01]ELb0EE", name) for name in funcs), "the exact walk on 8 amplitudes per thread"
     assert any(re.match(r"_ZN3qcx10k_gen_colsILi\d+ELb0EE", name) for name in funcs), "the exact by-columns kernel"
     assert any(re.match(r"_ZN3qcx10k_fused_q3ILi\d+ELi\d+ELi\d+ELb1ELb[01]EE", name) for name in funcs), "the exact radix-8 Hadamard kernel"
     assert txt.count("global_load_dwordx4") > 50            # 16-B amplitude accesses everywhere
@@ -194,9 +196,12 @@ def test_exact_walk_on_8_amplitudes_declares_its_fixed_registers():
     txt = open(s_path).read()
     meta = {m.group(1): (int(m.group(2)), int(m.group(3)), int(m.group(4)))
             for m in re.finditer(r"\.name:\s*(\S*k_fused_x8\S*)\s.*?\.private_segment_fixed_size:\s*(\d+).*?\.sgpr_count:\s*(\d+).*?\.vgpr_count:\s*(\d+)", txt, re.S)}
-    assert len(meta) == 6, sorted(meta)                       # 2^10, 2^11, 2^12 tiles, each read or generated
+    assert len(meta) == 7, sorted(meta)                       # 2^10, 2^11, 2^12 tiles, each read or generated; + the tolerance mode's (2^12)
     funcs = {m.group(1): txt[m.start():txt.find(".Lfunc_end", m.start())] for m in re.finditer(r"^(_Z\w+):", txt, re.M)}
     for name, (scratch, sgpr, vgpr) in meta.items():
+        if "ELb0ELb1EEEv" in name:                           # k_fused_x8<.., TOL = true>: FMA allowed, another register plan; no spills
+            assert scratch == 0 and vgpr <= 128, (name, scratch, vgpr)
+            continue
         assert scratch == 0 and sgpr >= 99 and 64 <= vgpr <= 128, (name, scratch, sgpr, vgpr)
         body = funcs[name]
         assert not re.search(r"v_fma_f64|v_fmac_f64", body)

@@ -206,7 +206,7 @@ def test_exact_walk_on_8_amplitudes_declares_its_fixed_registers():
         body = funcs[name]
         assert not re.search(r"v_fma_f64|v_fmac_f64", body)
         assert body.count("ds_read_b128 v[32:35]") >= 1 and body.count("s_load_dwordx8 s[72:79], s[88:89]") >= 14
-        assert "v_xor_b32" in body and "global_load_lds_dwordx4" in body or "ELb1EE" in name
+        assert "v_xor_b32" in body and ("global_load_lds_dwordx4" in body or "ELb1ELb0EEEv" in name)     # (GEN = true: the tiles are generated, not read)
 
 
 def test_product_rng_matches_oracle_and_known_answers(qc, ob):

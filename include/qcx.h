@@ -182,116 +182,15 @@ unsigned long qcx_rng_get(qcx_rng *rng);
 double        qcx_rng_uniform(qcx_rng *rng);                    /* get / 2^32 */
 void          qcx_rng_free(qcx_rng *rng);
 
-/* ---- shard-level entry points on caller-owned device memory ----------------
- * One rank of a sharded register owns 2^n_local consecutive amplitudes; the
- * index bits above n_local are the rank id.  These are what a
- * multi-process host (one process per GPU) calls between its exchanges.
- * `stream` is a hipStream_t (NULL = default stream).                          */
-int  qcx_shard_reset(void *amp, unsigned n_local, int holds_index_one, void *stream);
-int  qcx_shard_fill_random(void *amp, unsigned n_local, uint64_t first_global, uint64_t seed,
-                           double scale, void *stream);
-int  qcx_shard_hadamard(void *amp, unsigned n_local, unsigned q_local, void *stream);
-/* multiply by (cos_t + i sin_t) every amplitude whose local index has all bits of
- * `mask_local` set; mask_local has 0, 1 or 2 bits (global control bits that are 1
- * simply drop out of the mask; a global bit that is 0 means: do not call). */
-int  qcx_shard_phase(void *amp, unsigned n_local, uint64_t mask_local, double cos_t, double sin_t, void *stream);
-/* ctl_local < 0: the control is a global bit whose value on this rank is 1 */
-int  qcx_shard_camodc(void *amp, unsigned n_local, unsigned M, unsigned C, unsigned A,
-                      int ctl_local, void *stream);
-/* dst[j] = src[j with index bits pos_a[m] <-> pos_b[m] exchanged, m < npairs <= 8]; out of place.
- * The pack pass of the sharded qubit remap (brings the bits to be traded with the rank id to the top). */
-int  qcx_shard_swap_bits(const void *src, void *dst, unsigned n_local, unsigned npairs,
-                         const unsigned *pos_a, const unsigned *pos_b, void *stream);
-int  qcx_shard_norm2(const void *amp, unsigned n_local, double *out, void *stream);
-/* a list of gates on a shard, executed through the fusion scheduler (fused LDS-tile passes, same bits as the
- * one-by-one entry points).  All bit positions are LOCAL index bits of the shard. */
-typedef struct {
-    uint32_t type;      /* 0: Hadamard, 1: phase, 2: controlled modular multiply */
-    uint32_t q;         /* Hadamard: target bit;  modular multiply: control bit, or 0xffffffff = always on */
-    uint64_t mask;      /* phase: local bits that must all be 1 (0 = every amplitude of the shard) */
-    double   c, s;      /* phase: cos, sin (qcx_polar) */
-    uint32_t C, A;      /* modular multiply: modulus and multiplier (A < C) */
-} qcx_gate_desc;
-int  qcx_shard_run_fused(void *amp, unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates, void *stream);
-/* the same in a fusion mode: 1 = bit-exact (qcx_shard_run_fused), 2 = tolerance mode (merged diagonals, see qcx_set_fusion) */
-int  qcx_shard_run_fused_mode(int mode, void *amp, unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates, void *stream);
-/* This shard's part of the basis state |basis> of an (n, M) register -- amplitudes [first_global, first_global + 2^n_local)
- * -- written together with the longest prefix of `gates` that has a closed form on a basis state: Hadamards on distinct
- * qubits, then controlled modular multiplies (the front of Q:712-737).  Qubit numbers in `gates` are GLOBAL (identity
- * layout); a Hadamard or a control on a shard-id qubit costs nothing.  Every rank calls it with the same list and gets
- * the same *used (gates consumed; 0 = the plain basis state was written).  Replaces reset (Q:318-324) + those gates. */
-int  qcx_shard_basis_front(void *amp, unsigned n_local, uint64_t first_global, unsigned n, unsigned M, uint64_t basis,
-                           unsigned count, const qcx_gate_desc *gates, unsigned *used, void *stream);
-
-/* qcx_shard_run_fused keeps record buffers per (device, stream); call this before destroying a stream it was used on */
-int  qcx_shard_release_stream(void *stream);
-
-/* The pass planner alone, on the host (no GPU needed; test and tooling interface).  Cuts a gate list into actions --
- * fused passes over LDS tiles, or single gates that run as their stand-alone kernel -- and returns the records the
- * pass kernels interpret, 32 bytes each, all passes back to back.  Record formats: csrc/qcx_kernels.h (FuseOp and
- * the ROUNDS form); tests/fuse_emulator.py interprets them on the CPU and compares with the oracle.
- * Returns QCX_INSUFFICIENT_MEMORY (with the needed counts in n_actions / n_records) when an array is too small. */
-typedef struct {
-    uint32_t type, a;
-    uint64_t mask;
-    double   c, s;
-} qcx_fuse_record;
-typedef struct {
-    int      fused;                 /* 0: the single gate first_gate, stand-alone kernel; 1: one fused pass */
-    unsigned first_gate, ngates;    /* the gates of the list this action covers (in order, no gaps between actions) */
-    unsigned T, c, nh;              /* tile = 2^T amplitudes: the c lowest index bits + nh higher bits hbit[0..nh) */
-    unsigned char hbit[16];
-    unsigned nopipe;                /* 1: phase-dominated pass, planned on the smaller tile (fuse_T_phase) */
-    unsigned rounds_form;           /* 1: records in ROUNDS form (rounds / items / runs), 0: plain gate list */
-    size_t   rec_off, rec_cnt;      /* this pass's records (tables included) inside `records` */
-    unsigned nops;                  /* records the kernel walks (the rest, if any, are tables) */
-    unsigned table_bytes, table_rec_off;    /* folded modular-multiply tables: size, and offset in records from rec_off */
-    unsigned diag_cnt, diag_rec_off;        /* tolerance mode: merged diagonals of the pass, record offset of their table area */
-    /* tile addressing (round 4).  tl[j] = the qubit that is tile-local bit j in the records.  A CHAINED pass (chained = 1) reads
-     * the register's current buffer under one logical -> physical layout and writes the other buffer under another one: tile-local
-     * bit j is input index bit in_pos[j]; the j-th lowest output position of the tile's bits is output index bit st_pos[j] and
-     * belongs to tile-local bit st_loc[j]; bits [src, src + len) of the tile number go to index bits [dst, dst + len) of the
-     * input / output / logical index (seg_in / seg_out / seg_lg).  In place (chained = 0): out = in = logical, seg_in only. */
-    unsigned chained;
-    unsigned char tl[16], in_pos[16], st_loc[16], st_pos[16];
-    unsigned char nseg_in, nseg_out, nseg_lg, pad_;
-    struct { unsigned char src, dst, len, pad; } seg_in[16], seg_out[16], seg_lg[16];
-} qcx_plan_action;
-int  qcx_fusion_plan(unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates,
-                     qcx_plan_action *actions, unsigned max_actions, unsigned *n_actions,
-                     qcx_fuse_record *records, size_t max_records, size_t *n_records);
-/* the same for a fusion mode: 1 = the bit-exact plan (what qcx_fusion_plan returns), 2 = the tolerance mode's plan;
- * | 4: as a register with a second buffer plans (runs of passes chained through it, see qcx_plan_action) */
-int  qcx_fusion_plan_mode(int mode, unsigned n_local, unsigned M, unsigned count, const qcx_gate_desc *gates,
-                          qcx_plan_action *actions, unsigned max_actions, unsigned *n_actions,
-                          qcx_fuse_record *records, size_t max_records, size_t *n_records);
-/* sequential cumulative scan of |amp|^2 over this shard continuing from cum_in
- * (global index of local 0 = first_global; indices >= last_excluded are not
- * examined, Q:283).  Synchronous. */
-int  qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_t first_global,
-                            uint64_t last_excluded, double cum_in, double r,
-                            int *found, uint64_t *index, double *cum_out, void *stream);
-/* Compact circuits for a one-process-per-GPU host: behind the circuit front the M register reads one of the
- * residues of the multiply ladder's orbit; when nothing else in the queue touches it, the queue can run on a register of
- * L + cb qubits, [L register][orbit column], and every rank expands its part at the end.
- * qcx_compact_plan (pure host; same answer on every rank): *used = gates of the closed-form front, *ncols > 0: the compact form
- * exists, cb column bits, orbit16[0 .. *ncols) the populated M-register values ascending.
- * qcx_shard_compact_front writes a rank's part of the front in the compact form (n_local_compact = n_local - M + cb;
- * first_global = REAL global index of the rank's amplitude 0); qcx_shard_expand_compact turns a rank's compact part into its
- * part of the real register (n_local - M >= 6). */
-int  qcx_compact_plan(unsigned n, unsigned M, uint64_t basis, unsigned count, const qcx_gate_desc *gates,
-                      unsigned *used, unsigned *cb, unsigned *ncols, uint16_t *orbit16);
-int  qcx_shard_compact_front(void *compact, unsigned n_local_compact, uint64_t first_global, unsigned n, unsigned M, uint64_t basis,
-                             unsigned count, const qcx_gate_desc *gates, unsigned cb, unsigned ncols, const uint16_t *orbit16, void *stream);
-int  qcx_shard_expand_compact(const void *compact, void *real, unsigned n_local, unsigned M, unsigned cb, unsigned ncols,
-                              const uint16_t *orbit16, void *stream);
-/* zero the shard; if 0 <= local_index < 2^n_local set that amplitude to (1,0) */
-int  qcx_shard_collapse(void *amp, unsigned n_local, int64_t local_index, void *stream);
-/* -0 components of the shard become +0: for amplitudes the caller wrote, before the first gate runs on them (the
- * reference's mat-vec canonicalises every amplitude at every gate, Q:393-413; the gate kernels only those they act on) */
-int  qcx_shard_canon_zeros(void *amp, unsigned n_local, void *stream);
-
+/* ---- beyond the boundary ---------------------------------------------------
+ * Two further interfaces of the same library live in headers of their own and are included here for convenience:
+ *   qcx_shard.h   the per-rank (shard-level) entry points on caller-owned device memory: what a one-process-per-GPU host
+ *                 calls between its exchanges (quantumcomputer_amd/sharded.py), plus the compact-circuit helpers;
+ *   qcx_plan.h    the fused-pass planner alone, on the host: a test and tooling interface (tests/fuse_emulator.py).
+ * A program that replaces the reference's gate path needs neither. */
 #ifdef __cplusplus
 }
 #endif
+#include "qcx_shard.h"
+#include "qcx_plan.h"
 #endif /* QCX_H */

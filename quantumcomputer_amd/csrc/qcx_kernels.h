@@ -1055,9 +1055,26 @@ struct MeasLevels {
     int top;                         // highest level present
 };
 
-__global__ __launch_bounds__(64) void k_meas_walk(const amp_t *__restrict__ amp, uint64_t count, MeasLevels T,
-                                                  double cum_in, double r, MeasureOut *out, unsigned *stats, unsigned rlog)
+// Round 5: the walk's time was the LATENCY of its steps, not their work -- every event (a binade crossing, a tie ...) costs a
+// descent through the tree and a climb back, one dependent global read of 64 entries per level (a dense n = 30 state: 32 events,
+// 34 us each, 1.1 ms on top of the 2.8 ms scan).  The upper levels are tiny (64^-L of the records): the launch brings as many
+// of them as fit into LDS (stage_from = the lowest staged level; all 256 threads copy, then wave 0 walks alone), so only level 0
+// and the amplitudes of the few slow records still come from memory.
+__global__ __launch_bounds__(256) void k_meas_walk(const amp_t *__restrict__ amp, uint64_t count, MeasLevels T,
+                                                   double cum_in, double r, MeasureOut *out, unsigned *stats, unsigned rlog, int stage_from)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char qcx_lds_raw[];
+    {
+        MeasBlock *stage = reinterpret_cast<MeasBlock *>(qcx_lds_raw);
+        unsigned off = 0;
+        for (int L = T.top; L >= stage_from && L >= 1; L--) {
+            for (unsigned k = threadIdx.x; k < T.n[L]; k += blockDim.x) stage[off + k] = T.lv[L][k];
+            T.lv[L] = stage + off;                      // (a generic pointer into LDS: the walk below reads it like the global ones)
+            off += T.n[L];
+        }
+        __syncthreads();
+        if (threadIdx.x >= 64) return;
+    }
     const unsigned lane = threadIdx.x;
     const unsigned n0 = T.n[0];
     double cum = cum_in;

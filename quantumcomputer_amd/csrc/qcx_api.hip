@@ -89,7 +89,7 @@ struct Tune {
     long h_wave_r    = 4;      // registers per lane, wave-tile form (2, 4 or 8)
     long h_wave_block = 256;   // wave-tile form: threads per block (64 or 256)
     long h_wave_maxq = 7;      // auto: use the wave-tile form for q <= this
-    long ph_apt      = 1;      // measured (tools/tune_phase.py): one amplitude per lane, one wave per block,
+    long ph_apt      = 1;      // measured (tools/experiments/tune_phase.py): one amplitude per lane, one wave per block,
     long ph_grid_cap = 0;      // nontemporal, 2 or 4 interleaved streams: 6.4-6.9 TB/s on the touched quarter
     long ph_block    = 64;
     long ph_nt       = 1;
@@ -143,7 +143,7 @@ struct Tune {
     long fuse_camruns = 1;     // rounds form: fold runs of permutation-type modular multiplies into one gather
     long fuse_hsweep_T = 12;   // tile geometry of an all-Hadamard tail when it saves passes (0: never)
     long fuse_hsweep_c = 3;
-    long fuse_dbg    = 0;      // diagnostics (tools/probe_pass.py): bit 0 skip the gates, bit 1 skip the stores, bit 2 skip the fill of a rounds pass
+    long fuse_dbg    = 0;      // diagnostics (tools/experiments/probe_pass.py): bit 0 skip the gates, bit 1 skip the stores, bit 2 skip the fill of a rounds pass
     long fuse_rounds = 1;      // fused passes: rounds form (4 amplitudes per thread in registers, radix-4 H steps)
     long fuse_ldsdma = 1;      // fused passes: fill the tile with global_load_lds (LDS-DMA)
     long fuse_max_queue = 4096;
@@ -152,7 +152,7 @@ struct Tune {
     long fuse_chain_min_n = 20; // ... for registers of at least 2^this amplitudes
     long meas_block_log = 0;   // parallel measurement: 2^this amplitudes per block (8..13); 0 = from the shard size
     long meas_parallel = 1;    // 0: always the single-wave sequential scan
-    long meas_min_log2 = 12;   // shards below 2^this amplitudes use the single-wave scan (tools/probe_shots.py)
+    long meas_min_log2 = 12;   // shards below 2^this amplitudes use the single-wave scan (tools/experiments/probe_shots.py)
     long meas_onepass = 1;     // parallel measurement: 1 = K4c (one read of the state: look-back + tree walk), 0 = K4b (two reads + one-wave chain)
     long meas_dbg = 0;         // K4c diagnostics: bit 0 = no look-back (every binade guess from cum_in alone: times the pass without it)
     long meas_spin_limit = 4000000;   // K4c: polls a look-back may spend on one window before it gives up (the block is then scanned exactly)
@@ -372,7 +372,7 @@ static bool launch_h_wave_flags(const Tune &t, amp_t *a, unsigned q, uint64_t na
     return launch_h_wave<R, false, false>(t, a, q, namps, st);
 }
 
-// Launch plan per target qubit, measured on MI355X (tools/tune_h.py, profiles/r01_tune_h_*.json).
+// Launch plan per target qubit, measured on MI355X (tools/experiments/tune_h.py, profiles/r01_tune_h_*.json).
 // What matters is the ABSOLUTE pair distance 2^q * 16 B (the same q behaves the same at n = 26, 28
 // and 30), i.e. how the two streams of a wave fall onto HBM channels and banks:
 //   - the smallest work item wins everywhere: one wave, 2 x 16 B per lane (2 KiB in flight per wave);

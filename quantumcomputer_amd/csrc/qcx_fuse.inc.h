@@ -792,7 +792,7 @@ static bool pass_tables_chained(FusePass &P, unsigned n, const std::vector<unsig
     // the tile number's bits = the qubits outside the tile.  by_out: by ascending OUTPUT position -- tiles that run at the same
     // time (consecutive numbers) then store NEIGHBOURING runs: 2^(T - c) consecutive tiles fill the same 2^(T - c) blocks of
     // the output completely (a tile is read as one contiguous block wherever it lies).  Otherwise by ascending INPUT position
-    // (neighbouring tiles read neighbouring blocks).  Measured at n = 28 / 30 (tools/probe_chain.py): memory-bound passes
+    // (neighbouring tiles read neighbouring blocks).  Measured at n = 28 / 30 (tools/experiments/probe_chain.py): memory-bound passes
     // (Hadamard sweeps, tolerance mode) gain 1-4 % from the output order, the FP64-bound exact phase passes lose 5 % with it.
     std::vector<unsigned> fq;
     for (unsigned q = 0; q < n; q++) if (!in_tile[q]) fq.push_back(q);
@@ -951,7 +951,7 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         }
         if (!rounds) { all_ops.insert(all_ops.end(), legacy.begin(), legacy.end()); act.P.nops = (uint32_t)legacy.size(); }
         act.op_cnt = all_ops.size() - act.op_off;
-        static const bool dump = getenv("QCX_FUSE_DUMP") != nullptr;      // planner diagnostics (tools/probe_fuse3.py)
+        static const bool dump = getenv("QCX_FUSE_DUMP") != nullptr;      // planner diagnostics (tools/experiments/probe_fuse3.py)
         if (dump) {
             unsigned nround = 0, nh = 0, nrun = 0, nsingle = 0, ncam = 0, run_gates[16] = {0}, ext = 0, loc = 0;
             for (size_t q = act.op_off; q < act.op_off + act.P.nops; q++) {

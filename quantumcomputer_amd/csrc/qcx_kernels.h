@@ -1172,7 +1172,7 @@ struct FusePass {
                                 // [3]: byte offset of the table area behind the lut in LDS
     uint8_t  hbit[16];          // global bit carried by tile-local bit c + j, ascending
     uint32_t xm_off, xm_cnt;    // LDS copy of the records' outside-tile masks: byte offset behind the lut, entries (0 = none)
-    uint32_t has_cam, dbg;      // the pass holds modular multiplies (selects the kernel variant); dbg: diagnostics only (tools/probe_pass.py):
+    uint32_t has_cam, dbg;      // the pass holds modular multiplies (selects the kernel variant); dbg: diagnostics only (tools/experiments/probe_pass.py):
                                 // bit 0 skip the gates, bit 1 skip the stores, bit 2 skip the tile fill -- results are then wrong by design
     uint32_t dg_cnt, dg_rec_off;// tolerance mode: merged diagonals of the pass (0 = none), record offset of their table area in ops
     uint32_t dg_lds_off, dg_slim;// byte offset of their LDS area behind the lut; 1: every round of the pass is a fast round; 2: radix-8 fast rounds

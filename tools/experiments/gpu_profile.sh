@@ -16,6 +16,6 @@ cd $REPO
 find $OUT -name "*.csv" | head -20
 # fused workloads: kernel trace of the tuning script (H sweep n=30, IQFT n=28, Shor n=30 with fusion on)
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_fused -- python3 $REPO/tools/tune_fuse.py --geoms 11:4 --out $OUT/tune_fuse_under_trace.json > $OUT/fused_under_trace.log 2> $OUT/trace_fused.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_fused -- python3 $REPO/tools/experiments/tune_fuse.py --geoms 11:4 --out $OUT/tune_fuse_under_trace.json > $OUT/fused_under_trace.log 2> $OUT/trace_fused.err
 echo fused trace done
 cd $REPO

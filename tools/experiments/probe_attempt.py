@@ -5,7 +5,7 @@ expanded first (fuse_compact_lazy = 0) and without compact chains; HIP events ar
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import quantumcomputer_amd as qc  # noqa: E402
 
 for mode in (0, 2):

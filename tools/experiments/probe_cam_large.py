@@ -4,7 +4,7 @@ rate on the bytes the path moves (64 B per rewritten amplitude) and on SURVEY s8
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import quantumcomputer_amd as qc  # noqa: E402
 
 extra = dict(kv.split("=") for kv in sys.argv[1:])

@@ -4,7 +4,7 @@ and tolerance mode), n = 30 Shor N = 21 circuit (exact and tolerance mode); HIP-
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import quantumcomputer_amd as qc  # noqa: E402
 
 extra = dict(kv.split("=") for kv in sys.argv[1:])

@@ -11,7 +11,7 @@ import json
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import quantumcomputer_amd as qc  # noqa: E402
 
 PHASE_CASES = [(1, 0), (5, 0), (13, 1), (5, 2), (13, 2), (13, 5), (28, 5), (28, 13), (29, 28), (20, 3)]

@@ -5,7 +5,7 @@ blocked into cache-sized chunks (several tile passes per HBM round trip)."""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import quantumcomputer_amd as qc  # noqa: E402
 
 for n in (20, 21, 22, 23, 24, 25, 26, 27):

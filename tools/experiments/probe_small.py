@@ -1,7 +1,7 @@
 """one period-finding attempt (reset + circuit + measurement) at the reference's own sizes, 300 attempts each: wall time per
 attempt; run under rocprofv3 --kernel-trace to see the launches behind it"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import quantumcomputer_amd as qc
 for (L, M, Cn, a) in ((3, 4, 15, 7), (5, 5, 21, 2), (8, 4, 15, 7)):
     rng = qc.Rng(1)

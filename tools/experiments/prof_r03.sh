@@ -25,9 +25,9 @@ bench)
     echo write done
     ;;
 tol)
-    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_tol -- python3 $REPO/tools/run_iqft_modes.py > $OUT/tol_under_trace.log 2> $OUT/trace_tol.err
-    rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq_tol -- python3 $REPO/tools/run_iqft_modes.py > $OUT/tol_under_sq.log 2> $OUT/pmc_sq_tol.err
-    rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_sq2_tol -- python3 $REPO/tools/run_iqft_modes.py > $OUT/tol_under_sq2.log 2> $OUT/pmc_sq2_tol.err
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_tol -- python3 $REPO/tools/experiments/run_iqft_modes.py > $OUT/tol_under_trace.log 2> $OUT/trace_tol.err
+    rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq_tol -- python3 $REPO/tools/experiments/run_iqft_modes.py > $OUT/tol_under_sq.log 2> $OUT/pmc_sq_tol.err
+    rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_sq2_tol -- python3 $REPO/tools/experiments/run_iqft_modes.py > $OUT/tol_under_sq2.log 2> $OUT/pmc_sq2_tol.err
     echo tol done
     ;;
 esac

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """one fused IQFT at n qubits (profiling target)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import quantumcomputer_amd as qc
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 28
 with qc.Register(n, 0) as reg:

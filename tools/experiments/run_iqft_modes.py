@@ -4,7 +4,7 @@ and the n = 30 Shor circuit (reset + quantum_computation) twice per mode -- a fi
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import quantumcomputer_amd as qc  # noqa: E402
 
 with qc.Register(28, 0) as reg:

@@ -11,7 +11,7 @@ import json
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import quantumcomputer_amd as qc  # noqa: E402
 
 def _v(variant, ppt=1, nt=3, cap=0, r=4, wc=0, blk=256, sl=0, wb=256):

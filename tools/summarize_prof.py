@@ -6,7 +6,7 @@ kernel_stats pools every launch of a kernel; kernel_stats_by_grid keeps launches
 register of another size is another grid), so that e.g. the n = 30 launches of k_h_pair -- the ones the bench line's
 roofline stands on -- have a row of their own, with the one-line recomputation bytes / avg / 8 TB/s next to it.
 --per-dispatch lists, for the named kernels, every dispatch in launch order (duration, counters), so that a script
-that launches its cases in a fixed order (tools/probe_gates.py) can be matched case by case."""
+that launches its cases in a fixed order (tools/experiments/probe_gates.py) can be matched case by case."""
 import csv
 import glob
 import json

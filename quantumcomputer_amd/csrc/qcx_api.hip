@@ -101,7 +101,6 @@ struct Tune {
     long cam_logT    = 8;      // modular multiply: tile = 2^this amplitudes, at least the 2^M block (n = 30, C = 21, M = 5: 2^11 2.65 ms, 2^10 2.50, 2^9 2.3-2.6, 2^8 2.3; 2^12 4.2)
     long cam_skip    = 1;      // modular multiply: the 128-B lines of a 2^M block above row C are neither sources nor destinations: not read
     long cam_nt_lines = 0;     // modular multiply: completely rewritten lines leave as nontemporal stores (the partly rewritten one through L2)
-    long meas_walk_lds = 1;    // K4c: the upper levels of the walk's tree are staged in LDS (round 5)
     long fuse_T      = 11;     // fused passes: tile = 2^T amplitudes in LDS (8..12)
     long fuse_c      = 4;      // fused passes: contiguous low bits of a tile (runs of 16 * 2^c bytes)
     long fuse_grid_cap = 65536; // (round 4, chained passes: 65536 beats 24576 by 1-2 %, one per tile loses 15 % on the n = 30 exact Shor circuit)
@@ -153,7 +152,6 @@ struct Tune {
     long meas_block_log = 0;   // parallel measurement: 2^this amplitudes per block (8..13); 0 = from the shard size
     long meas_parallel = 1;    // 0: always the single-wave sequential scan
     long meas_min_log2 = 12;   // shards below 2^this amplitudes use the single-wave scan (tools/experiments/probe_shots.py)
-    long meas_onepass = 1;     // parallel measurement: 1 = K4c (one read of the state: look-back + tree walk), 0 = K4b (two reads + one-wave chain)
     long meas_dbg = 0;         // K4c diagnostics: bit 0 = no look-back (every binade guess from cum_in alone: times the pass without it)
     long meas_spin_limit = 4000000;   // K4c: polls a look-back may spend on one window before it gives up (the block is then scanned exactly)
 };
@@ -165,7 +163,7 @@ static Tune tune_now() { std::lock_guard<std::mutex> lock(g_tune_mutex); return 
 extern "C" int qcx_tune_set(const char *key, long value)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); g_tune.name = value; return QCX_NO_ERROR; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_full) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_onepass) K(meas_spin_limit) K(meas_dbg) K(meas_walk_lds) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_dir) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_gen_cols) K(fuse_cols_waves) K(fuse_cols_tol) K(fuse_compact) K(fuse_expand_direct) K(fuse_compact_lazy) K(fuse_zskip) K(fuse_zskip_maxw) K(fuse_x8) K(fuse_x8_T) K(fuse_x8_c) K(fuse_x8_map) K(fuse_x8_cap) K(fuse_x8_ratio) K(fuse_x8t)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_full) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_spin_limit) K(meas_dbg) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_dir) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_gen_cols) K(fuse_cols_waves) K(fuse_cols_tol) K(fuse_compact) K(fuse_expand_direct) K(fuse_compact_lazy) K(fuse_zskip) K(fuse_zskip_maxw) K(fuse_x8) K(fuse_x8_T) K(fuse_x8_c) K(fuse_x8_map) K(fuse_x8_cap) K(fuse_x8_ratio) K(fuse_x8t)
 #undef K
     return QCX_BAD_ARGUMENTS;
 }
@@ -173,7 +171,7 @@ extern "C" int qcx_tune_set(const char *key, long value)
 extern "C" long qcx_tune_get(const char *key)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); return g_tune.name; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_full) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_onepass) K(meas_spin_limit) K(meas_dbg) K(meas_walk_lds) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_dir) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_gen_cols) K(fuse_cols_waves) K(fuse_cols_tol) K(fuse_compact) K(fuse_expand_direct) K(fuse_compact_lazy) K(fuse_zskip) K(fuse_zskip_maxw) K(fuse_x8) K(fuse_x8_T) K(fuse_x8_c) K(fuse_x8_map) K(fuse_x8_cap) K(fuse_x8_ratio) K(fuse_x8t)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_full) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_spin_limit) K(meas_dbg) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_dir) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_gen_cols) K(fuse_cols_waves) K(fuse_cols_tol) K(fuse_compact) K(fuse_expand_direct) K(fuse_compact_lazy) K(fuse_zskip) K(fuse_zskip_maxw) K(fuse_x8) K(fuse_x8_T) K(fuse_x8_c) K(fuse_x8_map) K(fuse_x8_cap) K(fuse_x8_ratio) K(fuse_x8t)
 #undef K
     return -1;
 }
@@ -201,7 +199,6 @@ struct Workspace {
     size_t      tab_cap = 0;
     amp_t      *cam_stage = nullptr;    // staging buffer of the M > 12 modular multiply (K3b)
     size_t      cam_stage_cap = 0;
-    double     *meas_sums = nullptr, *meas_prefix = nullptr;   // exact parallel measurement (K4b)
     MeasBlock  *meas_blocks = nullptr;
     unsigned    meas_cap = 0;
     unsigned   *meas_stats = nullptr, *h_meas_stats = nullptr; // [slow-path blocks, blocks] of the last scan
@@ -750,36 +747,31 @@ extern "C" int qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_
         // small shards: the strictly sequential single-wave scan
         hipLaunchKernelGGL(k_measure_scan, dim3(1), dim3(64), 0, st, (const amp_t *)amp, count, cum_in, r, w->mout);
     } else {
-        // exact parallel form (qcx_kernels.h, K4b): block binade guesses -> integer block increments -> chain
-        // block size: the chain costs ~14 ns per block, the one block that is rescanned sequentially ~28 ns per amplitude
+        // exact parallel form (qcx_kernels.h, K4c): one read of the state (look-back for the binade guesses), a few tiny group
+        // launches, the tree walk.  A "block" of 2^blog amplitudes is one RECORD (one wave); a workgroup takes four of them.
         unsigned blog = (unsigned)tn.meas_block_log;
         if (blog == 0) {
             unsigned bits = 0;
             while (bits < 63 && ((uint64_t)1 << bits) < count) bits++;
             blog = bits ? (bits - 1) / 2 : 8;
         }
-        blog = std::min<unsigned>(std::max<unsigned>(blog, 8u), tn.meas_onepass ? 11u : (unsigned)MEAS_BLOCK_LOG_MAX);     // K4c: a record is one wave's 2^8 .. 2^11 amplitudes
+        blog = std::min<unsigned>(std::max<unsigned>(blog, 8u), 11u);     // a record is one wave's 2^8 .. 2^11 amplitudes
         const uint64_t nb64 = (count + (((uint64_t)1 << blog) - 1)) >> blog;
         if (nb64 > 0x7fffffffULL) return QCX_UNSUPPORTED;
         const unsigned nblocks = (unsigned)nb64;
         {
             std::lock_guard<std::mutex> lock(g_ws_mutex);
             if (w->meas_cap < nblocks) {
-                if (w->meas_sums) { HIP_TRY(hipFree(w->meas_sums)); HIP_TRY(hipFree(w->meas_prefix)); HIP_TRY(hipFree(w->meas_blocks));
-                                    HIP_TRY(hipFree(w->meas_look)); HIP_TRY(hipFree(w->meas_up)); }
-                w->meas_sums = w->meas_prefix = nullptr; w->meas_blocks = nullptr; w->meas_cap = 0;
+                if (w->meas_blocks) { HIP_TRY(hipFree(w->meas_blocks)); HIP_TRY(hipFree(w->meas_look)); HIP_TRY(hipFree(w->meas_up)); }
+                w->meas_blocks = nullptr; w->meas_cap = 0;
                 w->meas_look = nullptr; w->meas_up = nullptr;
-                HIP_TRY(hipMalloc(&w->meas_sums, (size_t)nblocks * sizeof(double)));
-                HIP_TRY(hipMalloc(&w->meas_prefix, (size_t)nblocks * sizeof(double)));
                 HIP_TRY(hipMalloc(&w->meas_blocks, ((size_t)nblocks + 4) * sizeof(MeasBlock)));
                 HIP_TRY(hipMalloc(&w->meas_look, (2 * (size_t)nblocks + 4 * ((size_t)nblocks / 64 + 2) + 8) * sizeof(meas_slot_t)));
                 HIP_TRY(hipMalloc(&w->meas_up, ((size_t)nblocks / 32 + 16) * sizeof(MeasBlock)));
                 w->meas_cap = nblocks;
             }
         }
-        if (tn.meas_onepass) {
-            // K4c: one read of the state (look-back for the binade guesses), a few tiny group launches, the tree walk.
-            // Here a "block" of 2^blog amplitudes is one RECORD (one wave); a workgroup takes four of them.
+        {
             const unsigned nwg = (nblocks + 3u) / 4u, ngrp = (nwg + 63u) / 64u;
             MeasLookback LB;
             LB.agg = w->meas_look; LB.incl = LB.agg + nwg; LB.gsum = LB.incl + nwg; LB.gincl = LB.gsum + ngrp;
@@ -804,20 +796,7 @@ extern "C" int qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_
                 T.lv[T.top] = up; T.n[T.top] = nout;
                 up += nout;
             }
-            // the upper levels of the tree ride in LDS (from the top down, as many as fit 128 KiB + a little)
-            int stage_from = T.top + 1;
-            size_t stage_bytes = 0;
-            while (tn.meas_walk_lds && stage_from > 1 && stage_bytes + (size_t)T.n[stage_from - 1] * sizeof(MeasBlock) <= (size_t)136 * 1024) {
-                stage_from--;
-                stage_bytes += (size_t)T.n[stage_from] * sizeof(MeasBlock);
-            }
-            hipLaunchKernelGGL(k_meas_walk, dim3(1), dim3(256), stage_bytes, st, (const amp_t *)amp, count, T, cum_in, r, w->mout, w->meas_stats, blog, stage_from);
-        } else {
-        hipLaunchKernelGGL((k_meas_blocksum<256>), dim3(nblocks), dim3(256), 0, st, (const amp_t *)amp, count, w->meas_sums, blog);
-        hipLaunchKernelGGL(k_meas_prefix, dim3(1), dim3(1024), 0, st, w->meas_sums, nblocks, cum_in, w->meas_prefix);
-        hipLaunchKernelGGL((k_meas_composite<256>), dim3(nblocks), dim3(256), 0, st, (const amp_t *)amp, count, w->meas_prefix, w->meas_blocks, blog);
-        hipLaunchKernelGGL(k_meas_chain, dim3(1), dim3(64), 0, st, (const amp_t *)amp, count, w->meas_blocks, nblocks,
-                           cum_in, r, w->mout, w->meas_stats, blog);
+            hipLaunchKernelGGL(k_meas_walk, dim3(1), dim3(64), 0, st, (const amp_t *)amp, count, T, cum_in, r, w->mout, w->meas_stats, blog);
         }
     }
     HIP_TRY(hipGetLastError());

@@ -493,28 +493,21 @@ __global__ __launch_bounds__(64) void k_measure_scan(const amp_t *__restrict__ a
 }
 
 // ---------------------------------------------------------------------------
-// K4b  measurement scan, exact AND parallel.
+// K4  exact AND parallel measurement scan: the arithmetic fact K4c below rests on.
 //
 // The reference's cumulative sum cum_i = fl(cum_{i-1} + p_i) is order dependent, so a parallel
 // prefix sum does not give the same decisions.  But while the running sum stays inside one binade
 // [2^e, 2^(e+1)) it is an integer K (53 bits) times the fixed ulp u = 2^(e-52), and adding p >= 0
 // rounds to   K + floor(p/u) + [frac(p/u) > 1/2]        (a tie, frac == 1/2, rounds to even).
-// So for a block of MEAS_BLOCK amplitudes with no tie and no element >= 2^e, the sequential sum
-// over the block is exactly K + S with S = sum_i (floor(p_i/u) + [frac > 1/2]) -- an ORDINARY
-// integer sum -- provided K + S < 2^53 (no binade crossing).  Pipeline:
-//   1. k_meas_blocksum / k_meas_prefix : approximate (tree) block sums and their exclusive prefix,
-//      only used to guess the binade e_b in which each block starts;
-//   2. k_meas_composite                 : per block, S under that binade, plus flags
-//      (all-zero, tie seen, element too large, binade unknown);
-//   3. k_meas_chain (one wave)          : walks the blocks in order with the EXACT running sum;
-//      a block whose guess holds costs a few integer operations, any other block (binade crossing,
-//      wrong guess, tie, start of the sum, the block in which cum reaches r) is redone with the
-//      strictly sequential wave scan of k_measure_scan.  The result is the reference's index,
-//      bit for bit, for every input; only the speed depends on the data.
+// So for a block of amplitudes with no tie and no element >= 2^e, the sequential sum over the block is
+// exactly K + S with S = sum_i (floor(p_i/u) + [frac > 1/2]) -- an ORDINARY integer sum -- provided
+// K + S < 2^53 (no binade crossing).  A block whose binade guess holds costs a few integer operations; any
+// other block (binade crossing, wrong guess, tie, start of the sum, the block in which cum reaches r) is redone
+// with a strictly sequential scan.  The result is the reference's index, bit for bit, for every input; only the
+// speed depends on the data.  (Round 3's two-read form of this, K4b -- tree block sums for the guesses, then the
+// increments, then a one-wave chain over the records: 7 ms at n = 30 -- was removed in round 5; K4c reads once.)
 // ---------------------------------------------------------------------------
-// amplitudes per block = 2^blog, a launch parameter (8..13): the chain costs ~14 ns per block and the one block that is
-// rescanned sequentially ~28 ns per amplitude, so small registers want small blocks (host: meas_block_log)
-constexpr int MEAS_BLOCK_LOG_MAX = 13;
+// amplitudes per record = 2^blog, a launch parameter (8..11; host: meas_block_log): small registers want small records
 enum : uint32_t { MEAS_ALLZERO = 1u << 16, MEAS_TIE = 1u << 17, MEAS_BIG = 1u << 18, MEAS_EUNK = 1u << 19 };
 
 struct MeasBlock {
@@ -525,202 +518,9 @@ struct MeasBlock {
 
 __device__ __forceinline__ double prob_of(amp_t v) { return v.x * v.x + v.y * v.y; }    // gsl_complex_abs2
 
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_meas_blocksum(const amp_t *__restrict__ amp, uint64_t count, double *sums, unsigned blog)
-{
-    __shared__ double red[BLOCK / 64];
-    const uint64_t base = (uint64_t)blockIdx.x << blog;
-    const unsigned MEAS_BLOCK = 1u << blog;
-    double acc = 0.0;
-#pragma unroll 4
-    for (unsigned j = threadIdx.x; j < MEAS_BLOCK; j += BLOCK) {
-        const uint64_t i = base + j;
-        if (i < count) acc += prob_of(__builtin_nontemporal_load(amp + i));
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int w = 0; w < BLOCK / 64; w++) t += red[w];
-        sums[blockIdx.x] = t;
-    }
-}
-
-// exclusive prefix of the block sums starting from `base` (one workgroup of 1024 threads)
-__global__ __launch_bounds__(1024) void k_meas_prefix(const double *__restrict__ sums, unsigned nblocks, double base, double *prefix)
-{
-    __shared__ double part[1024];
-    const unsigned per = (nblocks + 1023u) / 1024u;
-    const unsigned lo = threadIdx.x * per, hi = min(lo + per, nblocks);
-    double t = 0.0;
-    for (unsigned b = lo; b < hi; b++) t += sums[b];
-    part[threadIdx.x] = t;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double run = base;
-        const unsigned used = (nblocks + per - 1u) / per;            // threads that hold blocks (the rest hold 0: 64 of 1024 at n = 14)
-        for (unsigned k = 0; k < used; k++) { const double v = part[k]; part[k] = run; run += v; }
-    }
-    __syncthreads();
-    double run = part[threadIdx.x];
-    for (unsigned b = lo; b < hi; b++) { prefix[b] = run; run += sums[b]; }
-}
-
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_meas_composite(const amp_t *__restrict__ amp, uint64_t count,
-                                                            const double *__restrict__ prefix, MeasBlock *out, unsigned blog)
-{
-    __shared__ uint64_t redS[BLOCK / 64];
-    __shared__ uint32_t redF[BLOCK / 64];
-    const uint64_t base = (uint64_t)blockIdx.x << blog;
-    const unsigned MEAS_BLOCK = 1u << blog;
-    const uint64_t pbits = (uint64_t)__double_as_longlong(prefix[blockIdx.x]);
-    const int e = (int)((pbits >> 52) & 0x7ff);                  // biased exponent of the assumed start value
-    uint64_t S = 0;
-    uint32_t flags = (e == 0 || e == 0x7ff) ? (uint32_t)MEAS_EUNK : 0u;
-    bool nonzero = false;
-    const uint64_t SAT = (uint64_t)1 << 54;
-#pragma unroll 4
-    for (unsigned j = threadIdx.x; j < MEAS_BLOCK; j += BLOCK) {
-        const uint64_t i = base + j;
-        if (i >= count) continue;
-        const uint64_t b = (uint64_t)__double_as_longlong(prob_of(__builtin_nontemporal_load(amp + i)));
-        if (b == 0) continue;                                    // p = +0 (p is never negative)
-        nonzero = true;
-        int ep = (int)((b >> 52) & 0x7ff);
-        uint64_t mp = b & 0xfffffffffffffULL;
-        if (ep == 0) ep = 1; else mp |= (uint64_t)1 << 52;       // subnormal: no implicit bit
-        const int sh = e - ep;                                   // p/u = mp * 2^-sh
-        uint64_t inc;
-        if (sh <= 0) { flags |= MEAS_BIG; inc = SAT; }
-        else if (sh >= 54) inc = 0;
-        else if (sh == 53) { inc = (mp == ((uint64_t)1 << 52)) ? 0 : 1; if (mp == ((uint64_t)1 << 52)) flags |= MEAS_TIE; }
-        else {
-            const uint64_t rem = mp & (((uint64_t)1 << sh) - 1), half = (uint64_t)1 << (sh - 1);
-            inc = (mp >> sh) + (rem > half ? 1 : 0);
-            if (rem == half) flags |= MEAS_TIE;
-        }
-        S += inc;
-        if (S > SAT) S = SAT;
-    }
-    const unsigned long long any_nz = __ballot(nonzero);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        S += (uint64_t)__shfl_down((unsigned long long)S, o, 64);
-        flags |= (uint32_t)__shfl_down((int)flags, o, 64);
-    }
-    if ((threadIdx.x & 63) == 0) { redS[threadIdx.x >> 6] = S; redF[threadIdx.x >> 6] = flags | (any_nz ? 0x80000000u : 0u); }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t t = 0; uint32_t f = 0;
-        for (int w = 0; w < BLOCK / 64; w++) { t += redS[w]; f |= redF[w]; }
-        if (!(f & 0x80000000u)) f |= MEAS_ALLZERO;
-        MeasBlock mb; mb.S = t; mb.meta = (uint32_t)e | (f & 0x7fff0000u); mb.pad = 0;
-        out[blockIdx.x] = mb;
-    }
-}
-
-// exact sequential scan of amplitudes [first, first+len) continuing from cum (whole wave, uniform
-// result): returns true and sets *hit_index when the running sum reaches r
-__device__ __forceinline__ bool wave_exact_scan(const amp_t *__restrict__ amp, uint64_t first, uint64_t len,
-                                                double &cum, double r, uint64_t *hit_index, double *hit_cum)
-{
-    const unsigned lane = threadIdx.x & 63u;
-    for (uint64_t base = 0; base < len; base += 64) {
-        double p = 0.0;
-        if (base + lane < len) p = prob_of(amp[first + base + lane]);
-        double run = cum;
-#pragma unroll
-        for (int j = 0; j < 64; j++) {
-            const double pj = readlane_f64(p, j);
-            run = run + ((int)lane >= j ? pj : 0.0);
-        }
-        const bool hit = (base + lane < len) && (run >= r);
-        const unsigned long long m = __ballot(hit);
-        if (m) {
-            const int firstl = __builtin_ctzll(m);
-            *hit_index = first + base + (uint64_t)firstl;
-            *hit_cum = readlane_f64(run, firstl);
-            return true;
-        }
-        cum = readlane_f64(run, 63);
-    }
-    return false;
-}
-
-__global__ __launch_bounds__(64) void k_meas_chain(const amp_t *__restrict__ amp, uint64_t count,
-                                                   const MeasBlock *__restrict__ blocks, unsigned nblocks,
-                                                   double cum_in, double r, MeasureOut *out, unsigned *stats, unsigned blog)
-{
-    const unsigned lane = threadIdx.x;
-    double cum = cum_in;
-    unsigned slow = 0;
-    // r already reached before the first addition (r <= 0, Q:289 with cum_0 >= cum_in): the first
-    // examined element is the answer -- let the sequential scan of block 0 report it
-    const bool force = (cum_in >= r);
-    for (unsigned b0 = 0; b0 < nblocks; b0 += 64) {
-        MeasBlock mine; mine.S = 0; mine.meta = MEAS_ALLZERO; mine.pad = 0;
-        if (b0 + lane < nblocks) mine = blocks[b0 + lane];
-        const unsigned lim = min(64u, nblocks - b0);
-        {   // group step: when all 64 records are plain (no flag, same binade as the running sum, or all-zero) their
-            // increments simply add up; the sum is monotone, so checking the END of the group (still inside the
-            // binade, still below r) validates every intermediate value -- 64 blocks for the price of one
-            const uint64_t cb = (uint64_t)__double_as_longlong(cum);
-            const int ec = (int)((cb >> 52) & 0x7ff);
-            const bool zero = (mine.meta & MEAS_ALLZERO) != 0;
-            const bool plain = zero || (!(mine.meta & (MEAS_TIE | MEAS_BIG | MEAS_EUNK)) && (int)(mine.meta & 0x7ff) == ec);
-            if (!force && ec != 0 && ec != 0x7ff && __ballot(!plain) == 0ULL) {
-                unsigned long long tot = zero ? 0ULL : (unsigned long long)mine.S;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o, 64);
-                tot = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(tot >> 32), 0) << 32) |
-                      (uint32_t)__builtin_amdgcn_readlane((int)(tot & 0xffffffffu), 0);
-                const uint64_t K = (cb & 0xfffffffffffffULL) | ((uint64_t)1 << 52);
-                const uint64_t Kn = K + tot;
-                if (Kn < ((uint64_t)1 << 53)) {
-                    const double cn = __longlong_as_double((long long)(((uint64_t)ec << 52) | (Kn & 0xfffffffffffffULL)));
-                    if (!(cn >= r)) { cum = cn; continue; }
-                }
-            }
-        }
-        for (unsigned j = 0; j < lim; j++) {
-            const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)mine.meta, j);
-            if ((meta & MEAS_ALLZERO) && !force) continue;
-            const uint64_t S = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(mine.S >> 32), j) << 32) |
-                               (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(mine.S & 0xffffffffu), j);
-            const uint64_t cb = (uint64_t)__double_as_longlong(cum);
-            const int ec = (int)((cb >> 52) & 0x7ff);
-            bool fast = false;
-            if (!force && !(meta & (MEAS_ALLZERO | MEAS_TIE | MEAS_BIG | MEAS_EUNK)) && ec != 0 && ec == (int)(meta & 0x7ff)) {
-                const uint64_t K = (cb & 0xfffffffffffffULL) | ((uint64_t)1 << 52);
-                const uint64_t Kn = K + S;
-                if (Kn < ((uint64_t)1 << 53)) {
-                    const double cn = __longlong_as_double((long long)(((uint64_t)ec << 52) | (Kn & 0xfffffffffffffULL)));
-                    if (!(cn >= r)) { cum = cn; fast = true; }
-                }
-            }
-            if (!fast) {
-                slow++;
-                const uint64_t first = (uint64_t)(b0 + j) << blog;
-                const uint64_t len = min((uint64_t)1 << blog, count - first);
-                uint64_t hi = 0; double hc = 0.0;
-                if (wave_exact_scan(amp, first, len, cum, r, &hi, &hc)) {
-                    if (lane == 0) { out->found = 1; out->index = hi; out->cum = hc; if (stats) { stats[0] = slow; stats[1] = nblocks; } }
-                    return;
-                }
-            }
-        }
-    }
-    if (lane == 0) { out->found = 0; out->index = 0; out->cum = cum; if (stats) { stats[0] = slow; stats[1] = nblocks; } }
-}
-
 // ---------------------------------------------------------------------------
 // K4c  measurement scan, exact and parallel, in ONE read of the state (round 4).
 //
-// K4b above reads the vector twice (approximate block sums for the binade guesses, then the integer increments under
-// those guesses) and walks the block records on one wave.  Here:
 //   1. k_meas_onepass   a workgroup of four waves takes four consecutive RECORDS of 2^RLOG amplitudes (one per wave, kept
 //                       as |amp|^2 in registers), publishes the (tree) sum of the four, obtains the approximate sum of
 //                       everything before it by a DECOUPLED LOOK-BACK, and every wave computes the integer increment S of
@@ -1055,26 +855,12 @@ struct MeasLevels {
     int top;                         // highest level present
 };
 
-// Round 5: the walk's time was the LATENCY of its steps, not their work -- every event (a binade crossing, a tie ...) costs a
-// descent through the tree and a climb back, one dependent global read of 64 entries per level (a dense n = 30 state: 32 events,
-// 34 us each, 1.1 ms on top of the 2.8 ms scan).  The upper levels are tiny (64^-L of the records): the launch brings as many
-// of them as fit into LDS (stage_from = the lowest staged level; all 256 threads copy, then wave 0 walks alone), so only level 0
-// and the amplitudes of the few slow records still come from memory.
-__global__ __launch_bounds__(256) void k_meas_walk(const amp_t *__restrict__ amp, uint64_t count, MeasLevels T,
-                                                   double cum_in, double r, MeasureOut *out, unsigned *stats, unsigned rlog, int stage_from)
+// (Round 5 staged the upper levels of the tree in LDS for the walk: no change, 3.71 against 3.72 ms on a dense n = 30 state --
+// the ~30 us per event are spent in the exact rescans of the record the event lies in and in the steps' arithmetic on ONE wave,
+// not in the latency of the level reads.  Not kept.)
+__global__ __launch_bounds__(64) void k_meas_walk(const amp_t *__restrict__ amp, uint64_t count, MeasLevels T,
+                                                  double cum_in, double r, MeasureOut *out, unsigned *stats, unsigned rlog)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char qcx_lds_raw[];
-    {
-        MeasBlock *stage = reinterpret_cast<MeasBlock *>(qcx_lds_raw);
-        unsigned off = 0;
-        for (int L = T.top; L >= stage_from && L >= 1; L--) {
-            for (unsigned k = threadIdx.x; k < T.n[L]; k += blockDim.x) stage[off + k] = T.lv[L][k];
-            T.lv[L] = stage + off;                      // (a generic pointer into LDS: the walk below reads it like the global ones)
-            off += T.n[L];
-        }
-        __syncthreads();
-        if (threadIdx.x >= 64) return;
-    }
     const unsigned lane = threadIdx.x;
     const unsigned n0 = T.n[0];
     double cum = cum_in;

@@ -7,9 +7,9 @@ QCX_TEST_NMAX qubits (default 32 = 64 GiB; 33 = 128 GiB still has room for the s
 * `qcx_inverse_QFT` through the default fused path on basis states -- windows bit for bit against the oracle's per-index
   evaluation (orc_basis_iqft_window, pinned to the whole-state oracle in tests/test_oracle_pinning.py);
 * Shor N = 21 (M = 5, L = NMAX - 5): the front windows against the oracle's closed form, then the whole circuit -- norm, the
-  measured index the same through the one-read and the two-read scan, the period visible in omega;
+  measured index the same through two runs of the scan that share no binade guess (record sizes 2^11 and 2^8), the period visible in omega;
 * a fused Hadamard sweep applied twice (identity within rounding), norm kept;
-* measure_state on a dense random state: one-read scan == two-read scan for r over the whole range.
+* measure_state on a dense random state: the same index from both record sizes for r over the whole range.
 
 Everything is a window / property check: no state of this size visits the host.
 """
@@ -49,7 +49,7 @@ def scan(qc, reg, n, r):
 
 @pytest.fixture
 def tune_guard(qc):
-    keys = ("meas_onepass", "fuse_chain", "fuse_gen", "fuse_zskip")
+    keys = ("meas_block_log", "fuse_chain", "fuse_gen", "fuse_zskip")
     old = {k: qc.lib().qcx_tune_get(k.encode()) for k in keys}
     yield
     qc.tune(**old)
@@ -92,9 +92,9 @@ def test_shor_front_and_whole_circuit(qc, ob, tune_guard):
         assert abs(reg.norm2() - 1.0) < 1e-11
         picks = []
         for r in (0.0, 1e-7, 0.25, 0.5, 0.77, 0.999999, 1.0):
-            qc.tune(meas_onepass=1)
-            i1 = scan(qc, reg, n, r)
-            qc.tune(meas_onepass=0)
+            qc.tune(meas_block_log=11)          # two runs of the scan that share no binade guess: other records,
+            i1 = scan(qc, reg, n, r)          # other look-back groups
+            qc.tune(meas_block_log=8)
             i0 = scan(qc, reg, n, r)
             assert i1 == i0, (r, i1, i0)
             picks.append(i1)
@@ -103,7 +103,7 @@ def test_shor_front_and_whole_circuit(qc, ob, tune_guard):
             w = qc.read_omega(i, reg)
             assert min(abs(w - k / 6.0) for k in range(7)) < 2.0 ** -8, (i, w)
         # and the collapsing measurement itself
-        qc.tune(meas_onepass=1)
+        qc.tune(meas_block_log=0)
         assert qc.measure_state(reg, 0.5) == picks[3]
         assert abs(reg.norm2() - 1.0) == 0.0
 
@@ -139,9 +139,9 @@ def test_measure_dense_random_state_both_scans(qc, tune_guard):
         last = -1
         for f in (0.0, 1e-9, 0.1, 0.5, 0.9, 0.999999999, 1.0, 1.5):
             r = f * tot
-            qc.tune(meas_onepass=1)
+            qc.tune(meas_block_log=11)
             i1 = scan(qc, reg, n, r)
-            qc.tune(meas_onepass=0)
+            qc.tune(meas_block_log=8)
             i0 = scan(qc, reg, n, r)
             assert i1 == i0, (f, i1, i0)
             assert i1 >= last                                  # the cumulative sum is monotone in r

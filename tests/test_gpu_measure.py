@@ -1,4 +1,4 @@
-"""GPU: the exact parallel measurement scan (K4b) picks the SAME index as the reference's strictly
+"""GPU: the exact parallel measurement scan (K4c) picks the SAME index as the reference's strictly
 sequential cumulative sum (oracle), on inputs built to break a naive parallel prefix sum: ties at
 half an ulp, binade crossings inside blocks, subnormal partial sums, spikes larger than the running
 sum, sparse states, r on and next to partial sums."""
@@ -15,13 +15,12 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 
 
-@pytest.fixture(params=[(0, 1), (8, 1), (10, 1), (13, 1), (0, 0), (13, 0)],
-                ids=lambda b: (f"block=2^{b[0]}" if b[0] else "block=auto") + ("" if b[1] else "-two-reads"))
+@pytest.fixture(params=[0, 8, 9, 10, 13], ids=lambda b: f"record=2^{b}" if b else "record=auto")
 def force_parallel(qc, request):
-    """the exact parallel form even on small registers, with every block size (0: chosen from the register size); the
-    one-read scan (K4c, default) and round 3's two-read scan (K4b)"""
-    old = {k: qc.lib().qcx_tune_get(k.encode()) for k in ("meas_parallel", "meas_min_log2", "meas_block_log", "meas_onepass")}
-    qc.tune(meas_parallel=1, meas_min_log2=10, meas_block_log=request.param[0], meas_onepass=request.param[1])
+    """the exact parallel form (K4c: one read of the state, look-back, tree walk) even on small registers, with every record
+    size (0: chosen from the register size)"""
+    old = {k: qc.lib().qcx_tune_get(k.encode()) for k in ("meas_parallel", "meas_min_log2", "meas_block_log")}
+    qc.tune(meas_parallel=1, meas_min_log2=10, meas_block_log=request.param)
     yield
     qc.tune(**old)
 
@@ -61,8 +60,7 @@ def test_random_dense_states(qc, ob, force_parallel, n):
     check(qc, ob, n, a, [0.0, 1.0, 0.5, 1e-9, 0.999999999] + list(rs.uniform(0, 1, 10)) + partial_sum_rs(a, rs))
     slow, blocks = last_stats(qc)
     blog = qc.lib().qcx_tune_get(b"meas_block_log") or min(13, max(8, (n - 1) // 2))     # auto: from the register size
-    if qc.lib().qcx_tune_get(b"meas_onepass"):
-        blog = min(blog, 11)                        # the one-read scan (K4c): a record is one wave's 2^8 .. 2^11 amplitudes
+    blog = min(blog, 11)                            # a record is one wave's 2^8 .. 2^11 amplitudes
     assert blocks == -(-((1 << n) - 1) // (1 << blog)) and slow <= 80
 
 

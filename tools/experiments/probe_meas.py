@@ -21,7 +21,7 @@ with qc.Register(L, M) as reg:
     reg.set_fusion(-1)                          # eager collapse: the timed region holds the scan AND the collapse's memset
     for state in ("shor", "dense"):
         for onepass, dbg in ((1, 0),):
-            qc.tune(meas_onepass=onepass, meas_dbg=dbg)
+            qc.tune(meas_dbg=dbg)
             for r in (0.3, 0.77, 0.999):
                 if state == "shor":
                     reg.set_fusion(0); qc.reset_register(reg); qc.quantum_computation(21, 2, reg); reg.set_fusion(-1)

@@ -135,7 +135,7 @@ struct Tune {
     long fuse_front = 1;       // a pending reset / collapse is written together with the closed-form front of the queue (K0b)
     long fuse_tol_T = 10;      // tolerance mode: tile bits of diagonal passes when that costs no extra pass (0: same as the rest)
     long fuse_tol_occ = 6;     // tolerance-mode passes (merged diagonals): waves per SIMD the kernel is built for (6 or 8)
-    long fuse_rounds_occ = 8;  // rounds-form passes: k_fused_rounds built for this many waves per SIMD (6, 7, 8; 0 = the general kernel)
+    long fuse_rounds_occ = 7;  // rounds-form passes: k_fused_rounds built for this many waves per SIMD (6 or 7; 0 = the general kernel)
     long fuse_T_phase = 10;    // tile bits of phase-dominated passes (one tile per workgroup, not pipelined); 0 = same as the rest
     long fuse_c_phase = 4;
     long fuse_phase_ratio = 6; // a pass is phase-dominated when it holds at least this many phases per H (and nothing else)

@@ -610,7 +610,7 @@ static bool launch_rounds_kernel(int occ, int tol_occ, unsigned grid, size_t lds
         if (P.gen) {          // the tiles are generated (circuit front on an unwritten basis state): passes without multiplies only
 #define QCX_GEN_LAUNCH(O, S) hipLaunchKernelGGL((k_fused_rounds<B, TT, O, false, S, true>), dim3(grid), dim3(B), lds, st, amp, amp_out, n, P, d_ops, ntiles, d_ops)
             if (P.dg_cnt) { if (P.dg_slim) { if (tol_occ >= 8) QCX_GEN_LAUNCH(8, 2); else QCX_GEN_LAUNCH(6, 2); } else QCX_GEN_LAUNCH(6, 1); }
-            else if (occ >= 8) QCX_GEN_LAUNCH(8, 0);
+            else if (occ >= 7) QCX_GEN_LAUNCH(7, 0);
             else QCX_GEN_LAUNCH(6, 0);
 #undef QCX_GEN_LAUNCH
             return true;
@@ -625,8 +625,11 @@ static bool launch_rounds_kernel(int occ, int tol_occ, unsigned grid, size_t lds
             return true;
         }
 #define QCX_ROUNDS_LAUNCH(O, C) hipLaunchKernelGGL((k_fused_rounds<B, TT, O, C>), dim3(grid), dim3(B), lds, st, amp, amp_out, n, P, d_ops, ntiles, d_ops)
-        if (occ >= 8) { if (cam) QCX_ROUNDS_LAUNCH(8, true); else QCX_ROUNDS_LAUNCH(8, false); }
-        else if (occ == 7) { if (cam) QCX_ROUNDS_LAUNCH(7, true); else QCX_ROUNDS_LAUNCH(7, false); }
+        // (round 5: no 8-wave build of the kernels that hold the walk any more.  Its 16 record SGPRs lay beyond the allocator's
+        //  budget there -- hipcc: "reserved registers" on the clobber list -- and with 96 SGPRs a CU admits 7 blocks of 256 threads,
+        //  not 8, anyway; measured 11.81 (8) / 11.95 (7) / 11.89 (6) ms on the n = 28 inverse QFT, 12.71 / 12.53 on the n = 30
+        //  Shor circuit: no difference beyond the noise between boxes.  profiles/r05_occupancy.txt)
+        if (occ >= 7) { if (cam) QCX_ROUNDS_LAUNCH(7, true); else QCX_ROUNDS_LAUNCH(7, false); }
         else { if (cam) QCX_ROUNDS_LAUNCH(6, true); else QCX_ROUNDS_LAUNCH(6, false); }
 #undef QCX_ROUNDS_LAUNCH
         return true;
@@ -708,6 +711,15 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
         } else if (tn.fuse_ldsdma) hipLaunchKernelGGL((k_fused<B, TTv, true>), dim3(grid), dim3(B), lds, r->stream, amp_in, n, P, d_ops, ntiles, d_ops); \
         else hipLaunchKernelGGL((k_fused<B, TTv, false>), dim3(grid), dim3(B), lds, r->stream, amp_in, n, P, d_ops, ntiles, d_ops); } while (0)
     if (P.dg_slim == 2) {                 // tolerance mode, radix-8 fast rounds only
+        if (P.T == 13 && !P.dg_cnt && !P.gen) {
+            // EXPERIMENT (round 5, fuse_hsweep_T = 13): all-Hadamard passes on tiles of 2^13 amplitudes -- 9 hot bits next to c = 4,
+            // i.e. 256-byte store runs where the 2^12 geometry with c = 3 has 128-byte ones -- at the price of ONE 128-KiB workgroup
+            // per CU.  Measured slower; kept selectable so that the number can be reproduced.
+            const size_t lds13 = ((size_t)16 << 13) + 16;
+            hipLaunchKernelGGL((k_fused_q3<1024, 13, 4, true>), dim3(grid_for(ntiles, 1, tn.fuse_q3_cap_exact)), dim3(1024), lds13, r->stream, amp_in, amp_out, n, P, d_ops, ntiles);
+            HIP_TRY(hipGetLastError());
+            return QCX_NO_ERROR;
+        }
         if (P.T != 12) { set_error("radix-8 pass on a tile of 2^%u amplitudes", P.T); return QCX_UNKNOWN_ERROR; }
         if (P.dg_cnt && !P.gen && tn.fuse_x8t) {              // round 5: the hand-written round on the k_fused_x8 shell (K6x-t)
             P.dg_lds_off = 0;
@@ -876,8 +888,8 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         act.P.cam_ctl_local[3] = (int32_t)(sh.n_other ? cam_lut_bytes((unsigned)r->M) : 16);
         for (unsigned j = 0; j < act.P.nh; j++) act.P.hbit[j] = (uint8_t)sh.hbits[j];
         std::vector<FuseOp> legacy;
-        bool rounds = tn.fuse_rounds && act.P.T >= 10 && act.P.T <= 12;
-        if (sh.want_q3 && !(rounds && act.P.T == 12 && sh.n_other == 0)) return 1;
+        bool rounds = tn.fuse_rounds && act.P.T >= 10 && (act.P.T <= 12 || (act.P.T == 13 && sh.want_q3 && !tol && sh.n_ph == 0));
+        if (sh.want_q3 && !(rounds && (act.P.T == 12 || act.P.T == 13) && sh.n_other == 0)) return 1;
         if (sh.want_x8 && !(rounds && sh.n_other == 0 && !tol)) return 1;
         // (tolerance mode: merged diagonals exist in the rounds form only, at most 16 per pass -- their tables live in LDS;
         // otherwise the pass gets the plain phases they were merged from)
@@ -908,7 +920,8 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
             }
             const size_t nrec = all_ops.size() - act.op_off;
             size_t lds = 2 * ((size_t)16 << act.P.T) + (size_t)act.P.cam_ctl_local[3] + blob.size() + 64 + 8 * (nrec + 66);
-            size_t limit = (size_t)160 * 1024 / (act.P.T == 12 ? 1 : act.P.T == 11 ? 2 : 4);
+            size_t limit = (size_t)160 * 1024 / (act.P.T >= 12 ? 1 : act.P.T == 11 ? 2 : 4);
+            if (act.P.T == 13) lds = ((size_t)16 << 13) + 64 + 8 * (nrec + 66);          // one tile per CU
             if (keep_diags) {            // tolerance mode: what the workgroup really needs; two of them must fit a CU
                 lds = ((size_t)16 << act.P.T) + (sh.n_other ? (size_t)act.P.cam_ctl_local[3] : 16) + blob.size() + 64 + 8 * (nrec + 66) + 16 * 49 * pass_diags.size();
                 limit = (size_t)80 * 1024;
@@ -1011,7 +1024,7 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         const bool cols_pass = first_cols && first == 0 && n >= 14;
         {
             const unsigned Ta = (unsigned)tn.fuse_hsweep_T, ca = (unsigned)tn.fuse_hsweep_c;
-            bool tail_h = Ta >= 10 && Ta <= 12 && Ta <= n && ca <= Ta && tn.fuse_rounds;
+            bool tail_h = Ta >= 10 && Ta <= 13 && Ta <= n && ca <= Ta && tn.fuse_rounds;       // (13: experiment of round 5, 128-KiB tiles: see launch_pass)
             for (size_t k = first; tail_h && k < gates.size(); k++) tail_h = gates[k].type == FUSE_H;
             if (tail_h) {
                 auto passes = [&](unsigned TT, unsigned cc) {
@@ -1029,7 +1042,7 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
                 };
                 if (passes(Ta, ca) * 123u < passes(T, c_def) * 100u) {
                     Tcur = Ta; ccur = ca;
-                    if (Ta == 12 && q3_allowed && tn.fuse_q3) want_q3 = true;      // radix-8 rounds, exact butterflies (k_fused_q3<.., EXACT>)
+                    if ((Ta == 12 || Ta == 13) && q3_allowed && tn.fuse_q3) want_q3 = true;      // radix-8 rounds, exact butterflies (k_fused_q3<.., EXACT>)
                 }
             }
         }
@@ -1132,7 +1145,7 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         if (!acts[a].fused) return false;
         const FusePass &P = acts[a].P;
         if (!tn.fuse_ldsdma || tn.fuse_rounds_occ < 6) return false;               // (launch_pass would take the general kernel, which works in place only)
-        return P.cam_ctl_local[0] == 1 && !P.has_cam && P.T >= 10 && P.T <= 12 && P.T < n;
+        return P.cam_ctl_local[0] == 1 && !P.has_cam && P.T >= 10 && (P.T <= 12 || (P.T == 13 && P.dg_slim == 2)) && P.T < n;
     };
     bool any = false;
     for (size_t a0 = 0; a0 < acts.size();) {

@@ -1425,12 +1425,11 @@ struct Quad { double x0, y0, x1, y1, x2, y2, x3, y3; };
 // ONE asm statement for everything that touches the amplitudes inside the round's item loop: with separate
 // statements (or C++ butterflies) the compiler keeps two sets of VGPRs for the four amplitudes and copies between
 // them at every item, which costs more than a gate.
-// The record blocks s[72:79] / s[80:87] are named registers on the clobber list.  In the 8-waves-per-SIMD instantiations
-// the compiler's own SGPR budget ends at s71 (800 / 8 minus the trap handler's 16, in granules of 16, minus VCC /
-// FLAT_SCRATCH / XNACK), so there it reports them as "reserved registers" on the clobber list (-Winline-asm).  Reserved here
-// means "beyond what the allocator may hand out", not "in use": the kernel descriptor counts them (94 SGPRs, still 8
-// waves: 800 / 96), nothing outside this statement reads or writes them (tests/test_abi_and_build.py checks the listing),
-// and the walk gets its 16 record registers without taking any from the allocator.
+// The record blocks s[72:79] / s[80:87] are named registers on the clobber list.  The kernels that hold this statement are
+// built for at most 7 waves per SIMD (round 5), where the blocks lie inside the allocator's budget: it works around the
+// clobbers, the kernel descriptor counts them, and hipcc has nothing to warn about (tests/test_abi_and_build.py checks
+// the build log and the metadata).  (Rounds 2-4 also had 8-wave builds, with the blocks beyond the allocator's budget --
+// "reserved registers" -- which were no faster: 96 SGPRs admit 7 blocks of 256 threads per CU, not 8.)
 __device__ __forceinline__ void fuse_round_item(Quad &q, const FuseOp *item, uint64_t live, unsigned p, uint32_t hdr,
                                                 uint32_t &xaddr, uint32_t &hdr_next, uint64_t &mask_next)
 {

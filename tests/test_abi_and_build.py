@@ -148,40 +148,37 @@ def test_fused_rounds_kernel_keeps_its_scalar_record_loads():
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     txt = open(s_path).read()
-    bodies = [txt[m.start():txt.find(".Lfunc_end", m.start())] for m in re.finditer(r"^_ZN3qcx14k_fused_roundsILi512ELi11ELi8ELb[01]ELi0ELb0EE\w*:", txt, re.M)]
+    bodies = [txt[m.start():txt.find(".Lfunc_end", m.start())] for m in re.finditer(r"^_ZN3qcx14k_fused_roundsILi512ELi11ELi7ELb[01]ELi0ELb0EE\w*:", txt, re.M)]
     assert len(bodies) == 2
     for b in bodies:
         assert len(re.findall(r"global_load_dword ", b)) == 0 and len(re.findall(r"flat_load", b)) == 0
         assert b.count("s_load_dword") > 20 and b.count("v_cmpx_eq_u32") >= 15 * 4
         assert not re.search(r"v_fma_f64|v_fmac_f64|v_pk_fma_f64", b)
         m = re.search(r"; ScratchSize: (\d+)", txt[txt.find(b[:60]) + len(b):])
-        assert m and int(m.group(1)) <= 64          # at most a handful of spilled dwords at 64 VGPRs
+        assert m and int(m.group(1)) <= 64          # at most a handful of spilled dwords
 
 
-def test_walk_record_registers_are_private_to_the_walk():
-    """The item walk keeps its two gate records in the named blocks s[72:79] / s[80:87] (clobbers of the asm statement).
-    Where those lie beyond the allocator's budget (the 8-wave instantiations; hipcc warns "reserved registers") nothing
-    else in the kernel may touch them, and the kernel must still declare them (SGPR count above 87)."""
+def test_walk_record_registers_are_inside_the_allocators_budget():
+    """The item walk keeps its two gate records in the named blocks s[72:79] / s[80:87] (clobbers of the asm statement).  Every
+    kernel that holds the walk is built for at most 7 waves per SIMD (round 5), where those registers lie inside the
+    allocator's budget: the build must not warn about "reserved registers" on a clobber list, and the kernel descriptor must
+    count them (SGPR count above 87)."""
     s_path = os.path.join(ROOT, "quantumcomputer_amd", "libqcx.gfx950.s")
-    r = subprocess.run(["make", "-C", os.path.join(ROOT, "quantumcomputer_amd", "csrc"), "-s", "isa"],
+    r = subprocess.run(["make", "-B", "-C", os.path.join(ROOT, "quantumcomputer_amd", "csrc"), "-s", "isa"],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    assert "reserved registers" not in r.stderr, r.stderr[-2000:]
     txt = open(s_path).read()
     funcs = {m.group(1): txt[m.start():txt.find(".Lfunc_end", m.start())] for m in re.finditer(r"^(_Z\w+):", txt, re.M)}
     sgprs = {m.group(1): int(m.group(2)) for m in re.finditer(r"\.name:\s*(\S+)\s.*?\.sgpr_count:\s*(\d+)", txt, re.S)}
-    own = r"s_load_dwordx8 s\[(72:79|80:87)\]|v_mul_f64|s_cmp_eq_u32 s(73|81), 0|v_and_b32(_e32)? v\d+, s(73|81)|v_cmpx?_eq_u32(_e32)? vcc, s(73|81)"
     seen = 0
     for name, body in funcs.items():
         if "s_load_dwordx8 s[72:79]" not in body:
             continue
-        assert sgprs[name] >= 88 + 6, (name, sgprs[name])
-        if not re.match(r"_ZN3qcx14k_fused_roundsILi\d+ELi\d+ELi8E", name):
-            continue            # 6 and 7 waves: s72..s87 are inside the budget and the allocator works around the clobbers
         seen += 1
-        stray = [l.strip() for l in body.split("\n")
-                 if re.search(r"\bs(7[2-9]|8[0-7])\b|s\[(7[2-9]|8[0-7]):", l) and not re.search(own, l)]
-        assert not stray, (name, stray[:4])
-    assert seen == 9
+        assert sgprs[name] >= 88 + 6, (name, sgprs[name])
+        assert not re.match(r"_ZN3qcx14k_fused_roundsILi\d+ELi\d+ELi8ELb[01]ELi[01]E", name), ("an 8-wave build of the walk", name)
+    assert seen >= 10, seen
 
 
 def test_exact_walk_on_8_amplitudes_declares_its_fixed_registers():

@@ -31,7 +31,7 @@ def main():
     F, W = rows(dfetch, "FETCH_SIZE"), rows(dwrite, "WRITE_SIZE")
     mean = lambda v: sum(v) / len(v) if v else None
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline` "
-                     "(tools/experiments/prof_r04.sh), summarised by tools/make_traffic.py; KiB units; FETCH_SIZE doubled per the guide's gfx950 correction",
+                     "(tools/prof_r05.sh), summarised by tools/make_traffic.py; KiB units; FETCH_SIZE doubled per the guide's gfx950 correction",
            "kernels": []}
     keys = sorted(set(F) | set(W), key=lambda k: -(len(F.get(k, [])) + len(W.get(k, []))))
     for k in keys:

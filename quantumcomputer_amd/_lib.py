@@ -113,6 +113,7 @@ _EXTRA = {
     "qcx_gen_stats": (_i, [_p, C.POINTER(_ul)]),
     "qcx_gen_cols_stats": (_i, [_p, C.POINTER(_ul)]),
     "qcx_compact_stats": (_i, [_p, C.POINTER(_ul)]),
+    "qcx_compact_measure_stats": (_i, [_p, C.POINTER(_ul)]),
 }
 
 

@@ -844,6 +844,7 @@ struct qcx_register {
     // a compact chain left the state in its compact form (qcx_fuse.inc.h, compact_chain): r->amp is stale until expand_pending()
     // runs -- at the next flush, unless measure_state gets there first (it scans the compact form and collapses lazily)
     int        compact_pending;
+    unsigned long compact_measures;            // measurements that scanned the compact form
     amp_t     *compact_amp;     // inside r->scratch
     unsigned   compact_cb, compact_ncols;
     uint16_t   compact_orbit[16];
@@ -1364,6 +1365,14 @@ extern "C" int qcx_compact_stats(qcx_register *r, unsigned long *compact_chains)
     return QCX_NO_ERROR;
 }
 
+// diagnostics: measurements that scanned the compact form of a circuit's result instead of the register (no expansion written)
+extern "C" int qcx_compact_measure_stats(qcx_register *r, unsigned long *compact_measures)
+{
+    if (!r || !compact_measures) return QCX_BAD_ARGUMENTS;
+    *compact_measures = r->sh ? r->sh->compact_measures : r->compact_measures;
+    return QCX_NO_ERROR;
+}
+
 extern "C" int qcx_register_set_stream(qcx_register *r, void *hip_stream)
 {
     if (!r) return QCX_BAD_ARGUMENTS;
@@ -1553,6 +1562,7 @@ extern "C" int qcx_measure_state_r(qcx_register *r, double rnd, unsigned long *s
             else if (found) idx = ((cidx >> cb) << M) | r->compact_orbit[col];
         }
         r->compact_pending = 0;                                             // the collapse below replaces the whole state
+        r->compact_measures++;
     } else
     QCX_TRY(qcx_shard_measure_scan(r->amp, r->n, 0, r->dim - 1, 0.0, rnd, &found, &idx, &cum, r->stream));
     if (!found) idx = r->dim - 1;                                           // Q:283 fall-through

@@ -72,7 +72,12 @@ struct ShardSet {
                                                   // shard's OWN spare buffer and the chunks travel by hipMemcpyPeerAsync (no peer stores, no relays)
     bool     zeros_dirty = false;                 // the caller wrote amplitudes: one k_canon_zeros pass per shard before the next gate (Q:393-413)
     ShardSet *comp = nullptr;                     // the COMPANION register of compact circuits (sh_compact): L + cb qubits on the same devices, created on first use
-    unsigned long compact_circuits = 0;
+    unsigned long compact_circuits = 0, compact_measures = 0;
+    // round 5: the result of a compact circuit STAYS on the companion until something other than measure_state looks at the state
+    // (sh_flush expands it then); measure_state scans the companion's shards -- the left-out amplitudes are +0 and add nothing to the
+    // reference's running sum, the compact order is the index order -- so an attempt never writes the 16 * 2^n bytes at all
+    bool comp_pending = false;
+    ExpandParams comp_E;
     int      fusion = 1;                          // 1: each shard's gate list goes through the fused-pass scheduler; -1/0: one launch per gate
     size_t   max_queue = 8192;
     std::string trace;
@@ -596,7 +601,7 @@ static int sh_materialize_basis(ShardSet *sh)
     return QCX_NO_ERROR;
 }
 
-static int sh_flush(ShardSet *sh);
+static int sh_flush(ShardSet *sh, bool keep_compact = false);
 static int sh_identity(ShardSet *sh);
 static int sh_set_relays(ShardSet *sh, unsigned nrelays, const int *devices);
 
@@ -667,25 +672,14 @@ static int sh_compact(ShardSet *sh, bool *done)
     }
     QCX_TRY(sh_flush(c));
     QCX_TRY(sh_identity(c));
-    const uint64_t nchunks = ((uint64_t)1 << (sh->n_local - M)) >> 6;
     for (unsigned r = 0; r < sh->W; r++) {                  // every companion shard is complete (peers push into it; its streams are not the register's)
         SH_DEV(c, r);
         HIP_TRY(hipStreamSynchronize(c->st[r]));
         HIP_TRY(hipStreamSynchronize(c->xs[r]));
     }
     for (size_t i = 0; i < c->relay_st.size(); i++) { HIP_TRY(hipSetDevice(c->relay_dev[i])); HIP_TRY(hipStreamSynchronize(c->relay_st[i])); }
-    for (unsigned r = 0; r < sh->W; r++) {
-        SH_DEV(sh, r);
-        hipLaunchKernelGGL(k_expand_compact, dim3(grid_for(nchunks, 1, 65536)), dim3(256), 0, sh->st[r], (const amp_t *)c->buf[c->cur][r], sh->buf[sh->cur][r], nchunks, E, (int)tn.fuse_expand_direct);
-        HIP_TRY(hipGetLastError());
-        // the expansion READS the companion's buffer on the register's stream: whatever the companion's own streams do next
-        // (the front of the next compact circuit overwrites that buffer) has to wait for it
-        if (r < c->ev_a.size() && c->ev_a[r]) {
-            HIP_TRY(hipEventRecord(c->ev_a[r], sh->st[r]));
-            HIP_TRY(hipStreamWaitEvent(c->st[r], c->ev_a[r], 0));
-            HIP_TRY(hipStreamWaitEvent(c->xs[r], c->ev_a[r], 0));
-        } else HIP_TRY(hipStreamSynchronize(sh->st[r]));
-    }
+    sh->comp_pending = true;                                // the real register is written by sh_expand_pending -- or never
+    sh->comp_E = E;
     sh->exchanges += c->exchanges - ex0; sh->pack_passes += c->pack_passes - pp0;
     sh->relayed_bytes += c->relayed_bytes - rb0; sh->overlapped_gates += c->overlapped_gates - og0;
     sh->basis_pending = false;
@@ -696,12 +690,41 @@ static int sh_compact(ShardSet *sh, bool *done)
     return QCX_NO_ERROR;
 }
 
-static int sh_flush(ShardSet *sh)
+// the real register from the companion's compact form (every shard expands its own part)
+static int sh_expand_pending(ShardSet *sh)
 {
+    if (!sh->comp_pending) return QCX_NO_ERROR;
+    sh->comp_pending = false;
+    ShardSet *c = sh->comp;
+    if (!c) { set_error("sharded register: a compact result without its companion"); return QCX_UNKNOWN_ERROR; }
+    const Tune tn = tune_now();
+    const uint64_t nchunks = ((uint64_t)1 << (sh->n_local - sh->M)) >> 6;
+    for (unsigned r = 0; r < sh->W; r++) {
+        SH_DEV(sh, r);
+        hipLaunchKernelGGL(k_expand_compact, dim3(grid_for(nchunks, 1, 65536)), dim3(256), 0, sh->st[r], (const amp_t *)c->buf[c->cur][r], sh->buf[sh->cur][r], nchunks, sh->comp_E, (int)tn.fuse_expand_direct);
+        HIP_TRY(hipGetLastError());
+        // the expansion READS the companion's buffer on the register's stream: whatever the companion's own streams do next
+        // (the front of the next compact circuit overwrites that buffer) has to wait for it
+        if (r < c->ev_a.size() && c->ev_a[r]) {
+            HIP_TRY(hipEventRecord(c->ev_a[r], sh->st[r]));
+            HIP_TRY(hipStreamWaitEvent(c->st[r], c->ev_a[r], 0));
+            HIP_TRY(hipStreamWaitEvent(c->xs[r], c->ev_a[r], 0));
+        } else HIP_TRY(hipStreamSynchronize(sh->st[r]));
+    }
+    return QCX_NO_ERROR;
+}
+
+static int sh_flush(ShardSet *sh, bool keep_compact)
+{
+    if (sh->comp_pending) {                       // an earlier flush left the state on the companion register
+        if (keep_compact && sh->queue.empty() && !sh->basis_pending) return QCX_NO_ERROR;
+        if (sh->basis_pending) sh->comp_pending = false;        // (a reset came after it: the compact form is history)
+        else QCX_TRY(sh_expand_pending(sh));
+    }
     if (sh->basis_pending && !sh->queue.empty()) {
         bool done = false;
         QCX_TRY(sh_compact(sh, &done));
-        if (done) return QCX_NO_ERROR;
+        if (done) return keep_compact ? QCX_NO_ERROR : sh_expand_pending(sh);      // (only measure_state leaves the result on the companion)
     }
     if (sh->basis_pending) QCX_TRY(sh_materialize_basis(sh));
     if (sh->queue.empty()) return QCX_NO_ERROR;
@@ -921,6 +944,47 @@ static int sh_norm2(ShardSet *sh, double *out)
 // Q:272-306 over the shards: the sequential cumulative sum is handed from shard to shard in index order
 static int sh_measure(ShardSet *sh, double rnd, unsigned long *state_num)
 {
+    QCX_TRY(sh_flush(sh, true));                                                // (a compact circuit's result may stay on the companion)
+    if (sh->comp_pending && !sh->dry) {
+        // the scan of Q:283-292 on the compact form, shard by shard (qcx_measure_state_r does the same on one GPU): the amplitudes it
+        // leaves out are +0, the compact order is the index order; r <= 0 stops at index 0 whatever it holds; the register's last
+        // index stays unexamined also when it lies on the orbit
+        ShardSet *c = sh->comp;
+        const ExpandParams &E = sh->comp_E;
+        const uint64_t dim = (uint64_t)1 << sh->n;
+        uint64_t idx = dim - 1;
+        bool have = false, rescan = false;
+        if (rnd <= 0.0) { idx = 0; have = true; }
+        else {
+            uint64_t last_excl = (uint64_t)1 << c->n;
+            if (E.orbit[E.ncols - 1] == (1u << E.M) - 1u) last_excl = ((((uint64_t)1 << (sh->n - E.M)) - 1) << E.cb) | (E.ncols - 1);
+            double cum = 0.0;
+            for (unsigned r = 0; r < c->W && !have && !rescan; r++) {
+                SH_DEV(c, r);
+                int found = 0; uint64_t ci = 0; double c2 = cum;
+                QCX_TRY(qcx_shard_measure_scan(c->buf[c->cur][r], c->n_local, (uint64_t)r << c->n_local, last_excl, cum, rnd, &found, &ci, &c2, c->st[r]));
+                cum = c2;
+                if (found) {
+                    const unsigned col = (unsigned)(ci & ((1u << E.cb) - 1u));
+                    if (col >= E.ncols) rescan = true;                        // a hit in a padding column: the premise broke -- expand and scan the register
+                    else { idx = ((ci >> E.cb) << E.M) | E.orbit[col]; have = true; }
+                }
+            }
+            if (!rescan) have = true;                                           // (nothing found: Q:283 fall-through to the last index)
+        }
+        if (have && !rescan) {
+            sh->comp_pending = false;                                           // the collapse below replaces the whole state
+            sh->compact_measures++;
+            const unsigned owner = (unsigned)(idx >> sh->n_local);
+            for (unsigned r = 0; r < sh->W; r++) {
+                SH_DEV(sh, r);
+                QCX_TRY(qcx_shard_collapse(sh->buf[sh->cur][r], sh->n_local, r == owner ? (int64_t)(idx & ((((uint64_t)1) << sh->n_local) - 1)) : -1, sh->st[r]));
+            }
+            *state_num = (unsigned long)idx;
+            return QCX_NO_ERROR;
+        }
+        QCX_TRY(sh_expand_pending(sh));
+    }
     QCX_TRY(sh_identity(sh));
     if (sh->dry) return QCX_UNSUPPORTED;
     QCX_TRY(sh_sync(sh));

@@ -226,7 +226,10 @@ class ShardedRegister:
         self.exchanges = 0                # all-to-alls performed
         self.fronts = 0                   # circuit fronts written as one pass (qcx_shard_basis_front)
         self.compact_circuits = 0         # flushes that ran on the companion register of compact circuits (_try_compact)
+        self.compact_measures = 0         # measurements that scanned the companion register instead of the expanded state
         self._comp = None                 # that companion: L + cb qubits on the same ranks, created on first use
+        self._compact = None              # (cb, orbit) while the result of a compact circuit still sits on the companion (round 5:
+                                          # expanded when something other than measure_state looks at the state -- or never)
         self._slices_log2 = slices_log2
         self._basis_pending = False
         self.pack_passes = 0              # local pack passes performed
@@ -603,7 +606,7 @@ class ShardedRegister:
         comp.queue = [("h", g[1] - sh) if g[0] == "h" else ("p", g[1] - sh, g[2] - sh, g[3], g[4]) for g in rest]
         comp.flush()
         comp._identity()
-        eng.expand_compact(comp.shard, self.shard, self.n_local, M, cb, orbit)
+        self._compact = (cb, list(orbit))          # the real register is written by _expand_compact -- or never
         self.exchanges += comp.exchanges - ex0
         self.pack_passes += comp.pack_passes - pp0
         self.overlapped_gates += comp.overlapped_gates - og0
@@ -614,8 +617,25 @@ class ShardedRegister:
         self.compact_circuits += 1
         return True
 
-    def flush(self):
+    def _expand_compact(self):
+        """the real register from the companion's compact form (every rank expands its own part; no communication)"""
+        if self._compact is None:
+            return
+        cb, orbit = self._compact
+        self._compact = None
+        self.engine.expand_compact(self._comp.shard, self.shard, self.n_local, self.M_size, cb, orbit)
+
+    def flush(self, keep_compact=False):
+        if self._compact is not None:            # an earlier flush left the state on the companion register
+            if keep_compact and not self.queue and not getattr(self, "_basis_pending", False):
+                return
+            if getattr(self, "_basis_pending", False):
+                self._compact = None             # (a reset came after it: the compact form is history)
+            else:
+                self._expand_compact()
         if getattr(self, "_basis_pending", False) and self._try_compact():
+            if not keep_compact:
+                self._expand_compact()           # (only measure_state leaves the result on the companion)
             return
         if getattr(self, "_basis_pending", False):
             self._materialize_basis()
@@ -687,6 +707,7 @@ class ShardedRegister:
     # -- gates ----------------------------------------------------------------------------------
     def reset_register(self):
         self.queue = []                                   # pending gates act on a state that is being overwritten
+        self._compact = None                              # (and so does a compact result nobody looked at)
         n = self.num_qubits
         self.perm, self.inv = list(range(n)), list(range(n))
         if self.fusion and hasattr(self.engine, "basis_front"):
@@ -715,6 +736,7 @@ class ShardedRegister:
 
     def fill_random(self, seed):
         self._basis_pending = False
+        self._compact = None
         self.queue = []
         n = self.num_qubits
         self.perm, self.inv = list(range(n)), list(range(n))
@@ -762,7 +784,20 @@ class ShardedRegister:
 
     def measure_state(self, r):
         """qc_shor.c:272-306 over the shards: the sequential cumulative sum is handed from rank to
-        rank in index order, so the selected index is the one the unsharded scan would pick."""
+        rank in index order, so the selected index is the one the unsharded scan would pick.
+        Round 5: behind a compact circuit the scan runs on the companion register's shards -- the amplitudes the compact form
+        leaves out are +0 and add nothing to the running sum, the compact order is the index order -- and the 16 * 2^n bytes
+        of the real register are never written (the collapse replaces them)."""
+        self.flush(keep_compact=True)
+        if self._compact is not None:
+            idx = self._measure_compact(float(r))
+            if idx is not None:
+                self._compact = None
+                self.compact_measures += 1
+                owner = idx >> self.n_local
+                self.engine.collapse(self.shard, self.n_local, idx & ((1 << self.n_local) - 1) if owner == self.rank else -1)
+                return idx
+            self._expand_compact()               # (a hit in a padding column: the premise broke -- scan the expanded register)
         self._identity()
         last_excluded = self.num_states - 1
         msg = torch.zeros(3, dtype=torch.float64, device=self.device)
@@ -780,6 +815,35 @@ class ShardedRegister:
         owner = idx >> self.n_local
         self.engine.collapse(self.shard, self.n_local, idx & ((1 << self.n_local) - 1) if owner == self.rank else -1)
         return idx
+
+    def _measure_compact(self, r):
+        """Q:283-292 on the companion register; the real index, or None when the compact premise does not hold"""
+        comp = self._comp
+        cb, orbit = self._compact
+        M, n = self.M_size, self.num_qubits
+        if r <= 0.0:
+            return 0                             # the reference stops at index 0 whatever it holds
+        last_excl = 1 << comp.num_qubits         # compact elements whose real index is below 2^n - 1
+        if orbit[-1] == (1 << M) - 1:
+            last_excl = (((1 << (n - M)) - 1) << cb) | (len(orbit) - 1)
+        msg = torch.zeros(3, dtype=torch.float64, device=self.device)
+        cum, cidx = 0.0, None
+        for rk in range(self.world):
+            if self.rank == rk:
+                f, i, cum_out = self.engine.measure_scan(comp.shard, comp.n_local, rk << comp.n_local, last_excl, cum, r)
+                msg[0], msg[1], msg[2] = float(f), float(i), cum_out
+            dist.broadcast(msg, src=rk if self.group is None else dist.get_global_rank(self.group, rk), group=self.group)
+            m = msg.tolist()
+            cum = m[2]
+            if m[0] != 0.0:
+                cidx = int(m[1])
+                break
+        if cidx is None:
+            return self.num_states - 1           # Q:283 fall-through
+        col = cidx & ((1 << cb) - 1)
+        if col >= len(orbit):
+            return None
+        return ((cidx >> cb) << M) | orbit[col]
 
     def local_numpy(self):
         """this rank's shard in the IDENTITY layout, as a numpy array of 2*2^n_local doubles"""

@@ -64,6 +64,10 @@ def test_shor_circuit_and_measurement(qc, ob, shards, C, L, M, a):
         qc.lib().qcx_compact_stats(reg._h, Ct.byref(cc))
         if (C, L, M) in ((21, 12, 5), (33, 9, 6)):
             assert cc.value == 4, cc.value
+            # round 5: shots 2-4 measure right behind the circuit -- on the companion's compact form, the register is never expanded
+            cm = Ct.c_ulong(0)
+            qc.lib().qcx_compact_measure_stats(reg._h, Ct.byref(cm))
+            assert cm.value == 3, cm.value
         if n - k >= M + 6 and M <= 12:
             # the circuit front (reset + Hadamard layer, shard-id qubits included + multiply ladder) went out as one write
             # pass per shard, without an exchange: one front per shot

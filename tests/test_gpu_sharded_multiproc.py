@@ -96,7 +96,9 @@ def test_compact_circuits_across_processes(world):
     against the oracle"""
     same, picks, nrm, compact = run_gpu(world, G.sc_shor_compact)
     assert same and all(a == b for a, b in picks), picks
-    assert compact == 6, compact
+    # six circuits ran on the companion; the three that were measured right behind the circuit were scanned THERE (round 5: the
+    # register is not expanded for a measurement), the three that were gathered first were expanded
+    assert compact == (6, 3), compact
 
 
 @pytest.mark.parametrize("world", [2, 4])

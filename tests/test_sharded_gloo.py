@@ -181,7 +181,7 @@ def sc_shor_compact(rank, world, ob, make):
         w = want.copy()
         picks.append((reg.measure_state(r), ob.measure(w, n, r)))
         same = same and bool(np.array_equal(bits(reg.gather()), bits(w)))
-    return same, picks, reg.norm2(), getattr(reg, "compact_circuits", 0)
+    return same, picks, reg.norm2(), (getattr(reg, "compact_circuits", 0), getattr(reg, "compact_measures", 0))
 
 
 def sc_mixed_gates_in_swapped_layout(rank, world, ob, make):

@@ -1086,7 +1086,8 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         // (the walk on 8 amplitudes takes a pass as soon as it holds fuse_x8_ratio phases per Hadamard -- far fewer than what makes
         //  a radix-4 pass "phase-dominated": the tail of an inverse QFT, 9 Hadamards with 36 phases, is then ONE pass of 8 hot bits
         //  instead of two of 7)
-        const bool x8_ok = !tol && !cols_pass && q3_allowed && tn.fuse_x8 && tn.fuse_x8_T >= 10 && tn.fuse_x8_T <= 12 && (unsigned)tn.fuse_x8_T <= n &&
+        // (registers of a tile or two keep the radix-4 kernels: a lone 512-thread workgroup is slower there -- the n = 12 attempt 43 -> 50 us)
+        const bool x8_ok = !tol && !cols_pass && q3_allowed && tn.fuse_x8 && tn.fuse_x8_T >= 10 && tn.fuse_x8_T <= 12 && (unsigned)tn.fuse_x8_T + (unsigned)tn.fuse_x8_min_tiles_log2 <= n &&
                            tn.fuse_ldsdma && tn.fuse_rounds_occ >= 6 && n_ph >= 1 && n_ph >= (size_t)tn.fuse_x8_ratio * std::max<size_t>(n_h, 1);
         if (!want_q3 && Tp >= 9 && Tp <= 12 && Tp <= n && tn.fuse_rounds && n_other == 0 &&
             (cols_pass || x8_ok || n_ph >= (size_t)tn.fuse_phase_ratio * std::max<size_t>(n_h, 1))) {

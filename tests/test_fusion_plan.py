@@ -15,12 +15,15 @@ def bits(a):
 
 
 TUNE_KEYS = ("fuse_T", "fuse_c", "fuse_rounds", "fuse_camruns", "fuse_T_phase", "fuse_c_phase", "fuse_phase_ratio", "fuse_tol_T", "fuse_q3",
-             "fuse_x8", "fuse_x8_T", "fuse_x8_c", "fuse_x8_map")
+             "fuse_x8", "fuse_x8_T", "fuse_x8_c", "fuse_x8_map", "fuse_x8_min_tiles_log2")
 
 
 @pytest.fixture()
 def tune_guard(qc):
     old = {k: qc.lib().qcx_tune_get(k.encode()) for k in TUNE_KEYS}
+    # (by default registers of fewer than four tiles keep the radix-4 kernels; the emulator tests run on small registers and want the
+    #  walk on 8 amplitudes wherever the planner would take it at full size)
+    qc.tune(fuse_x8_min_tiles_log2=0)
     yield
     qc.tune(**old)
 
@@ -438,7 +441,7 @@ CHAIN_KEYS = TUNE_KEYS + ("fuse_chain", "fuse_chain_min_n", "fuse_chain_dir", "f
 @pytest.fixture()
 def chain_guard(qc):
     old = {k: qc.lib().qcx_tune_get(k.encode()) for k in CHAIN_KEYS}
-    qc.tune(fuse_chain=1, fuse_chain_min_n=13)
+    qc.tune(fuse_chain=1, fuse_chain_min_n=13, fuse_x8_min_tiles_log2=0)
     yield
     qc.tune(**old)
 

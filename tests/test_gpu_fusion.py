@@ -391,3 +391,59 @@ def test_chained_passes_give_the_same_bits(qc, ob, chain_guard, L, M, Cn, mode):
         got = reg.read()
         assert reg.device_pointer() == p0 and chained_passes(qc, reg) == before
         assert np.array_equal(bits(got), bits(w3)) if mode == 1 else float(np.max(np.abs(got - w3))) <= 1e-12
+
+
+# ---- round 5: the exact walk on 8 amplitudes per thread (k_fused_x8) and the tolerance round on the same shell ---------------
+@pytest.fixture()
+def x8_guard(qc):
+    keys = ("fuse_x8", "fuse_x8_T", "fuse_x8_c", "fuse_x8_map", "fuse_x8_min_tiles_log2", "fuse_x8_ratio", "fuse_x8_cap", "fuse_x8t",
+            "fuse_chain", "fuse_chain_min_n", "fuse_phase_ratio", "fuse_gen")
+    old = {k: qc.lib().qcx_tune_get(k.encode()) for k in keys}
+    yield
+    qc.tune(**old)
+
+
+@pytest.mark.parametrize("T,c", [(12, 4), (12, 3), (11, 4), (11, 3), (10, 4), (10, 2)])
+@pytest.mark.parametrize("xmap", [1, 0], ids=["maps", "ascending"])
+def test_exact_walk_on_8_amplitudes_every_tile_size(qc, ob, x8_guard, T, c, xmap):
+    """k_fused_x8 at every tile size it is built for (2^10, 2^11, 2^12), with the planner's thread maps (wave-private parts, no
+    barriers between rounds) and with plain ascending maps, in place and chained, few tiles and many, grid-stride and one
+    workgroup per tile: random programs (all register patterns of a run, long runs, rounds with one or two Hadamards) and the
+    inverse-QFT schedule, bit for bit against the oracle"""
+    qc.tune(fuse_x8=1, fuse_x8_T=T, fuse_x8_c=c, fuse_x8_map=xmap, fuse_x8_min_tiles_log2=0, fuse_x8_ratio=0, fuse_chain_min_n=13)
+    rs = np.random.RandomState(100 * T + 10 * c + xmap)
+    for L, M, Cn, chain, cap in ((13, 0, 1, 1, 65536), (16, 0, 1, 1, 7), (12, 4, 15, 0, 65536), (T, 0, 1, 1, 65536), (17, 0, 1, 0, 65536)):
+        n = L + M
+        qc.tune(fuse_chain=chain, fuse_x8_cap=cap)
+        prog = [g for g in random_program(rs, n, M, Cn, 90) if g[0] != "c"]
+        # a long run behind one Hadamard (cut at 63 gates) and phases whose two qubits are both register bits of a round
+        top = n - 1
+        prog += [("h", top)] + [("p", top, int(rs.randint(M, top)), float(rs.uniform(-3, 3))) for _ in range(70)]
+        prog += [("h", top - 1), ("p", top, top - 1, 0.3), ("h", top - 2), ("p", top - 1, top - 2, 0.4), ("p", top, top - 2, 0.5)]
+        got, want, stats = run_both(qc, ob, L, M, Cn, prog, 90 + n)
+        assert np.array_equal(bits(got), bits(want)), (T, c, xmap, L, M, chain, cap)
+    # the schedule of Q:678-690
+    n = 16
+    qc.tune(fuse_chain=1, fuse_x8_cap=65536)
+    want = ob.random_state(n, 5)
+    with qc.Register(n, 0) as reg:
+        reg.write(want)
+        qc.inverse_QFT(reg)
+        ob.iqft(want, n, 0, 4)
+        assert np.array_equal(bits(reg.read()), bits(want))
+
+
+@pytest.mark.parametrize("C,L,M,a", [(21, 12, 5, 2), (15, 13, 4, 7)])
+def test_exact_walk_generates_the_circuit_front(qc, ob, x8_guard, C, L, M, a):
+    """GenFront inside a k_fused_x8 pass (the tile generated under the swizzle): Shor circuits whose first pass behind the front
+    is a phase-carrying pass, with the compact chain switched off so that the generated fill of THIS kernel runs"""
+    old = qc.lib().qcx_tune_get(b"fuse_compact")
+    try:
+        qc.tune(fuse_compact=0, fuse_gen_cols=0, fuse_x8_min_tiles_log2=0)
+        n = L + M
+        want = np.zeros(2 << n); ob.reset(want, n); ob.quantum_computation(want, n, M, C, a, threads=4)
+        with qc.Register(L, M) as reg:
+            qc.reset_register(reg); qc.quantum_computation(C, a, reg)
+            assert np.array_equal(bits(reg.read()), bits(want))
+    finally:
+        qc.tune(fuse_compact=old, fuse_gen_cols=1)

@@ -261,10 +261,9 @@ __device__ __forceinline__ unsigned camodc_elem(bool squeeze, unsigned ctl, unsi
     return ((e & ~low) << 1) | (1u << ctl) | (e & low);
 }
 
-// FULL: every amplitude of the tile is stored back (identity rows with the bits they had) as whole nontemporal lines, and
-// the fill is nontemporal too: 32 B per amplitude of the control half instead of 16 + 16 * C / 2^M, but no partial-line
-// writes.  The host takes it when C / 2^M >= 1/2 (most of every line is rewritten anyway).
-template <int BLOCK, bool FULL = false>
+// (A variant that stored every amplitude of the tile back as whole nontemporal lines -- 32 B per amplitude instead of 16 + 16 * C / 2^M,
+// no partial-line writes -- measured 2.9-3.4 against 2.8-2.9 ms in round 3 and was removed in round 5.)
+template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_camodc(amp_t *__restrict__ amp, CamodcParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char qcx_lds_raw[];
@@ -275,31 +274,10 @@ __global__ __launch_bounds__(BLOCK) void k_camodc(amp_t *__restrict__ amp, Camod
     // 32-bit modulo per residue instead of two divisions and a modulo per amplitude (round 4: 2.85 -> 2.4 ms at n = 30 together
     // with the skipped lines)
     unsigned short *lut = reinterpret_cast<unsigned short *>(tile + T);
-    const bool perm = !FULL && P.d == 1u && P.M <= 12u;
+    const bool perm = P.d == 1u && P.M <= 12u;
     if (perm) for (unsigned f = threadIdx.x; f <= blkmask; f += BLOCK) lut[f] = (unsigned short)(f < P.C ? (f * P.inv) % P.C : f);
     for (uint64_t tt = blockIdx.x; tt < P.ntiles; tt += gridDim.x) {
         amp_t *g = camodc_tile(amp, P, tt);
-        if constexpr (FULL) {
-            for (unsigned e = threadIdx.x; e < T; e += BLOCK) tile[e] = __builtin_nontemporal_load(g + camodc_elem(squeeze, (unsigned)P.ctl, e));
-            __syncthreads();
-            for (unsigned e = threadIdx.x; e < T; e += BLOCK) {
-                const unsigned f = e & blkmask;
-                bool on = true;
-                if (P.ctl >= 0 && P.ctl < (int)P.M) on = (e >> P.ctl) & 1u;
-                amp_t acc = tile[e];
-                if (on && f < P.C) {                               // (identity rows keep their bits: Q:611-613, Q:631-634)
-                    acc.x = 0.0; acc.y = 0.0;
-                    if (f % P.d == 0) {
-                        unsigned src = ((f / P.d) * P.inv) % P.Cd;
-                        const amp_t *blk = tile + (e - f);
-                        for (unsigned t = 0; t < P.d; t++, src += P.Cd) { acc.x += blk[src].x; acc.y += blk[src].y; }
-                    }
-                }
-                __builtin_nontemporal_store(acc, g + camodc_elem(squeeze, (unsigned)P.ctl, e));
-            }
-            __syncthreads();
-            continue;
-        }
         // (fill through registers with the DEFAULT cache policy, measured at n = 30: 2.9 ms per gate; an LDS-DMA fill 3.0-3.2 ms;
         // nontemporal loads 4.1-4.5 ms -- the moved elements are rewritten as PARTIAL lines a moment later and those
         // writes must still find their lines in L2)

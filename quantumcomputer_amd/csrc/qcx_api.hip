@@ -124,6 +124,7 @@ struct Tune {
     long cam_stage_mb = 1024;  // M > 12: staging buffer of the in-place modular multiply (MiB; at least one 2^M-block)
     long fuse_compact = 1;     // behind a circuit front whose M register stays on a small orbit: the flush runs on a compact copy of the state (compact_chain)
     long fuse_compact_lazy = 1; // ... and stays compact behind a whole-circuit entry point until something other than measure_state looks at the state
+    long fuse_expand_fused = 1;  // the last pass of a compact chain stores the real register itself (k_fused_x8's expanding store) instead of k_expand_compact
     long fuse_cols_tol = 1;    // tolerance mode: the by-columns pass of a compact chain keeps its merged diagonals (fast rounds inside k_gen_cols)
     long fuse_cols_waves = 4;  // waves per workgroup of k_gen_cols (4 ... 8; the first four generate and store the tile)
     long fuse_expand_direct = 1; // k_expand_compact: 1 = gather the compact sources straight from memory (8 per thread in flight) instead of staging 64 blocks in LDS
@@ -152,7 +153,8 @@ struct Tune {
     long meas_block_log = 0;   // parallel measurement: 2^this amplitudes per block (8..13); 0 = from the shard size
     long meas_parallel = 1;    // 0: always the single-wave sequential scan
     long meas_min_log2 = 12;   // shards below 2^this amplitudes use the single-wave scan (tools/experiments/probe_shots.py)
-    long meas_dbg = 0;         // K4c diagnostics: bit 0 = no look-back (every binade guess from cum_in alone: times the pass without it)
+    long meas_dbg = 0;         // K4c diagnostics: bit 0 = no look-back (every binade guess from cum_in alone: times the pass without it); bit 1 = k_meas_fast hands over to the walk at its third candidate
+    long meas_fast = 1;        // K4c: the scan's events by k_meas_fast (list of candidate records, 8 waves) with k_meas_walk as the fallback; 0: the walk alone
     long meas_spin_limit = 4000000;   // K4c: polls a look-back may spend on one window before it gives up (the block is then scanned exactly)
 };
 static Tune g_tune;
@@ -163,7 +165,7 @@ static Tune tune_now() { std::lock_guard<std::mutex> lock(g_tune_mutex); return 
 extern "C" int qcx_tune_set(const char *key, long value)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); g_tune.name = value; return QCX_NO_ERROR; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_spin_limit) K(meas_dbg) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_dir) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_gen_cols) K(fuse_cols_waves) K(fuse_cols_tol) K(fuse_compact) K(fuse_expand_direct) K(fuse_compact_lazy) K(fuse_zskip) K(fuse_zskip_maxw) K(fuse_x8) K(fuse_x8_T) K(fuse_x8_c) K(fuse_x8_map) K(fuse_x8_cap) K(fuse_x8_ratio) K(fuse_x8_min_tiles_log2) K(fuse_x8t)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_spin_limit) K(meas_dbg) K(meas_fast) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_dir) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_gen_cols) K(fuse_cols_waves) K(fuse_cols_tol) K(fuse_compact) K(fuse_expand_direct) K(fuse_compact_lazy) K(fuse_expand_fused) K(fuse_zskip) K(fuse_zskip_maxw) K(fuse_x8) K(fuse_x8_T) K(fuse_x8_c) K(fuse_x8_map) K(fuse_x8_cap) K(fuse_x8_ratio) K(fuse_x8_min_tiles_log2) K(fuse_x8t)
 #undef K
     return QCX_BAD_ARGUMENTS;
 }
@@ -171,7 +173,7 @@ extern "C" int qcx_tune_set(const char *key, long value)
 extern "C" long qcx_tune_get(const char *key)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); return g_tune.name; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_spin_limit) K(meas_dbg) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_dir) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_gen_cols) K(fuse_cols_waves) K(fuse_cols_tol) K(fuse_compact) K(fuse_expand_direct) K(fuse_compact_lazy) K(fuse_zskip) K(fuse_zskip_maxw) K(fuse_x8) K(fuse_x8_T) K(fuse_x8_c) K(fuse_x8_map) K(fuse_x8_cap) K(fuse_x8_ratio) K(fuse_x8_min_tiles_log2) K(fuse_x8t)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_spin_limit) K(meas_dbg) K(meas_fast) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_dir) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_gen_cols) K(fuse_cols_waves) K(fuse_cols_tol) K(fuse_compact) K(fuse_expand_direct) K(fuse_compact_lazy) K(fuse_expand_fused) K(fuse_zskip) K(fuse_zskip_maxw) K(fuse_x8) K(fuse_x8_T) K(fuse_x8_c) K(fuse_x8_map) K(fuse_x8_cap) K(fuse_x8_ratio) K(fuse_x8_min_tiles_log2) K(fuse_x8t)
 #undef K
     return -1;
 }
@@ -202,6 +204,8 @@ struct Workspace {
     MeasBlock  *meas_blocks = nullptr;
     unsigned    meas_cap = 0;
     unsigned   *meas_stats = nullptr, *h_meas_stats = nullptr; // [slow-path blocks, blocks] of the last scan
+    MeasCands  *meas_cands = nullptr;                           // k_meas_fast: the candidate records of the scan in flight ...
+    MeasResume *meas_resume = nullptr;                          // ... and what it leaves for k_meas_walk
     meas_slot_t *meas_look = nullptr;   // K4c: look-back area (one allocation): agg, incl per workgroup, gincl per group (filled with ones), then
                                         // gsum, gcount per group and the ticket (zeroed)
     MeasBlock  *meas_up = nullptr;      // K4c: the levels above the records (sums of 64, 64^2, ... records), back to back
@@ -224,6 +228,8 @@ static int workspace(Workspace **out)
         HIP_TRY(hipHostMalloc(&w.h_mout, sizeof(MeasureOut)));
         HIP_TRY(hipHostMalloc(&w.h_scalar, sizeof(double)));
         HIP_TRY(hipMalloc(&w.meas_stats, 2 * sizeof(unsigned)));
+        HIP_TRY(hipMalloc(&w.meas_cands, sizeof(MeasCands)));
+        HIP_TRY(hipMalloc(&w.meas_resume, sizeof(MeasResume)));
         HIP_TRY(hipHostMalloc(&w.h_meas_stats, 2 * sizeof(unsigned)));
         w.h_meas_stats[0] = w.h_meas_stats[1] = 0;
     }
@@ -776,7 +782,7 @@ extern "C" int qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_
             HIP_TRY(hipMemsetAsync(w->meas_look, 0xff, (2 * (size_t)nwg + 2 * (size_t)ngrp) * sizeof(meas_slot_t), st));
             HIP_TRY(hipMemsetAsync(LB.ticket, 0, 2 * sizeof(meas_slot_t), st));
             const unsigned spin = (unsigned)std::max<long>(1000, tn.meas_spin_limit);
-#define QCX_ONEPASS(B) hipLaunchKernelGGL((k_meas_onepass<B>), dim3(nwg), dim3(256), 0, st, (const amp_t *)amp, count, cum_in, LB, w->meas_blocks, spin, (unsigned)tn.meas_dbg)
+#define QCX_ONEPASS(B) hipLaunchKernelGGL((k_meas_onepass<B>), dim3(nwg), dim3(256), 0, st, (const amp_t *)amp, count, cum_in, LB, w->meas_blocks, spin, (unsigned)tn.meas_dbg, r)
             switch (blog) {
             case 8: QCX_ONEPASS(8); break;   case 9: QCX_ONEPASS(9); break;   case 10: QCX_ONEPASS(10); break;
             default: QCX_ONEPASS(11); break;
@@ -786,14 +792,21 @@ extern "C" int qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_
             memset(&T, 0, sizeof T);
             T.lv[0] = w->meas_blocks; T.n[0] = nblocks; T.top = 0;
             MeasBlock *up = w->meas_up;
+            // the events of the scan go to k_meas_fast (the launch over the records lists them), the walk stands behind it
+            const bool fast = tn.meas_fast != 0 && T.n[0] > 64u;
+            if (fast) HIP_TRY(hipMemsetAsync(w->meas_cands, 0, 2 * sizeof(unsigned), st));
             while (T.n[T.top] > 64u && T.top < 4) {
                 const unsigned nin = T.n[T.top], nout = (nin + 63u) / 64u;
-                hipLaunchKernelGGL(k_meas_groups, dim3(nout), dim3(64), 0, st, T.lv[T.top], nin, up);
+                hipLaunchKernelGGL(k_meas_groups, dim3(nout), dim3(64), 0, st, T.lv[T.top], nin, up, (fast && T.top == 0) ? w->meas_cands : (MeasCands *)nullptr);
                 T.top++;
                 T.lv[T.top] = up; T.n[T.top] = nout;
                 up += nout;
             }
-            hipLaunchKernelGGL(k_meas_walk, dim3(1), dim3(64), 0, st, (const amp_t *)amp, count, T, cum_in, r, w->mout, w->meas_stats, blog);
+            if (fast)
+                hipLaunchKernelGGL(k_meas_fast, dim3(1), dim3(512), 0, st, (const amp_t *)amp, count, T, cum_in, r, w->mout, w->meas_stats, blog,
+                                   (const MeasCands *)w->meas_cands, w->meas_resume, (unsigned)tn.meas_dbg);
+            hipLaunchKernelGGL(k_meas_walk, dim3(1), dim3(64), 0, st, (const amp_t *)amp, count, T, cum_in, r, w->mout, w->meas_stats, blog,
+                               fast ? (const MeasResume *)w->meas_resume : (const MeasResume *)nullptr);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -1231,7 +1244,9 @@ extern "C" int qcx_fusion_plan_mode(int mode, unsigned n_local, unsigned M, unsi
     QCX_TRY(descs_to_gates(n_local, M, count, gates, q));
     std::vector<FuseAction> acts;
     std::vector<FuseOp> ops;
-    fuse_plan(&tmp, tune_now(), q, acts, ops, (mode & 3) == 2, (mode & 4) != 0);       // mode | 4: with chained passes (a register with a second buffer)
+    // mode | 4: with chained passes (a register with a second buffer); | 8: as compact_chain plans the virtual register of a compact
+    // chain (the first pass generated by columns: a tile of the M register's bits x 8 hot bits)
+    fuse_plan(&tmp, tune_now(), q, acts, ops, (mode & 3) == 2, (mode & 4) != 0, (mode & 8) ? (((mode & 3) == 2 && tune_now().fuse_cols_tol) ? 2 : 1) : 0);
     *n_actions = (unsigned)acts.size();
     *n_records = ops.size();
     if (acts.size() > max_actions || ops.size() > max_records || (!actions && !acts.empty()) || (!records && !ops.empty()))
@@ -1359,6 +1374,14 @@ extern "C" int qcx_compact_stats(qcx_register *r, unsigned long *compact_chains)
 {
     if (!r || !compact_chains) return QCX_BAD_ARGUMENTS;
     *compact_chains = r->sh ? r->sh->compact_circuits : (r->queue ? r->queue->compact_chains : 0);
+    return QCX_NO_ERROR;
+}
+
+// diagnostics: compact chains whose LAST pass stored the real register itself (no k_expand_compact launch)
+extern "C" int qcx_expanding_store_stats(qcx_register *r, unsigned long *expanding_stores)
+{
+    if (!r || !expanding_stores) return QCX_BAD_ARGUMENTS;
+    *expanding_stores = (!r->sh && r->queue) ? r->queue->expanding_stores : 0;
     return QCX_NO_ERROR;
 }
 
@@ -1537,6 +1560,7 @@ extern "C" int qcx_measure_state_r(qcx_register *r, double rnd, unsigned long *s
     if (r->sh) return sh_measure(r->sh, rnd, state_num);
     QCX_TRY(fuse_flush(r, true));                                           // (a compact chain's result may stay compact)
     int found = 0; uint64_t idx = 0; double cum = 0.0;
+    if (r->compact_pending == 2) QCX_TRY(compact_finish_last(r, false));   // (the chain's deferred last pass, as an ordinary pass: the scan wants the compact form)
     if (r->compact_pending) {
         // The scan of Q:283-292 on the compact form: the amplitudes it leaves out are +0 and add exactly nothing to the running
         // sum, and the compact order IS the index order (orbit ascending), so the first compact element with cum >= r is the

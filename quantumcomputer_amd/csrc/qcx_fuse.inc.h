@@ -84,9 +84,21 @@ struct GateQueue {
     size_t   d_cap = 0;
     FuseOp  *h_ops = nullptr;       // pinned staging
     size_t   h_cap = 0;
-    unsigned long passes_launched = 0, gates_fused = 0, chained_passes = 0, gen_fronts = 0, gen_cols = 0, compact_chains = 0;
+    unsigned long passes_launched = 0, gates_fused = 0, chained_passes = 0, gen_fronts = 0, gen_cols = 0, compact_chains = 0, expanding_stores = 0;
     hipEvent_t ev;                  // recorded after the last kernel of a flush: guards the record buffers
     bool     ev_valid = false;
+    // the LAST pass of a compact chain that was asked to stay compact (qcx_register::compact_pending == 2): not launched yet.
+    // It runs when somebody looks -- as an ordinary pass when that is measure_state (which scans the compact form), with the
+    // expanding store (FusePass::xp_on: straight into the register, no k_expand_compact) for everybody else -- or never, when
+    // a reset comes first.  Its records stay in d_ops: nothing uploads before the pending state is resolved (fuse_flush).
+    struct {
+        FusePass P, Pxp;            // as planned / with the expanding store
+        size_t   op_off = 0;
+        bool     nopipe = false;
+        amp_t   *in = nullptr, *out = nullptr;      // compact buffers: the pass reads in, an ordinary launch writes out (== in: in place)
+        unsigned nv = 0, cb = 0, ngates = 0;
+        Tune     tn;                // the knobs the plan was made under
+    } last;
 };
 
 static void queue_free(GateQueue *gq)
@@ -641,13 +653,22 @@ static bool launch_rounds_kernel(int occ, int tol_occ, unsigned grid, size_t lds
 
 static bool pass_tables_cover(const FusePass &P, unsigned n);
 
+// does launch_pass hand this pass to k_fused_x8<512, 12> (exact walk on 8 amplitudes, or its tolerance round)?  The only kernel
+// with the expanding store of a compact chain's last pass.
+static bool pass_is_x8(const FusePass &P, const Tune &tn)
+{
+    if (P.T != 12 || P.gen || P.has_cam || P.zskip || !tn.fuse_ldsdma) return false;
+    return P.dg_slim == 3 || (P.dg_slim == 2 && P.dg_cnt && tn.fuse_x8t);
+}
+
 // amp_in / amp_out: the buffer the pass reads / writes (the same for a pass that works in place; a chained pass goes from one of
 // the register's two buffers to the other)
 static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, const FuseOp *d_ops, bool nopipe, amp_t *amp_in, amp_t *amp_out)
 {
     (void)nopipe;
     FusePass P = P_in;
-    if ((P.chained != 0) != (amp_in != amp_out)) { set_error("fused pass: chained flag and buffers disagree"); return QCX_UNKNOWN_ERROR; }
+    if (!P.xp_on && (P.chained != 0) != (amp_in != amp_out)) { set_error("fused pass: chained flag and buffers disagree"); return QCX_UNKNOWN_ERROR; }
+    if (P.xp_on && !pass_is_x8(P, tn)) { set_error("expanding store on a pass that is not a k_fused_x8 pass"); return QCX_UNKNOWN_ERROR; }
     const unsigned n = r->n;
     if (!pass_tables_cover(P, n)) { set_error("fused pass: the addressing tables do not cover the %u tile-number bits", n - P.T); return QCX_UNKNOWN_ERROR; }
     const uint64_t ntiles = (uint64_t)1 << (n - P.T);
@@ -1470,9 +1491,40 @@ static bool compact_orbit(const BasisFront &B, unsigned M, std::vector<uint16_t>
     return true;
 }
 
+// the deferred last pass of a compact chain (compact_pending == 2, GateQueue::last): into_register: with the expanding store,
+// the state is then in r->amp (compact_pending = 0); otherwise as planned, the compact form is complete (compact_pending = 1)
+static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, const FuseOp *d_ops, bool nopipe, amp_t *amp_in, amp_t *amp_out);
+static int compact_finish_last(qcx_register *r, bool into_register)
+{
+    if (r->compact_pending != 2) return QCX_NO_ERROR;
+    GateQueue *gq = r->queue;
+    if (!gq) return QCX_UNKNOWN_ERROR;
+    qcx_register v;
+    memset(&v, 0, sizeof v);
+    v.L = (int)(gq->last.nv - gq->last.cb); v.M = (int)gq->last.cb; v.n = gq->last.nv; v.dim = (uint64_t)1 << gq->last.nv;
+    v.amp = gq->last.in; v.scratch = gq->last.out;
+    v.own_stream = r->own_stream; v.stream = r->stream; v.fusion = r->fusion;
+    if (into_register) {
+        QCX_TRY(launch_pass(&v, gq->last.tn, gq->last.Pxp, gq->d_ops + gq->last.op_off, gq->last.nopipe, gq->last.in, r->amp));
+        r->compact_pending = 0;
+        gq->expanding_stores++;
+    } else {
+        QCX_TRY(launch_pass(&v, gq->last.tn, gq->last.P, gq->d_ops + gq->last.op_off, gq->last.nopipe, gq->last.in, gq->last.out));
+        r->compact_amp = gq->last.out;
+        r->compact_pending = 1;
+    }
+    if (gq->last.P.chained) gq->chained_passes++;
+    gq->passes_launched++;
+    gq->gates_fused += gq->last.ngates;
+    if (!gq->ev_valid) { HIP_TRY(hipEventCreateWithFlags(&gq->ev, hipEventDisableTiming)); gq->ev_valid = true; }
+    HIP_TRY(hipEventRecord(gq->ev, r->stream));            // (the record buffers are in use until this pass is through)
+    return QCX_NO_ERROR;
+}
+
 // the real register from a pending compact form
 static int expand_pending(qcx_register *r)
 {
+    if (r->compact_pending == 2) QCX_TRY(compact_finish_last(r, true));
     if (!r->compact_pending) return QCX_NO_ERROR;
     ExpandParams E;
     memset(&E, 0, sizeof E);
@@ -1577,10 +1629,41 @@ static int compact_chain(qcx_register *r, GateQueue *gq, const Tune &tn, const B
         acts[0].P.zskip = 0;
         acts[0].P.gen_rec_off = (uint32_t)(at - acts[0].op_off);
     }
+    // Round 5: when the chain's last pass is a k_fused_x8 pass whose tile holds the column bits, that pass can store the REAL
+    // register itself (FusePass::xp_on) -- k_expand_compact's extra read and write of the compact form (8.6 of its 21.5 GB at
+    // n = 30, M = 5) disappear.  keep = false: it does.  keep = true (a whole-circuit entry point: measure_state may come next and
+    // wants the compact form): the last pass is DEFERRED (GateQueue::last, compact_pending = 2) until somebody looks.
+    // (The last pass of a plan always stores the identity layout.)
+    bool expanded = false, deferred = false;
+    if (tn.fuse_expand_fused && acts.size() > 1 && acts.back().fused && pass_is_x8(acts.back().P, tn) && M <= 9 && cb <= 4) {
+        FusePass PL = acts.back().P;
+        bool ok = true;
+        for (unsigned j = 0; j < cb; j++) if (PL.st_pos[j] != j) ok = false;
+        if (ok) {
+            PL.xp_on = 1; PL.xp_M = (uint8_t)M; PL.xp_cb = (uint8_t)cb; PL.xp_ncols = (uint8_t)orbit.size();
+            for (size_t j = 0; j < orbit.size(); j++) PL.xp_orbit[j] = orbit[j];
+            for (unsigned j = 0; j < cb; j++) PL.xp_colloc[j] = PL.st_loc[j];
+            for (unsigned i = M; i < M + PL.T - cb; i++) { PL.xp_pos[i] = (uint8_t)(PL.st_pos[cb + i - M] - cb + M); PL.xp_loc[i] = PL.st_loc[cb + i - M]; }
+            if (keep) {
+                deferred = true;
+                gq->last.P = acts.back().P; gq->last.Pxp = PL;
+                gq->last.op_off = acts.back().op_off; gq->last.nopipe = acts.back().nopipe != 0; gq->last.ngates = acts.back().ngates;
+                gq->last.nv = nv; gq->last.cb = cb; gq->last.tn = tn;
+            } else { acts.back().P = PL; expanded = true; }
+        }
+    }
     QCX_TRY(upload_ops(r, gq, all_ops));
-    for (const FuseAction &act : acts) {
+    for (size_t ai = 0; ai < acts.size(); ai++) {
+        const FuseAction &act = acts[ai];
         if (!act.fused) { QCX_TRY(launch_standalone(&v, vg[act.gate])); continue; }
-        if (act.P.chained) {
+        if (deferred && ai + 1 == acts.size()) {
+            gq->last.in = v.amp; gq->last.out = act.P.chained ? v.scratch : v.amp;
+            break;
+        }
+        if (act.P.xp_on) {
+            QCX_TRY(launch_pass(&v, tn, act.P, gq->d_ops + act.op_off, act.nopipe != 0, v.amp, r->amp));
+            if (act.P.chained) gq->chained_passes++;
+        } else if (act.P.chained) {
             QCX_TRY(launch_pass(&v, tn, act.P, gq->d_ops + act.op_off, act.nopipe != 0, v.amp, v.scratch));
             std::swap(v.amp, v.scratch);
             gq->chained_passes++;
@@ -1589,10 +1672,13 @@ static int compact_chain(qcx_register *r, GateQueue *gq, const Tune &tn, const B
         gq->passes_launched++;
         gq->gates_fused += act.ngates;
     }
-    r->compact_pending = 1;
-    r->compact_amp = v.amp; r->compact_cb = cb; r->compact_ncols = (unsigned)orbit.size();
-    for (size_t j = 0; j < orbit.size(); j++) r->compact_orbit[j] = orbit[j];
-    if (!keep) QCX_TRY(expand_pending(r));
+    if (expanded) { r->compact_pending = 0; gq->expanding_stores++; }
+    else {
+        r->compact_pending = deferred ? 2 : 1;
+        r->compact_amp = v.amp; r->compact_cb = cb; r->compact_ncols = (unsigned)orbit.size();
+        for (size_t j = 0; j < orbit.size(); j++) r->compact_orbit[j] = orbit[j];
+        if (!keep) QCX_TRY(expand_pending(r));
+    }
     r->basis_pending = 0;
     r->zeros_dirty = 0;
     r->fronts++;

@@ -308,6 +308,12 @@ __global__ __launch_bounds__(BLOCK) void k_camodc(amp_t *__restrict__ amp, Camod
     }
 }
 
+// (Round 5 tried the permutation case WITHOUT the LDS tile for blocks that fit a wave (M <= 6): lane l loads its amplitude, the
+// destination lanes fetch theirs by shuffle, four tiles of 64 amplitudes per wave in flight, no barrier.  Slower: 2.52 ms per gate
+// at n = 30 against 2.33 for k_camodc (2.42 when it writes whole lines with nontemporal traffic); the counters of k_camodc --
+// 71 % of wave cycles waiting, traffic exactly the touched lines -- and this experiment say the same thing: the gate is bound by
+// the memory side's handling of 3-lines-in-4 read-modify-write traffic, not by the workgroups' load -> barrier -> store chains.
+// profiles/r05g_camodc_*.json, profiles/r05_camodc_wave_experiment.txt.  Removed again.)
 // generic table form (C > 2^M, or 32-bit wrap in A*f): CSR of sources per
 // destination low-bits value, built on the host exactly as Q:619-647 maps them.
 template <int BLOCK>
@@ -487,6 +493,9 @@ __global__ __launch_bounds__(64) void k_measure_scan(const amp_t *__restrict__ a
 // ---------------------------------------------------------------------------
 // amplitudes per record = 2^blog, a launch parameter (8..11; host: meas_block_log): small registers want small records
 enum : uint32_t { MEAS_ALLZERO = 1u << 16, MEAS_TIE = 1u << 17, MEAS_BIG = 1u << 18, MEAS_EUNK = 1u << 19 };
+// MEAS_RHIT (round 5): the APPROXIMATE running sum reaches r inside this record (with a margin) -- a hint for k_meas_fast's
+// list of records to look at closely; it decides nothing
+enum : uint32_t { MEAS_RHIT = 1u << 20 };
 
 struct MeasBlock {
     uint64_t S;        // integer increment of the block in units of the assumed ulp (saturated)
@@ -514,7 +523,10 @@ __device__ __forceinline__ double prob_of(amp_t v) { return v.x * v.x + v.y * v.
 //                       run; the walk below validates every guess against the exact running sum, so the measured index
 //                       never depends on it;
 //   2. k_meas_groups    sums of 64, 64^2, ... consecutive records (a few tiny launches);
-//   3. k_meas_walk      one wave descends that tree with the EXACT running sum: 64 entries per step, whole groups at a
+//   3. k_meas_fast      (round 5, further down) the EVENTS of the scan from a list of candidate records the groups launch wrote:
+//                       8 waves, stretch sums and record data prepared in parallel, ~1 us of serial work per event;
+//   4. k_meas_walk      the fallback behind it, and the whole of step 3 in round 4:
+//                       one wave descends that tree with the EXACT running sum: 64 entries per step, whole groups at a
 //                       time while they are plain (integer additions inside one binade are associative); only a record with
 //                       a tie, an oversized element, a wrong guess, a binade crossing or the crossing of r is redone: as one
 //                       integer addition per 1024 amplitudes where that holds, per 64 below that, and the strictly
@@ -577,7 +589,7 @@ __device__ __forceinline__ int meas_window(unsigned lane, unsigned lanes, meas_s
 
 template <int RLOG>
 __global__ __launch_bounds__(256) void k_meas_onepass(const amp_t *__restrict__ amp, uint64_t count, double cum_in,
-                                                       MeasLookback LB, MeasBlock *out, unsigned spin_limit, unsigned dbg)
+                                                       MeasLookback LB, MeasBlock *out, unsigned spin_limit, unsigned dbg, double r)
 {
     constexpr unsigned PER = (1u << RLOG) / 64u;            // amplitudes per lane: 4 .. 32
     __shared__ unsigned s_blk;
@@ -676,6 +688,7 @@ __global__ __launch_bounds__(256) void k_meas_onepass(const amp_t *__restrict__ 
     const int e = (int)(((uint64_t)__double_as_longlong(pref) >> 52) & 0x7ff);
     uint64_t S = 0;
     uint32_t flags = (e == 0 || e == 0x7ff) ? (uint32_t)MEAS_EUNK : 0u;
+    if (pref <= r * (1.0 + 1e-9) && pref + red[wave] >= r * (1.0 - 1e-9)) flags |= (uint32_t)MEAS_RHIT;
     bool nonzero = false;
     const uint64_t SAT = (uint64_t)1 << 54;
 #pragma unroll
@@ -703,12 +716,33 @@ __global__ __launch_bounds__(256) void k_meas_onepass(const amp_t *__restrict__ 
 
 // one level up: record g = 64 consecutive records of the level below (one wave each).  A group is PLAIN when all its
 // non-zero members are unflagged and were computed under the same binade; anything else sets MEAS_EUNK = "descend".
-__global__ __launch_bounds__(64) void k_meas_groups(const MeasBlock *__restrict__ in, unsigned nin, MeasBlock *__restrict__ outg)
+// cands (the launch over the records themselves only): the records k_meas_fast has to look at closely -- flagged ones, and both
+// sides of every change of the binade guess (a crossing lies in one of the two)
+#define QCX_MEAS_CAND_CAP 192u
+struct MeasCands { unsigned count, pad; unsigned list[QCX_MEAS_CAND_CAP]; };
+
+__global__ __launch_bounds__(64) void k_meas_groups(const MeasBlock *__restrict__ in, unsigned nin, MeasBlock *__restrict__ outg, MeasCands *cands)
 {
     const unsigned lane = threadIdx.x, i = blockIdx.x * 64u + lane;
     MeasBlock m; m.S = 0; m.meta = MEAS_ALLZERO; m.pad = 0;
     if (i < nin) m = in[i];
     const bool zero = (m.meta & MEAS_ALLZERO) != 0;
+    if (cands) {
+        const int e_me = (int)(m.meta & 0x7ffu);
+        int e_next = __shfl_down(e_me, 1, 64), e_prev = __shfl_up(e_me, 1, 64);
+        if (lane == 63u && i + 1u < nin) e_next = (int)(in[i + 1u].meta & 0x7ffu);
+        if (lane == 0u) e_prev = i > 0u ? (int)(in[i - 1u].meta & 0x7ffu) : e_me;
+        if (i + 1u >= nin) e_next = e_me;
+        const bool c = i < nin && ((!zero && (m.meta & (MEAS_TIE | MEAS_BIG | MEAS_EUNK | MEAS_RHIT))) || e_next != e_me || e_prev != e_me);
+        const unsigned long long cm = __ballot(c);
+        if (cm) {
+            unsigned base = 0;
+            if (lane == 0u) base = atomicAdd(&cands->count, (unsigned)__builtin_popcountll(cm));
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            const unsigned slot = base + (unsigned)__builtin_popcountll(cm & (((unsigned long long)1 << lane) - 1ULL));
+            if (c && slot < QCX_MEAS_CAND_CAP) cands->list[slot] = i;
+        }
+    }
     const unsigned long long nz = __ballot(!zero);
     MeasBlock g; g.S = 0; g.meta = MEAS_ALLZERO; g.pad = 0;
     if (nz) {
@@ -836,18 +870,26 @@ struct MeasLevels {
 // (Round 5 staged the upper levels of the tree in LDS for the walk: no change, 3.71 against 3.72 ms on a dense n = 30 state --
 // the ~30 us per event are spent in the exact rescans of the record the event lies in and in the steps' arithmetic on ONE wave,
 // not in the latency of the level reads.  Not kept.)
+// resume: what k_meas_fast (below) left -- nothing to do (state 0), or "go on at record b with the exact running sum cum"; nullptr:
+// the whole scan is this kernel's
+struct MeasResume { uint32_t state, slow; uint64_t b; double cum; };
+
 __global__ __launch_bounds__(64) void k_meas_walk(const amp_t *__restrict__ amp, uint64_t count, MeasLevels T,
-                                                  double cum_in, double r, MeasureOut *out, unsigned *stats, unsigned rlog)
+                                                  double cum_in, double r, MeasureOut *out, unsigned *stats, unsigned rlog, const MeasResume *resume)
 {
     const unsigned lane = threadIdx.x;
     const unsigned n0 = T.n[0];
     double cum = cum_in;
     unsigned slow = 0;
     uint64_t b = 0;                                   // next record
+    if (resume) {
+        if (resume->state == 0u) return;
+        b = resume->b; cum = resume->cum; slow = resume->slow;
+    }
     int cap = T.top;                                  // highest level the next step may use
     uint64_t hi = 0; double hc = 0.0;
     // r already reached before the first addition (Q:289 with cum_0 >= cum_in): the first examined element is the answer
-    if (cum_in >= r) {
+    if (b == 0 && cum_in >= r) {
         const uint64_t len = min((uint64_t)1 << rlog, count);
         slow++;
         if (wave_exact_block(amp, 0, len, cum, r, &hi, &hc)) {
@@ -904,6 +946,254 @@ __global__ __launch_bounds__(64) void k_meas_walk(const amp_t *__restrict__ amp,
         cap = T.top;
     }
     if (lane == 0) { out->found = 0; out->index = 0; out->cum = cum; if (stats) { stats[0] = slow; stats[1] = n0; } }
+}
+
+// ---------------------------------------------------------------------------
+// K4c, step 3a (round 5): the events of the scan WITHOUT the one-wave tree walk.  On a dense state the walk above spends ~34 us per
+// record it has to redo (a binade crossing every time the running sum doubles: 32 of them at n = 30, 1.1 ms next to a 2.8 ms read)
+// -- the descent to the record and back up, a dependent load per level, and the redo itself, all on one wave.  But WHERE the
+// events are is known beforehand from the approximate prefixes: k_meas_groups lists the flagged records and both sides of
+// every change of the binade guess (MeasCands).  One workgroup of 8 waves takes the list in index order, candidate k on wave
+// k mod 8, in two phases:
+//   parallel (no dependence on the running sum): the integer sum of the stretch of plain records between candidate k-1 and
+//     candidate k -- straight from the tree: at most 63 entries at either end per level, every address known up front, all
+//     loads in flight together -- and the candidate's own amplitudes: lane l keeps 2^rlog / 64 CONSECUTIVE probabilities in
+//     registers, with their integer increments under the stretch's binade and the next one;
+//   serial (wave k waits for wave k-1's exact running sum in LDS): validate the stretch against it (same binade, no overflow,
+//     below r), then the record: a prefix scan of the lanes' increments finds the first lane in which something happens
+//     (crossing, tie, oversized element, r); THAT lane adds its few probabilities one by one -- the reference's own
+//     additions, no shuffles -- and the lanes behind it go on under the binade it ended in.  About a microsecond.
+// Every decision is validated against the exact running sum exactly as in the walk, so the index is the reference's for any
+// input; whatever does not go as the list predicts (a stretch that fails, more than QCX_MEAS_CAND_CAP candidates, r reached
+// before the first addition) is handed to k_meas_walk with the exact state (MeasResume) -- slower, same result.
+// ---------------------------------------------------------------------------
+struct MeasStretch { uint64_t tot; int es; bool ok; };          // es = -1: nothing but zeros
+
+__device__ __forceinline__ void meas_stretch_take(const MeasBlock &m, bool valid, MeasStretch &st)
+{
+    const bool zero = !valid || (m.meta & MEAS_ALLZERO) != 0;
+    const unsigned long long nz = __ballot(!zero);
+    if (!nz) return;
+    if (st.es < 0) st.es = __builtin_amdgcn_readlane((int)(m.meta & 0x7ffu), __builtin_ctzll(nz));
+    const bool bad = !zero && ((m.meta & (MEAS_TIE | MEAS_BIG | MEAS_EUNK)) || (int)(m.meta & 0x7ffu) != st.es);
+    if (__ballot(bad)) st.ok = false;
+    unsigned long long t = zero ? 0ULL : (unsigned long long)m.S;                  // <= 2^54 each
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+    st.tot += readlane_u64(t, 0);                                                  // <= 10 x 64 entries: no overflow
+}
+
+// the records [a, b) as ONE integer addition, from the tree (every load issued before the first is used)
+__device__ __forceinline__ MeasStretch meas_stretch(const MeasLevels &T, uint64_t a, uint64_t b)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    MeasBlock mL[5], mR[5];
+    bool vL[5], vR[5];
+    uint64_t ua = a, ub = b;
+#pragma unroll
+    for (int L = 0; L < 5; L++) {
+        vL[L] = vR[L] = false;
+        mL[L].S = mR[L].S = 0; mL[L].meta = mR[L].meta = MEAS_ALLZERO; mL[L].pad = mR[L].pad = 0;
+        if (L > T.top || ua >= ub) continue;
+        if (L == T.top) {                               // (at most 64 entries up here)
+            vL[L] = lane < ub - ua;
+            if (vL[L]) mL[L] = T.lv[L][ua + lane];
+            ua = ub;
+            continue;
+        }
+        const uint64_t lb = min(ub, (ua + 63u) & ~(uint64_t)63);          // up to the next group boundary
+        vL[L] = lane < lb - ua;
+        if (vL[L]) mL[L] = T.lv[L][ua + lane];
+        if (lb < ub) {
+            const uint64_t ra = ub & ~(uint64_t)63;                         // >= lb: the whole groups in between belong to the level above
+            vR[L] = lane < ub - ra;
+            if (vR[L]) mR[L] = T.lv[L][ra + lane];
+            ua = lb >> 6; ub = ra >> 6;
+        } else ua = ub;
+    }
+    MeasStretch st; st.tot = 0; st.es = -1; st.ok = true;
+#pragma unroll
+    for (int L = 0; L < 5; L++) { meas_stretch_take(mL[L], vL[L], st); meas_stretch_take(mR[L], vR[L], st); }
+    return st;
+}
+
+// this lane's `per` consecutive probabilities as one integer increment under binade e (saturated), and their flags
+__device__ __forceinline__ void meas_lane_inc(const double (&p)[32], unsigned per, int e, uint64_t &S, uint32_t &fl)
+{
+    S = 0; fl = 0;
+#pragma unroll
+    for (unsigned j = 0; j < 32; j++) {
+        if (j < per) {
+            const uint64_t pb = (uint64_t)__double_as_longlong(p[j]);
+            uint32_t f1 = 0;
+            const uint64_t i1 = meas_inc(pb, e, f1);
+            S += pb ? i1 : 0; fl |= pb ? f1 : 0u;
+        }
+    }
+    if (S > ((uint64_t)1 << 54)) S = (uint64_t)1 << 54;
+}
+
+// one record, exactly, from the exact running sum cum (< r on entry).  true: r was reached at *hit_index; false: cum = the running sum behind it
+__device__ __forceinline__ bool meas_record_exact(const double (&p)[32], unsigned per, uint64_t first, double &cum, double r,
+                                                  int eA, uint64_t SA, uint32_t flA, int eB, uint64_t SB, uint32_t flB,
+                                                  uint64_t *hit_index, double *hit_cum)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    unsigned done = 0;                                   // lanes [0, done) are behind us
+    while (done < 64u) {
+        const uint64_t cb = (uint64_t)__double_as_longlong(cum);
+        const int ec = (int)((cb >> 52) & 0x7ff);
+        const bool ecok = ec != 0 && ec != 0x7ff;
+        uint64_t S = 0; uint32_t fl = MEAS_EUNK;
+        if (ecok) {
+            if (ec == eA) { S = SA; fl = flA; }
+            else if (ec == eB) { S = SB; fl = flB; }
+            else meas_lane_inc(p, per, ec, S, fl);
+        }
+        const bool in = lane >= done;
+        unsigned long long inc = in ? (unsigned long long)S : 0ULL;           // <= 2^54 each: no overflow over 64 lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long up = __shfl_up(inc, o, 64);
+            if ((int)lane >= o) inc += up;
+        }
+        const unsigned long long flagged = __ballot(in && fl != 0u);
+        const unsigned firstfl = flagged ? (unsigned)__builtin_ctzll(flagged) : 64u;
+        const uint64_t Kn = ((cb & 0xfffffffffffffULL) | ((uint64_t)1 << 52)) + inc;
+        bool ok = in && ecok && lane < firstfl && Kn < ((uint64_t)1 << 53);
+        double cn = cum;
+        if (ok) { cn = __longlong_as_double((long long)(((uint64_t)ec << 52) | (Kn & 0xfffffffffffffULL))); ok = !(cn >= r); }
+        const unsigned long long bad = ~__ballot(ok) & ~(done ? (((unsigned long long)1 << done) - 1ULL) : 0ULL);
+        const unsigned L = bad ? (unsigned)__builtin_ctzll(bad) : 64u;       // monotone sums: a good lane validates all before it
+        if (L > done) cum = readlane_f64(cn, (int)L - 1);
+        if (L >= 64u) break;
+        // lane L: the reference's own additions, one by one (every lane runs them on its own numbers; lane L's count)
+        double run = cum, hc = 0.0;
+        int hj = -1;
+#pragma unroll
+        for (unsigned j = 0; j < 32; j++) {
+            if (j < per) {
+                run = run + p[j];
+                if (hj < 0 && run >= r) { hj = (int)j; hc = run; }
+            }
+        }
+        const int hjL = __builtin_amdgcn_readlane(hj, (int)L);
+        if (hjL >= 0) {
+            *hit_index = first + (uint64_t)L * per + (uint64_t)hjL;
+            *hit_cum = readlane_f64(hc, (int)L);
+            return true;
+        }
+        cum = readlane_f64(run, (int)L);
+        done = L + 1u;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(512) void k_meas_fast(const amp_t *__restrict__ amp, uint64_t count, MeasLevels T, double cum_in, double r,
+                                                   MeasureOut *out, unsigned *stats, unsigned rlog, const MeasCands *cands,
+                                                   MeasResume *resume, unsigned dbg)
+{
+    __shared__ unsigned s_raw[QCX_MEAS_CAND_CAP], s_sorted[QCX_MEAS_CAND_CAP + 1];
+    __shared__ unsigned long long s_cum[QCX_MEAS_CAND_CAP + 1];
+    __shared__ unsigned s_flag[QCX_MEAS_CAND_CAP + 1];
+    __shared__ unsigned s_stop;
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const unsigned n0 = T.n[0], ncand = cands->count;
+    if (ncand > QCX_MEAS_CAND_CAP || cum_in >= r) {                 // (uniform) not this kernel's case: the walk takes everything
+        if (threadIdx.x == 0) { resume->state = 1u; resume->slow = 0u; resume->b = 0; resume->cum = cum_in; }
+        return;
+    }
+    for (unsigned t = threadIdx.x; t < ncand; t += blockDim.x) s_raw[t] = cands->list[t];
+    for (unsigned t = threadIdx.x; t <= ncand; t += blockDim.x) s_flag[t] = 0u;
+    if (threadIdx.x == 0) s_stop = 0u;
+    __syncthreads();
+    for (unsigned t = threadIdx.x; t < ncand; t += blockDim.x) {   // rank sort (distinct values)
+        const unsigned v = s_raw[t];
+        unsigned rank = 0;
+        for (unsigned j = 0; j < ncand; j++) rank += s_raw[j] < v ? 1u : 0u;
+        s_sorted[rank] = v;
+    }
+    __syncthreads();
+    const unsigned per = (1u << rlog) >> 6;                           // 4 .. 32 probabilities per lane
+    // (no workgroup barrier below: waves leave at different times)
+    for (unsigned k = wave; k <= ncand; k += nwaves) {                // k = ncand: the stretch behind the last candidate
+        const uint64_t a = k ? (uint64_t)s_sorted[k - 1u] + 1u : 0u;
+        const bool has_rec = k < ncand;
+        const uint64_t b = has_rec ? (uint64_t)s_sorted[k] : (uint64_t)n0;
+        // ---- parallel phase -------------------------------------------------------------------------------------------------
+        const MeasStretch st = meas_stretch(T, a, b);
+        double p[32];
+        const uint64_t first = b << rlog;
+        int eA = -1, eB = -1;
+        uint64_t SA = 0, SB = 0; uint32_t flA = 0, flB = 0;
+        if (has_rec) {
+#pragma unroll
+            for (unsigned j = 0; j < 32; j++) {
+                p[j] = 0.0;
+                if (j < per) { const uint64_t i = first + (uint64_t)lane * per + j; if (i < count) p[j] = prob_of(amp[i]); }
+            }
+            eA = st.es >= 0 ? st.es : (int)(T.lv[0][b].meta & 0x7ffu);     // the binade the record most likely starts in
+            if (eA > 0 && eA < 0x7fe) {
+                eB = eA + 1;
+                meas_lane_inc(p, per, eA, SA, flA);
+                meas_lane_inc(p, per, eB, SB, flB);
+            } else eA = -1;
+        } else {
+#pragma unroll
+            for (unsigned j = 0; j < 32; j++) p[j] = 0.0;
+        }
+        // ---- serial phase: the exact running sum behind candidate k - 1 ------------------------------------------------------
+        double cum = cum_in;
+        if (k) {
+            unsigned f = 0;
+            while (true) {
+                f = __hip_atomic_load(&s_flag[k - 1u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (f || __hip_atomic_load(&s_stop, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!f) return;                                           // somebody before us finished the scan (or handed it over)
+            cum = __longlong_as_double((long long)__hip_atomic_load(&s_cum[k - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        }
+        bool fail = (dbg & 2u) && k == 2u;                            // (diagnostics: hand over at the third candidate)
+        // the stretch [a, b): plain records under the binade of cum, no overflow, below r
+        if (!fail && st.es >= 0) {
+            const uint64_t cb = (uint64_t)__double_as_longlong(cum);
+            const int ec = (int)((cb >> 52) & 0x7ff);
+            const uint64_t Kn = ((cb & 0xfffffffffffffULL) | ((uint64_t)1 << 52)) + st.tot;
+            if (!st.ok || ec == 0 || ec == 0x7ff || ec != st.es || Kn >= ((uint64_t)1 << 53)) fail = true;
+            else {
+                const double cn = __longlong_as_double((long long)(((uint64_t)ec << 52) | (Kn & 0xfffffffffffffULL)));
+                if (cn >= r) fail = true; else cum = cn;
+            }
+        } else if (!fail && !st.ok) fail = true;
+        if (fail) {                                                   // the walk goes on from the start of the stretch
+            if (lane == 0) {
+                resume->state = 1u; resume->slow = k; resume->b = a; resume->cum = cum;
+                __hip_atomic_store(&s_stop, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            return;
+        }
+        if (has_rec) {
+            uint64_t hi = 0; double hc = 0.0;
+            if (meas_record_exact(p, per, first, cum, r, eA, SA, flA, eB, SB, flB, &hi, &hc)) {
+                if (lane == 0) {
+                    out->found = 1; out->index = hi; out->cum = hc;
+                    if (stats) { stats[0] = k + 1u; stats[1] = n0; }
+                    resume->state = 0u;
+                    __hip_atomic_store(&s_stop, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                return;
+            }
+            if (lane == 0) {
+                __hip_atomic_store(&s_cum[k], (unsigned long long)__double_as_longlong(cum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&s_flag[k], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        } else if (lane == 0) {                                       // the end of the records: r was never reached
+            out->found = 0; out->index = 0; out->cum = cum;
+            if (stats) { stats[0] = ncand; stats[1] = n0; }
+            resume->state = 0u;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -964,6 +1254,15 @@ struct FusePass {
     uint8_t  zskip, zb[3];
     uint32_t zpad;
     uint64_t zlist;             // the zb[] ascending, one per byte
+    // xp_on (round 5): the LAST pass of a compact chain stores the REAL register (k_fused_x8 only): its output index is the virtual
+    // register's [L-register bits][column], cb column bits; the amplitude of L-part l and column j belongs at real index
+    // (l << M) | orbit[j], every other amplitude of the 2^M-block is +0 -- the pass writes all 2^M of them, 2^(M - cb) times its
+    // tile, and k_expand_compact (one more read and write of the compact form) does not run.  The expanded store order: bits
+    // 0 .. M-1 of a store index = the M-register value f, the bits above = the tile's store-order bits cb .. T-1;
+    // xp_pos[i] / xp_loc[i] (i >= M) = REAL index bit / tile-local bit of store-index bit i; xp_colloc[b] = tile-local bit of column bit b
+    uint8_t  xp_on, xp_M, xp_cb, xp_ncols;
+    uint8_t  xp_pos[24], xp_loc[24], xp_colloc[4];
+    uint16_t xp_orbit[16];
 };
 
 // The circuit front on a basis state (K0b, BasisFront below) evaluated per TILE of the first pass behind it (round 4): the
@@ -2844,6 +3143,23 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     const uint32_t tile_lds = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) amp_t *)tile;
     const uint32_t xm_lds = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint64_t *)xm;
     const uint32_t dg_lds = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) amp_t *)dg;
+    // the expanding store of a compact chain's last pass (FusePass::xp_on): this thread's share of an expanded store index --
+    // its M-register value f (BLOCK >= 2^M: the same in every store), hence its column, and the thread bits above f
+    uint64_t xp_off_t = 0;
+    unsigned xp_slot_t = 0;
+    bool xp_live = false;
+    if (!GEN && P.xp_on) {
+        const unsigned M = P.xp_M, f = threadIdx.x & ((1u << M) - 1u);
+        unsigned col = 0xffu;
+        for (unsigned j = 0; j < P.xp_ncols; j++) if (P.xp_orbit[j] == f) col = j;
+        xp_live = col != 0xffu;
+        unsigned loc = 0;
+        if (xp_live) for (unsigned b = 0; b < P.xp_cb; b++) loc |= ((col >> b) & 1u) << P.xp_colloc[b];
+        xp_off_t = f;
+        for (unsigned i = M; (1u << i) < (unsigned)BLOCK; i++)
+            if ((threadIdx.x >> i) & 1u) { xp_off_t |= (uint64_t)1 << P.xp_pos[i]; loc |= 1u << P.xp_loc[i]; }
+        xp_slot_t = x8_swz(loc);
+    }
     // GEN: the tiles are generated (the circuit front on a basis state that was never written, GenFront), not read: slot s holds
     // element x8_swz(s), and the per-element words of the generated fill are linear over XOR like everything else here
     const GenFront *GF = reinterpret_cast<const GenFront *>(ops + P.gen_rec_off);
@@ -2930,6 +3246,33 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         }
         amp_t v[8];
         const double sc = (TOL && !(P.dbg & 1u)) ? P.tol_scale : 1.0;        // tolerance mode: the Hadamards' 1/sqrt 2, once per pass
+        if (!GEN && P.xp_on) {
+            // the real register from the compact tile: 2^(T - cb + M) amplitudes, store index e = it * BLOCK + thread; consecutive
+            // threads write consecutive amplitudes (whole 2^M-blocks, runs of 2^(M + c - cb) of them), the threads whose f is on
+            // the orbit fetch theirs from the tile, all others write +0
+            constexpr unsigned LB = TT - 3u;                                 // log2 BLOCK
+            const unsigned ebits = (unsigned)TT - P.xp_cb + P.xp_M, nit = 1u << (ebits - LB);
+            amp_t *gx = amp_out + (((base_out >> P.xp_cb) << P.xp_M) | xp_off_t);
+            for (unsigned it0 = 0; it0 < nit; it0 += 8) {
+                uint64_t oi[8];
+#pragma unroll
+                for (unsigned k = 0; k < 8; k++) {
+                    const unsigned it = it0 + k;
+                    uint64_t off = 0; unsigned loc = 0;
+                    for (unsigned b = 0; b < ebits - LB; b++)
+                        if ((it >> b) & 1u) { off |= (uint64_t)1 << P.xp_pos[LB + b]; loc |= 1u << P.xp_loc[LB + b]; }
+                    oi[k] = off;
+                    v[k].x = 0.0; v[k].y = 0.0;
+                    if (xp_live) { v[k] = tile[xp_slot_t ^ x8_swz(loc)]; if constexpr (TOL) { v[k].x *= sc; v[k].y *= sc; } }
+                }
+                if (!(P.dbg & 2u)) {
+#pragma unroll
+                    for (unsigned k = 0; k < 8; k++) if (it0 + k < nit) __builtin_nontemporal_store(v[k], gx + oi[k]);
+                }
+            }
+            __syncthreads();
+            continue;
+        }
 #pragma unroll
         for (unsigned k = 0; k < 8; k++) {
             v[k] = tile[ld_k[k] ^ ld_t];          // (store order: ascending OUTPUT positions; slots under the swizzle)

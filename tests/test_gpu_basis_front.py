@@ -262,6 +262,72 @@ def test_measurement_on_the_compact_form(qc, ob, C, L, M, a, mode):
         qc.tune(**old)
 
 
+def _expanding(qc, reg):
+    import ctypes as C
+    out = C.c_ulong(0)
+    qc.lib().qcx_expanding_store_stats(reg._h, C.byref(out))
+    return out.value
+
+
+@pytest.mark.parametrize("mode", [0, 2], ids=["exact", "tolerance"])
+@pytest.mark.parametrize("C,L,M,a", [(21, 16, 5, 2), (21, 19, 5, 2), (15, 16, 4, 7), (35, 17, 6, 2), (255, 15, 8, 2), (32, 15, 5, 31), (21, 15, 5, 16)])
+def test_last_pass_of_a_compact_chain_stores_the_real_register(qc, ob, C, L, M, a, mode):
+    """round 5: when the state is wanted in the register, the last pass of a compact chain (a k_fused_x8 pass) writes the real
+    register itself -- (l << M) | orbit[j] for column j, +0 everywhere else -- and k_expand_compact does not run.  Same bits as
+    with the separate expansion (fuse_expand_fused = 0) and as the oracle, from a reset state and from a measured basis state."""
+    n = L + M
+    old = qc.lib().qcx_tune_get(b"fuse_expand_fused")
+    want = np.zeros(2 << n); ob.reset(want, n); ob.quantum_computation(want, n, M, C, a, threads=8)
+    # does the chain's last pass qualify?  The planner alone, as compact_chain calls it (mode | 8), on the virtual register
+    # [L register][orbit column]: a k_fused_x8 pass (records FUSE_ROUND8 = 9 / FUSE_QROUND3 = 8 on a 2^12 tile) holding the column bits
+    orbit = sorted({pow(a, e, C) for e in range(4 * C)})
+    cb = max(2, (len(orbit) - 1).bit_length())
+    nv = L + cb
+    descs = []
+    for l in range(nv - 1, cb - 1, -1):
+        descs.append((0, l, 0, 0.0, 0.0, 0, 0))
+        for k in range(l - 1, cb - 1, -1):
+            c_, s_ = qc.polar(math.pi / float(1 << (l - k)))
+            descs.append((1, 0, (1 << l) | (1 << k), c_, s_, 0, 0))
+    acts, recs, _ = qc.fusion_plan(nv, cb, descs, (2 if mode == 2 else 1) | 4 | 8)
+    last = acts[-1]
+    kinds = {recs[last.rec_off + k].type & 0xFF for k in range(last.nops)} if last.fused else set()
+    qualifies = int(len(acts) > 1 and last.fused and last.T == 12 and (9 in kinds or (8 in kinds and last.diag_cnt > 0)) and list(last.st_pos[:cb]) == list(range(cb)))
+    # (35, 17, 6): the plan ends in a stand-alone gate -- the separate expansion runs, also a case worth having
+    assert qualifies or mode == 2 or (C, L, M) == (35, 17, 6), "the exact chains of these sizes end in a k_fused_x8 pass"
+    try:
+        outs = []
+        for fused in (1, 0):
+            qc.tune(fuse_expand_fused=fused)
+            with qc.Register(L, M) as reg:
+                reg.set_fusion(mode)
+                reg.fill_random(3)                                   # stale amplitudes everywhere: every +0 must be written
+                e0, k0 = _expanding(qc, reg), _compact(qc, reg)
+                qc.reset_register(reg); qc.quantum_computation(C, a, reg)
+                first = reg.read()
+                assert _compact(qc, reg) - k0 == 1
+                assert _expanding(qc, reg) - e0 == fused * qualifies
+                idx = qc.measure_state(reg, 0.77)                    # collapse, then the Hadamard layer and the inverse QFT again: minus signs in the front
+                for l in range(M, n):
+                    qc.hadamard_gate(l, reg)
+                qc.inverse_QFT(reg)
+                second = reg.read()
+                outs.append((first, idx, second))
+        w = want.copy()
+        assert outs[0][1] == outs[1][1] and (mode != 0 or outs[0][1] == ob.measure(w, n, 0.77))
+        if mode == 0:
+            assert np.array_equal(bits(outs[0][0]), bits(want)) and np.array_equal(bits(outs[1][0]), bits(want))
+            for l in range(M, n):
+                ob.hadamard(w, n, l, 8)
+            ob.iqft(w, n, M, 8)
+            assert np.array_equal(bits(outs[0][2]), bits(w)) and np.array_equal(bits(outs[1][2]), bits(w))
+        else:
+            assert float(np.max(np.abs(outs[0][0] - want))) <= 1e-12 and float(np.max(np.abs(outs[1][0] - want))) <= 1e-12
+            assert float(np.max(np.abs(outs[0][2] - outs[1][2]))) <= 1e-12
+    finally:
+        qc.tune(fuse_expand_fused=old)
+
+
 @pytest.mark.parametrize("mode", [1, 2], ids=["exact (every gate queued)", "tolerance"])
 @pytest.mark.parametrize("seed", range(6))
 def test_compact_chain_under_random_programs(qc, ob, seed, mode):

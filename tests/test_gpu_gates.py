@@ -240,13 +240,14 @@ def test_bad_arguments(qc):
 @pytest.mark.parametrize("skip,ntl", [(0, 0), (1, 0), (1, 1), (0, 1)])
 def test_camodc_store_and_fill_variants(qc, ob, skip, ntl):
     """k_camodc with and without reading the lines above row C, with default and nontemporal stores of the completely
-    rewritten lines: the same bits (C just above / below line boundaries, non-coprime multipliers, controls inside and
-    above the tile)"""
+    rewritten lines: the same bits (C just above / below line boundaries, non-coprime multipliers, controls right above
+    the M register, inside and above the tile, every M from 3 to 7)"""
     old = {k: qc.lib().qcx_tune_get(k.encode()) for k in ("cam_skip", "cam_nt_lines")}
     qc.tune(cam_skip=skip, cam_nt_lines=ntl)
     try:
         for (L, M, C, atox, ctl) in [(11, 5, 21, 2, 9), (11, 5, 24, 5, 15), (10, 6, 33, 7, 6), (9, 5, 7, 3, 13), (12, 4, 15, 10, 5),
-                                     (8, 7, 100, 30, 14), (14, 5, 32, 3, 18), (14, 5, 17, 4, 12)]:
+                                     (8, 7, 100, 30, 14), (14, 5, 32, 3, 18), (14, 5, 17, 4, 12), (11, 5, 21, 16, 5), (12, 4, 15, 7, 4),
+                                     (12, 4, 13, 6, 5), (10, 6, 64, 5, 7), (10, 6, 61, 17, 15), (11, 3, 7, 3, 3), (9, 3, 8, 5, 11), (6, 3, 5, 2, 4)]:
             n = L + M
             a = ob.random_state(n, 600 + ctl)
             want = a.copy(); ob.camodc(want, n, M, C, atox, ctl)

@@ -120,6 +120,36 @@ def test_subnormal_start_and_spikes(qc, ob, force_parallel):
     check(qc, ob, n, a, [1e-322, 4e-320, 1e-300, 0.05, 0.5, 0.81, 1.2, 1.4, 5.0])
 
 
+@pytest.mark.parametrize("knobs", [dict(meas_fast=0), dict(meas_dbg=2), dict(meas_fast=1)], ids=["walk-alone", "hand-over", "fast"])
+@pytest.mark.parametrize("blog", [8, 11])
+def test_event_list_and_walk_agree_with_the_oracle(qc, ob, knobs, blog):
+    """k_meas_fast (the events of the scan from the candidate list), the tree walk alone, and the hand-over from one to the other
+    in the middle of a scan (meas_dbg bit 1: at the third candidate) all pick the reference's index"""
+    keys = ("meas_parallel", "meas_min_log2", "meas_block_log", "meas_fast", "meas_dbg")
+    old = {k: qc.lib().qcx_tune_get(k.encode()) for k in keys}
+    qc.tune(meas_parallel=1, meas_min_log2=10, meas_block_log=blog, **knobs)
+    try:
+        n = 17
+        rs = np.random.RandomState(blog)
+        a = ob.random_state(n, 77)
+        check(qc, ob, n, a, [0.0, 1.0, 0.5, 1e-9, 3e-6, 0.999999999] + list(rs.uniform(0, 1, 6)) + partial_sum_rs(a, rs, 4))
+        if knobs.get("meas_fast", 1) and not knobs.get("meas_dbg"):
+            slow, blocks = last_stats(qc)
+            assert blocks == (1 << n) >> blog and 0 < slow <= 80, (slow, blocks)
+        i = np.arange(1 << n, dtype=np.float64)
+        b = np.zeros(2 << n)
+        b[0::2] = 2.0 ** (-30 + i / 8192.0)                            # p doubles every 4096 elements: crossings inside records
+        tot = float(((b[0::2]) ** 2).sum())
+        check(qc, ob, n, b, [tot * f for f in (1e-12, 1e-6, 0.01, 0.3, 0.9, 0.999999, 1.0, 1.01)])
+        c = np.zeros(2 << n); c[2 * 70000] = 0.6; c[2 * 70000 + 1] = 0.8   # sparse: one amplitude far inside
+        check(qc, ob, n, c, [1e-300, 0.3, 1.0])
+        d = ob.random_state(n, 5)
+        d[0:64] = 1e-160; d[2 * 5000] = 0.9; d[2 * 90000 + 1] = -0.7      # subnormal start, spikes larger than the running sum
+        check(qc, ob, n, d, [1e-322, 4e-320, 0.05, 0.5, 0.81, 1.2, 1.4, 5.0])
+    finally:
+        qc.tune(**old)
+
+
 @pytest.mark.parametrize("n", [24, 27])
 def test_parallel_equals_sequential_scan_on_the_gpu(qc, n):
     """larger than the CPU comfortably checks: the single-wave sequential kernel is the arbiter"""

@@ -20,8 +20,8 @@ L, M = n - 5, 5
 with qc.Register(L, M) as reg:
     reg.set_fusion(-1)                          # eager collapse: the timed region holds the scan AND the collapse's memset
     for state in ("shor", "dense"):
-        for onepass, dbg in ((1, 0),):
-            qc.tune(meas_dbg=dbg)
+        for onepass, dbg in ((1, 0), (0, 0)):        # (the column says "onepass": it is meas_fast since round 5)
+            qc.tune(meas_dbg=dbg, meas_fast=onepass)
             for r in (0.3, 0.77, 0.999):
                 if state == "shor":
                     reg.set_fusion(0); qc.reset_register(reg); qc.quantum_computation(21, 2, reg); reg.set_fusion(-1)
@@ -35,5 +35,5 @@ with qc.Register(L, M) as reg:
                 reg.timer_start()
                 idx = qc.measure_state(reg, r)
                 t_meas = reg.timer_stop()
-                print(f"n={n} {state:5s} onepass={onepass} dbg={dbg} r={r}: index {idx}  scan-to-end {t_scan:7.3f} ms (slow/blocks {s_scan}, P={p!r})  "
+                print(f"n={n} {state:5s} fast={onepass} dbg={dbg} r={r}: index {idx}  scan-to-end {t_scan:7.3f} ms (slow/blocks {s_scan}, P={p!r})  "
                       f"measure+collapse {t_meas:7.3f} ms (slow/blocks {stats()})", flush=True)

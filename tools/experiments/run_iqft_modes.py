@@ -18,5 +18,5 @@ with qc.Register(25, 5) as reg:
     for mode in (0, 2):
         reg.set_fusion(mode)
         for _ in range(2):
-            reg.timer_start(); qc.reset_register(reg); qc.quantum_computation(21, 2, reg); ms = reg.timer_stop()
+            reg.timer_start(); qc.reset_register(reg); qc.quantum_computation(21, 2, reg); reg.flush(); ms = reg.timer_stop()
         print(f"shor30 mode {mode}: {ms:.3f} ms", flush=True)

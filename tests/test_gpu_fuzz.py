@@ -1,0 +1,137 @@
+"""GPU: time-boxed randomised comparison of the fused engine with the oracle -- register sizes, gate mixes, modes, observers and
+knob settings drawn at random from one seed.  The suite runs a short, fixed-seed slice; a longer campaign is
+    QCX_FUZZ_SECONDS=480 QCX_FUZZ_SEED=$RANDOM python -m pytest tests/test_gpu_fuzz.py -m gpu -x -q -s
+(every case prints its own seed first, so a failure names the case to replay with QCX_FUZZ_CASE=<seed>)."""
+import math
+import os
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+KNOBS = ("fuse_T", "fuse_c", "fuse_x8", "fuse_x8_min_tiles_log2", "fuse_chain", "fuse_chain_min_n", "fuse_chain_dir", "fuse_compact",
+         "fuse_compact_lazy", "fuse_expand_fused", "fuse_gen", "fuse_gen_cols", "meas_parallel", "meas_min_log2", "meas_block_log", "meas_fast")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def same(got, want, mode, what):
+    if mode == 2:
+        err = float(np.max(np.abs(got - want)))
+        assert err <= TOL, f"{what}: max |delta| {err:.3e}"
+    else:
+        bad = np.nonzero(bits(got) != bits(want))[0]
+        assert bad.size == 0, f"{what}: {bad.size} doubles differ, first at {int(bad[0])}: {got[bad[0]]!r} vs {want[bad[0]]!r}"
+
+
+def gate_mix(rs, n, M, Cn, length, lo, phase_bias):
+    """H / CPHASE / C_AMODC on qubits lo .. n-1 (lo = M: nothing touches the M register -- what a compact chain needs)"""
+    prog = []
+    for _ in range(length):
+        k = rs.uniform()
+        if k < (1.0 - phase_bias) * 0.8:
+            prog.append(("h", int(rs.randint(lo, n))))
+        elif k < 0.97 or M == 0 or lo:
+            c, t = (int(v) for v in rs.choice(np.arange(lo, n), 2, replace=False))
+            th = float(rs.uniform(-3.2, 3.2)) if rs.randint(0, 2) else math.pi / (1 << int(rs.randint(1, 14)))
+            prog.append(("p", c, t, th))
+        else:
+            prog.append(("c", int(rs.randint(1, 4 * Cn)), int(rs.randint(M, n))))
+    return prog
+
+
+def apply(qc, ob, reg, want, n, M, Cn, prog, threads=8):
+    for g in prog:
+        if g[0] == "h":
+            qc.hadamard_gate(g[1], reg); ob.hadamard(want, n, g[1], threads)
+        elif g[0] == "p":
+            qc.c_phase_shift_gate(g[1], g[2], g[3], reg); ob.cphase(want, n, g[1], g[2], g[3], threads)
+        else:
+            qc.c_amodc_gate(Cn, g[1], g[2], reg); ob.camodc(want, n, M, Cn, g[1], g[2], threads)
+
+
+def one_case(qc, ob, seed):
+    rs = np.random.RandomState(seed)
+    Cn, M, a = [(21, 5, 2), (15, 4, 7), (35, 6, 2), (1, 0, 1), (1, 0, 1), (21, 5, 16), (33, 6, 7)][rs.randint(0, 7)]
+    n = int(rs.randint(max(M + 6, 10), 23))
+    L = n - M
+    mode = int(rs.choice([0, 1, 2]))
+    knobs = dict(fuse_T=int(rs.choice([10, 11, 12])), fuse_c=int(rs.choice([3, 4])), fuse_x8=int(rs.randint(0, 4) != 0),
+                 fuse_x8_min_tiles_log2=int(rs.choice([0, 2])), fuse_chain=int(rs.randint(0, 4) != 0), fuse_chain_min_n=13,
+                 fuse_chain_dir=int(rs.choice([-1, 0, 1])), fuse_compact=int(rs.randint(0, 5) != 0), fuse_compact_lazy=int(rs.randint(0, 3) != 0),
+                 fuse_expand_fused=int(rs.randint(0, 4) != 0), fuse_gen=int(rs.randint(0, 6) != 0), fuse_gen_cols=int(rs.randint(0, 6) != 0),
+                 meas_parallel=1, meas_min_log2=10, meas_block_log=int(rs.choice([0, 8, 9, 11])), meas_fast=int(rs.randint(0, 4) != 0))
+    kind = int(rs.randint(0, 3)) if M else 0
+    tag = f"case {seed}: n={n} M={M} C={Cn} mode={mode} kind={kind} {knobs}"
+    print(tag, flush=True)
+    qc.tune(**knobs)
+    scale = 1.0
+    with qc.Register(L, M) as reg:
+        reg.set_fusion(mode)
+        if kind == 0:                                   # a random program on a random dense state
+            want = ob.fill_random(n, seed & 0xFFFF); reg.fill_random(seed & 0xFFFF)
+            prog = gate_mix(rs, n, M, Cn, int(rs.randint(20, 260)), 0, float(rs.choice([0.3, 0.6, 0.9])))
+            apply(qc, ob, reg, want, n, M, Cn, prog)
+        else:                                           # behind a reset: the circuit front, then the inverse QFT (1) or a random tail on the L register (2)
+            want = np.zeros(2 << n); ob.reset(want, n)
+            qc.reset_register(reg)
+            if kind == 1:
+                qc.quantum_computation(Cn, a, reg); ob.quantum_computation(want, n, M, Cn, a, threads=8)
+            else:
+                for l in range(M, n):
+                    qc.hadamard_gate(l, reg); ob.hadamard(want, n, l, 8)
+                x = a % Cn
+                for l in range(M, n):
+                    qc.c_amodc_gate(Cn, x, l, reg); ob.camodc(want, n, M, Cn, x, l, 8); x = (x * x) % Cn
+                apply(qc, ob, reg, want, n, M, Cn, gate_mix(rs, n, M, Cn, int(rs.randint(10, 200)), M, float(rs.choice([0.5, 0.8, 0.95]))))
+        # observers, in random order; each must see the reference's state
+        for obs in rs.permutation(["read", "norm", "window", "measure", "more"])[:int(rs.randint(1, 5))]:
+            if obs == "read":
+                same(reg.read(), want, mode, tag + " read")
+            elif obs == "norm":
+                assert abs(reg.norm2() - ob.norm2(want, n)) < 1e-11, tag + " norm"
+            elif obs == "window":
+                s = int(rs.randint(0, (1 << n) - 64)); cnt = int(rs.randint(1, min(1 << n, 5000) - 63))
+                cnt = min(cnt, (1 << n) - s)
+                same(reg.read(s, cnt), want[2 * s:2 * (s + cnt)], mode, tag + " window")
+            elif obs == "measure":
+                r = float(rs.uniform(0, 1)) if rs.randint(0, 4) else float(rs.choice([0.0, 1.0, 1e-9, 0.999999999]))
+                got = qc.measure_state(reg, r)
+                if mode == 2:
+                    # the tolerance mode's probabilities differ in the last bits: the draw must land next to the same boundary
+                    cum = np.cumsum((want.reshape(-1, 2) ** 2).sum(axis=1))
+                    lo, hi = int(np.searchsorted(cum, r - 1e-9)), int(np.searchsorted(cum, r + 1e-9))
+                    assert (r <= 0.0 and got == 0) or lo <= got <= max(hi, lo) or got == (1 << n) - 1, tag + f" measure r={r!r}: {got} not in [{lo}, {hi}]"
+                    want[:] = 0.0; want[2 * got] = 1.0
+                else:
+                    assert got == ob.measure(want, n, r), tag + f" measure r={r!r}"
+                same(reg.read(), want, 0, tag + " collapsed state")
+            else:
+                prog = gate_mix(rs, n, M, Cn, int(rs.randint(1, 60)), 0, 0.6)
+                apply(qc, ob, reg, want, n, M, Cn, prog)
+                same(reg.read(), want, mode, tag + " more gates")
+    return scale
+
+
+def test_randomised_cases_against_the_oracle(qc, ob):
+    budget = float(os.environ.get("QCX_FUZZ_SECONDS", "25"))
+    master = int(os.environ.get("QCX_FUZZ_SEED", "20260504"))
+    only = os.environ.get("QCX_FUZZ_CASE")
+    old = {k: qc.lib().qcx_tune_get(k.encode()) for k in KNOBS}
+    try:
+        if only:
+            one_case(qc, ob, int(only))
+            return
+        rs = np.random.RandomState(master)
+        t0, done = time.time(), 0
+        while time.time() - t0 < budget or done < 6:
+            one_case(qc, ob, int(rs.randint(0, 2 ** 31 - 1)))
+            done += 1
+        print(f"{done} cases in {time.time() - t0:.1f} s (master seed {master})")
+    finally:
+        qc.tune(**old)

@@ -662,12 +662,12 @@ def single_gpu_configs(qc, reps=3):
         row("c_phase_shift_gate(20, 1) [k_phase_lines]", best(lambda: qc.c_phase_shift_gate(20, 1, 0.3, reg)), 32.0 * 2.0 ** (n - 1),
             "32 B x the touched 128-B lines (bit 1 lies inside a line: half the state's lines)")
         row("hadamard_gate(1) [k_h_wave]", best(lambda: qc.hadamard_gate(1, reg)), 32.0 * 2.0 ** n, "32 B per amplitude")
-        row("measure_state scan to the end, dense random state [k_meas_onepass + walk]", best(lambda: reg.total_probability()), 16.0 * 2.0 ** n,
+        row("measure_state scan to the end, dense random state [k_meas_onepass + k_meas_fast]", best(lambda: reg.total_probability()), 16.0 * 2.0 ** n,
             "one read of the state (qcx_total_probability: the exact scan without a collapse); the synthetic dense state is the scan's "
             "worst case: its running sum crosses 32 binades, each costs an exact rescan of one record on one wave")
         # the same scan on the state the workload measures: the final state of the n = 30 Shor circuit (expanded into the register)
         reg.set_fusion(0); qc.reset_register(reg); qc.quantum_computation(21, 2, reg); reg.flush(); reg.set_fusion(-1)
-        row("measure_state scan to the end, Shor N=21 final state [k_meas_onepass + walk]", best(lambda: reg.total_probability()), 16.0 * 2.0 ** n,
+        row("measure_state scan to the end, Shor N=21 final state [k_meas_onepass + k_meas_fast]", best(lambda: reg.total_probability()), 16.0 * 2.0 ** n,
             "one read of the state; 10 of 524288 records take the exact rescan")
         reg.fill_random(3)
         reg.set_fusion(0)

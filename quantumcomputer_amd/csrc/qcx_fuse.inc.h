@@ -717,10 +717,13 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
             P.dg_lds_off = (uint32_t)((8 * ((size_t)P.xm_cnt + 66) + 15) & ~(size_t)15);
             lds_cols = (size_t)P.zpad * QCX_COL_STRIDE * sizeof(amp_t) + P.dg_lds_off + 16 * (size_t)P.dg_cnt * 49;
         }
+        P.gen_lds_off = (uint32_t)((lds_cols - (size_t)P.zpad * QCX_COL_STRIDE * sizeof(amp_t) + 15) & ~(size_t)15);   // the residue -> column table of a compact chain
+        lds_cols = (size_t)P.zpad * QCX_COL_STRIDE * sizeof(amp_t) + P.gen_lds_off + (P.gen == 3 ? P.gen_tab_bytes : 0);
         // (four waves; one wave per column -- six for the orbit of N = 21 -- is slower: 5.3 against 3.8 ms at n = 30, the extra waves idle through generation and store)
         const unsigned waves = (unsigned)std::min<long>(8, std::max<long>(4, tn.fuse_cols_waves));
-        if (P.dg_cnt) hipLaunchKernelGGL((k_gen_cols<6, true>), dim3(grid), dim3(64 * waves), lds_cols, r->stream, amp_out, n, P, d_ops, ntiles, d_ops);
-        else hipLaunchKernelGGL((k_gen_cols<6, false>), dim3(grid), dim3(64 * waves), lds_cols, r->stream, amp_out, n, P, d_ops, ntiles, d_ops);
+        const unsigned gridc = grid_for(ntiles, 1, tn.fuse_cols_cap);
+        if (P.dg_cnt) hipLaunchKernelGGL((k_gen_cols<6, true>), dim3(gridc), dim3(64 * waves), lds_cols, r->stream, amp_out, n, P, d_ops, ntiles, d_ops);
+        else hipLaunchKernelGGL((k_gen_cols<6, false>), dim3(gridc), dim3(64 * waves), lds_cols, r->stream, amp_out, n, P, d_ops, ntiles, d_ops);
         HIP_TRY(hipGetLastError());
         return QCX_NO_ERROR;
     }
@@ -1625,6 +1628,7 @@ static int compact_chain(qcx_register *r, GateQueue *gq, const Tune &tn, const B
         memset(&all_ops[at], 0, nrec * sizeof(FuseOp));
         memcpy(&all_ops[at], &G, sizeof G);
         acts[0].P.gen = 3;
+        acts[0].P.gen_tab_bytes = (uint32_t)(((G.C ? G.C : (1u << M)) + 15u) & ~15u);
         acts[0].P.zpad = (uint16_t)orbit.size();
         acts[0].P.zskip = 0;
         acts[0].P.gen_rec_off = (uint32_t)(at - acts[0].op_off);

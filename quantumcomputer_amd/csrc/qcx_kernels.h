@@ -1246,6 +1246,7 @@ struct FusePass {
     // gen = 1: the pass does not READ its tiles: the register is a basis state that has not been written yet (lazy reset /
     // collapse), and the tile -- that state after the closed-form circuit front, see GenFront -- is generated in LDS
     uint32_t gen, gen_rec_off, gen_lds_off;
+    uint32_t gen_tab_bytes;     // gen = 3: bytes of k_gen_cols' residue -> column table in LDS (at gen_lds_off behind the columns)
     // zskip = W > 0 (W = log2 of the waves per workgroup): the wave number is mapped onto the tile-local bits zb[0..W) -- bits no
     // Hadamard of the pass targets and no multiply moves -- instead of onto the highest thread bits, and a wave whose
     // amplitudes are ALL +0 skips the rounds (gates map +0 to +0: same bits).  The host asks for it behind a circuit front:
@@ -2183,6 +2184,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
 // stored as +0 straight from registers.  Same records, same walk (fuse_round_item), same bits.
 // ---------------------------------------------------------------------------
 #define QCX_COL_STRIDE 257u
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for the wave's outstanding GLOBAL stores
+// (s_waitcnt vmcnt(0) in front of s_barrier): inside k_gen_cols' tile loop that made every wave sit out the round trip of the
+// tile it had just stored before it could generate the next one -- and since all workgroups of a CU run in step, the chip
+// alternated between computing and storing.  The loop has no vector load from global memory (records: scalar loads, masks and
+// tables: LDS), so nothing in it needs the stores to have landed; they drain while the next tile is generated and walked.
+#define QCX_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 // x mod C with the host's Cinv = floor(2^32 / C): the quotient estimate is at most one short
 __device__ __forceinline__ unsigned gen_mod(unsigned x, unsigned C, unsigned Cinv)
 {
@@ -2199,7 +2206,7 @@ __device__ __forceinline__ unsigned gen_mod(unsigned x, unsigned C, unsigned Cin
 // further waves only walk columns.
 template <int OCC, bool TOL = false>     // TOL: the pass holds merged diagonals (tolerance mode): fast rounds run as in k_fused_rounds<.., TOL>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC))) void k_gen_cols(
-    amp_t *amp_out, unsigned n, FusePass P, const FuseOp *__restrict__ ops, uint64_t ntiles, const FuseOp *ops_asm)
+    amp_t *__restrict__ amp_out, unsigned n, FusePass P, const FuseOp *__restrict__ ops, uint64_t ntiles, const FuseOp *ops_asm)
 {
     constexpr unsigned BLOCK = 256;
     const unsigned nthreads = blockDim.x, nwaves = blockDim.x >> 6;
@@ -2234,25 +2241,40 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC))) void
 #pragma unroll
     for (unsigned b = 0; b < 4; b++) { bl[b] = (unsigned)fuse_spread(256u << b, P.st_loc, TT); bp[b] = fuse_spread(256u << b, P.st_pos, TT); }
     if (threadIdx.x == 0) s_mask = 0;
+    // the front's constants, read ONCE: amp_out may alias the record buffer as far as the compiler knows, so every GF-> access
+    // inside the tile loop was a fresh scalar load -- some twenty per tile, half of them in a dependent chain (the orbit search, the
+    // factor tables): 0.73 ms of the pass at n = 30 was this latency (generation alone, gates and stores skipped)
+    const uint64_t gf_fixed_out = GF->fixed_out, gf_fixed_val = GF->basis & GF->fixed_out, gf_sign_out = GF->sign_out;
+    const double gf_v = GF->v;
+    const unsigned gf_C = GF->C, gf_Cinv = GF->Cinv, gf_present = GF->present, gf_M = GF->M, gf_lowout = GF->lowout_mask, gf_ncols = GF->ncols;
+    // compact form: column of a residue, tabulated once per workgroup (residues < C <= 4096; 0xff: not on the orbit)
+    unsigned char *col_of = reinterpret_cast<unsigned char *>(behind + P.gen_lds_off);
+    if (compact) {
+        for (unsigned f = threadIdx.x; f < (gf_C ? gf_C : (1u << gf_M)); f += nthreads) {
+            unsigned char c = 0xff;
+            for (unsigned jj = 0; jj < gf_ncols; jj++) if (GF->orbit[jj] == f) c = (unsigned char)jj;
+            col_of[f] = c;
+        }
+    }
     __syncthreads();
     for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const uint64_t base_in = fuse_deposit(t, P.seg_in, P.nseg_in);
         uint64_t base = base_in, base_out = base_in;
         if (P.chained) { base = fuse_deposit(t, P.seg_lg, P.nseg_lg); base_out = fuse_deposit(t, P.seg_out, P.nseg_out); }
         amp_t *go = amp_out + (base_out | st_t);
-        const uint64_t rbase = compact ? (base >> cb) << GF->M : base;            // the tile's base as an index of the REAL register
+        const uint64_t rbase = compact ? (base >> cb) << gf_M : base;            // the tile's base as an index of the REAL register
         // ---- generate: this thread's one candidate amplitude (hot combination h): its residue, column and sign ----------
         unsigned f = 0xffffu;
-        if ((rbase & GF->fixed_out) == (GF->basis & GF->fixed_out) && phot != 0xffffu) {
+        if ((rbase & gf_fixed_out) == gf_fixed_val && phot != 0xffffu) {
             f = phot;
-            if (GF->C) {
+            if (gf_C) {
                 unsigned pt = 1;                                                  // controls outside the tile: one factor per tile
 #pragma unroll
                 for (unsigned k = 0; k < 5; k++)
-                    if ((GF->present >> k) & 1u) pt = gen_mod(pt * (unsigned)GF->tabP[k][(unsigned)((rbase >> (8u * k)) & 255u)], GF->C, GF->Cinv);
-                f = gen_mod(f * pt, GF->C, GF->Cinv);
+                    if ((gf_present >> k) & 1u) pt = gen_mod(pt * (unsigned)GF->tabP[k][(unsigned)((rbase >> (8u * k)) & 255u)], gf_C, gf_Cinv);
+                f = gen_mod(f * pt, gf_C, gf_Cinv);
             }
-            if (!compact && (f & GF->lowout_mask) != ((uint32_t)base & GF->lowout_mask)) f = 0xffffu;   // its low bits outside the tile belong to another tile
+            if (!compact && (f & gf_lowout) != ((uint32_t)base & gf_lowout)) f = 0xffffu;   // its low bits outside the tile belong to another tile
         }
         if constexpr (TOL) {
             // E_out of this tile for every diagonal of the pass: one thread each (read by the rounds, behind the barriers below)
@@ -2268,23 +2290,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC))) void
         }
         unsigned mycol = f & 15u;
         if (compact) {                                                            // column = the residue's place in the orbit
-            mycol = 0xffu;
-            for (unsigned j = 0; j < GF->ncols; j++) if (GF->orbit[j] == f) mycol = j;
+            mycol = f != 0xffffu ? (unsigned)col_of[f] : 0xffu;
             if (mycol == 0xffu) f = 0xffffu;                                      // (cannot happen: the orbit holds every reachable residue)
         } else if (f != 0xffffu) atomicOr(&s_mask, 1u << mycol);
-        __syncthreads();
-        const unsigned mask = compact ? (1u << GF->ncols) - 1u : s_mask;
+        QCX_LDS_BARRIER();
+        const unsigned mask = compact ? (1u << gf_ncols) - 1u : s_mask;
         const unsigned ncol = (unsigned)__builtin_popcount(mask);
         if (worker) for (unsigned s = 0; s < ncol; s++) { amp_t z; z.x = 0.0; z.y = 0.0; cols[s * QCX_COL_STRIDE + h] = z; }
         if (f != 0xffffu) {
-            const uint32_t par = (parH ^ (uint32_t)__builtin_popcountll(rbase & GF->sign_out)) & 1u;
-            amp_t a; a.x = par ? -GF->v : GF->v; a.y = 0.0;
+            const uint32_t par = (parH ^ (uint32_t)__builtin_popcountll(rbase & gf_sign_out)) & 1u;
+            amp_t a; a.x = par ? -gf_v : gf_v; a.y = 0.0;
             cols[(unsigned)__builtin_popcount(mask & ((1u << mycol) - 1u)) * QCX_COL_STRIDE + h] = a;
         }
-        __syncthreads();
+        QCX_LDS_BARRIER();
         // ---- rounds: every wave takes whole columns through the pass on its own --------------------------------------
+        // (which columns a wave takes rotates with the tile number: six columns over four waves are 2 + 2 + 1 + 1, a wave sits on one
+        //  SIMD for good, and with a fixed assignment SIMDs 0 and 1 of every CU would carry twice the work of SIMDs 2 and 3)
         if (!(P.dbg & 1u))
-        for (unsigned s = wave; s < ncol; s += nwaves) {
+        for (unsigned s = (wave + (unsigned)t + (unsigned)(t >> 2)) % nwaves; s < ncol; s += nwaves) {
             unsigned cpat = 0;                                                    // the column's low-bit value: the s-th set bit of mask
             { unsigned m = mask; for (unsigned k = 0; k < s; k++) m &= m - 1u; cpat = (unsigned)__builtin_ctz(m); }
             amp_t *col = cols + s * QCX_COL_STRIDE;
@@ -2336,7 +2359,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC))) void
                 i += 1 + cnt;
             }
         }
-        __syncthreads();
+        QCX_LDS_BARRIER();
         if (threadIdx.x == 0) s_mask = 0;                                         // (read by everyone before the barrier above)
         // ---- store the whole tile: populated columns from LDS, the others as +0 ------------------------------------------
         if (worker && !(P.dbg & 2u)) {
@@ -2354,7 +2377,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC))) void
                 __builtin_nontemporal_store(v, go + offk);
             }
         }
-        __syncthreads();
+        QCX_LDS_BARRIER();
     }
 }
 

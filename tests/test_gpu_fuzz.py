@@ -58,7 +58,7 @@ def apply(qc, ob, reg, want, n, M, Cn, prog, threads=8):
 def one_case(qc, ob, seed):
     rs = np.random.RandomState(seed)
     Cn, M, a = [(21, 5, 2), (15, 4, 7), (35, 6, 2), (1, 0, 1), (1, 0, 1), (21, 5, 16), (33, 6, 7)][rs.randint(0, 7)]
-    n = int(rs.randint(max(M + 6, 10), 23))
+    n = int(rs.randint(max(M + 6, int(os.environ.get("QCX_FUZZ_NMIN", "10"))), int(os.environ.get("QCX_FUZZ_NMAX", "22")) + 1))
     L = n - M
     mode = int(rs.choice([0, 1, 2]))
     knobs = dict(fuse_T=int(rs.choice([10, 11, 12])), fuse_c=int(rs.choice([3, 4])), fuse_x8=int(rs.randint(0, 4) != 0),
@@ -67,11 +67,17 @@ def one_case(qc, ob, seed):
                  fuse_expand_fused=int(rs.randint(0, 4) != 0), fuse_gen=int(rs.randint(0, 6) != 0), fuse_gen_cols=int(rs.randint(0, 6) != 0),
                  meas_parallel=1, meas_min_log2=10, meas_block_log=int(rs.choice([0, 8, 9, 11])), meas_fast=int(rs.randint(0, 4) != 0))
     kind = int(rs.randint(0, 3)) if M else 0
-    tag = f"case {seed}: n={n} M={M} C={Cn} mode={mode} kind={kind} {knobs}"
+    # one case in five on a register SHARDED by this process (the C host: virtual shards of the one GPU): the exchange step,
+    # the relabelling of global qubits, compact circuits on companion registers, measurement across shards
+    shards = int(rs.choice([2, 4, 8])) if rs.randint(0, 5) == 0 else 1
+    k = shards.bit_length() - 1
+    if shards > 1 and n - k - max(M, 6) < 2 * k:
+        shards = 1
+    tag = f"case {seed}: n={n} M={M} C={Cn} mode={mode} kind={kind} shards={shards} {knobs}"
     print(tag, flush=True)
     qc.tune(**knobs)
     scale = 1.0
-    with qc.Register(L, M) as reg:
+    with (qc.Register(L, M, shards=shards, devices=qc.spread_devices(shards)) if shards > 1 else qc.Register(L, M)) as reg:
         reg.set_fusion(mode)
         if kind == 0:                                   # a random program on a random dense state
             want = ob.fill_random(n, seed & 0xFFFF); reg.fill_random(seed & 0xFFFF)
@@ -94,7 +100,9 @@ def one_case(qc, ob, seed):
             if obs == "read":
                 same(reg.read(), want, mode, tag + " read")
             elif obs == "norm":
-                assert abs(reg.norm2() - ob.norm2(want, n)) < 1e-11, tag + " norm"
+                # (two different summation orders -- the oracle's is the sequential one: 1.1e-11 apart at n = 25 -- so this observer
+                #  only checks that the flush it triggers leaves the right state behind; the reads do the comparing)
+                assert abs(reg.norm2() - ob.norm2(want, n)) < 1e-9, tag + " norm"
             elif obs == "window":
                 s = int(rs.randint(0, (1 << n) - 64)); cnt = int(rs.randint(1, min(1 << n, 5000) - 63))
                 cnt = min(cnt, (1 << n) - s)

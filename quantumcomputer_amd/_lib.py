@@ -115,6 +115,7 @@ _EXTRA = {
     "qcx_compact_stats": (_i, [_p, C.POINTER(_ul)]),
     "qcx_compact_measure_stats": (_i, [_p, C.POINTER(_ul)]),
     "qcx_expanding_store_stats": (_i, [_p, C.POINTER(_ul)]),
+    "qcx_plan_cache_stats": (_i, [_p, C.POINTER(_ul)]),
 }
 
 

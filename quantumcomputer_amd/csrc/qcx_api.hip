@@ -124,6 +124,7 @@ struct Tune {
     long cam_stage_mb = 1024;  // M > 12: staging buffer of the in-place modular multiply (MiB; at least one 2^M-block)
     long fuse_compact = 1;     // behind a circuit front whose M register stays on a small orbit: the flush runs on a compact copy of the state (compact_chain)
     long fuse_compact_lazy = 1; // ... and stays compact behind a whole-circuit entry point until something other than measure_state looks at the state
+    long fuse_plan_cache = 1;   // a flush whose inputs (shape, mode, knobs, front, gate list) are bit for bit those of the last one reuses its plan and, when nothing was uploaded since, its records on the device
     long fuse_expand_fused = 1;  // the last pass of a compact chain stores the real register itself (k_fused_x8's expanding store) instead of k_expand_compact
     long fuse_cols_tol = 1;    // tolerance mode: the by-columns pass of a compact chain keeps its merged diagonals (fast rounds inside k_gen_cols)
     long fuse_cols_cap = 12288; // workgroups of a k_gen_cols launch (a workgroup's prologue is long; n = 30 Shor circuit 11.06-11.09 ms with 12288-24576, 11.14-11.3 with 65536, 12.07 with 1536; tolerance 7.4-7.8 against 8.1)
@@ -166,7 +167,7 @@ static Tune tune_now() { std::lock_guard<std::mutex> lock(g_tune_mutex); return 
 extern "C" int qcx_tune_set(const char *key, long value)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); g_tune.name = value; return QCX_NO_ERROR; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_spin_limit) K(meas_dbg) K(meas_fast) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_dir) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_gen_cols) K(fuse_cols_waves) K(fuse_cols_cap) K(fuse_cols_tol) K(fuse_compact) K(fuse_expand_direct) K(fuse_compact_lazy) K(fuse_expand_fused) K(fuse_zskip) K(fuse_zskip_maxw) K(fuse_x8) K(fuse_x8_T) K(fuse_x8_c) K(fuse_x8_map) K(fuse_x8_cap) K(fuse_x8_ratio) K(fuse_x8_min_tiles_log2) K(fuse_x8t)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_spin_limit) K(meas_dbg) K(meas_fast) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_dir) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_gen_cols) K(fuse_cols_waves) K(fuse_cols_cap) K(fuse_cols_tol) K(fuse_compact) K(fuse_expand_direct) K(fuse_compact_lazy) K(fuse_expand_fused) K(fuse_plan_cache) K(fuse_zskip) K(fuse_zskip_maxw) K(fuse_x8) K(fuse_x8_T) K(fuse_x8_c) K(fuse_x8_map) K(fuse_x8_cap) K(fuse_x8_ratio) K(fuse_x8_min_tiles_log2) K(fuse_x8t)
 #undef K
     return QCX_BAD_ARGUMENTS;
 }
@@ -174,7 +175,7 @@ extern "C" int qcx_tune_set(const char *key, long value)
 extern "C" long qcx_tune_get(const char *key)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); return g_tune.name; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_spin_limit) K(meas_dbg) K(meas_fast) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_dir) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_gen_cols) K(fuse_cols_waves) K(fuse_cols_cap) K(fuse_cols_tol) K(fuse_compact) K(fuse_expand_direct) K(fuse_compact_lazy) K(fuse_expand_fused) K(fuse_zskip) K(fuse_zskip_maxw) K(fuse_x8) K(fuse_x8_T) K(fuse_x8_c) K(fuse_x8_map) K(fuse_x8_cap) K(fuse_x8_ratio) K(fuse_x8_min_tiles_log2) K(fuse_x8t)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_spin_limit) K(meas_dbg) K(meas_fast) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_dir) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_gen_cols) K(fuse_cols_waves) K(fuse_cols_cap) K(fuse_cols_tol) K(fuse_compact) K(fuse_expand_direct) K(fuse_compact_lazy) K(fuse_expand_fused) K(fuse_plan_cache) K(fuse_zskip) K(fuse_zskip_maxw) K(fuse_x8) K(fuse_x8_T) K(fuse_x8_c) K(fuse_x8_map) K(fuse_x8_cap) K(fuse_x8_ratio) K(fuse_x8_min_tiles_log2) K(fuse_x8t)
 #undef K
     return -1;
 }
@@ -1375,6 +1376,14 @@ extern "C" int qcx_compact_stats(qcx_register *r, unsigned long *compact_chains)
 {
     if (!r || !compact_chains) return QCX_BAD_ARGUMENTS;
     *compact_chains = r->sh ? r->sh->compact_circuits : (r->queue ? r->queue->compact_chains : 0);
+    return QCX_NO_ERROR;
+}
+
+// diagnostics: flushes that took their plan from the plan cache (GateQueue::pc)
+extern "C" int qcx_plan_cache_stats(qcx_register *r, unsigned long *hits)
+{
+    if (!r || !hits) return QCX_BAD_ARGUMENTS;
+    *hits = (!r->sh && r->queue) ? r->queue->plan_hits : 0;
     return QCX_NO_ERROR;
 }
 

@@ -78,6 +78,15 @@ static void merge_diagonals(const std::vector<QGate> &in, std::vector<QGate> &ou
     }
 }
 
+struct FuseAction {
+    int      fused;          // 0: stand-alone gate `gate`, 1: fused pass
+    size_t   gate;
+    FusePass P;
+    size_t   op_off, op_cnt, ngates, first_gate;
+    int      nopipe;         // phase-dominated pass (planned on the smaller tile of fuse_T_phase); reported by qcx_fusion_plan
+    uint8_t  tl[16];         // the qubit that is tile-local bit j (the records' numbering)
+};
+
 struct GateQueue {
     std::vector<QGate> gates;
     FuseOp  *d_ops = nullptr;       // device copy of the ops of the passes in flight
@@ -99,7 +108,35 @@ struct GateQueue {
         unsigned nv = 0, cb = 0, ngates = 0;
         Tune     tn;                // the knobs the plan was made under
     } last;
+    // The plan of the last flush, kept: a period-finding run issues the same circuit attempt after attempt, and planning it
+    // (cutting the list into passes, the records, thread maps, merged diagonals: 0.2-0.4 ms for the 406 gates of an n = 28 inverse
+    // QFT, on the host, with the GPU idle) plus uploading the records is pure repetition.  A flush whose inputs are bit for
+    // bit those of the cached one -- register shape, fusion mode, every knob, the circuit front, the gate list -- reuses
+    // actions and records; when nothing has been uploaded since, the records are still on the device as well.
+    // kind 1: a flush without a front (fuse_flush's plain path); 2: a compact chain.
+    struct {
+        bool     valid = false;
+        int      kind = 0;
+        unsigned n = 0, M = 0;
+        int      fusion = 0;
+        bool     chain = false;
+        Tune     tn;
+        BasisFront Bf;
+        size_t   kfront = 0;
+        std::vector<QGate> gates;
+        std::vector<FuseAction> acts;
+        std::vector<FuseOp> all_ops;
+        std::vector<uint16_t> orbit;    // kind 2
+        unsigned cb = 0;                // kind 2
+        unsigned long stamp = 0;        // upload_stamp right after these records were uploaded
+    } pc;
+    unsigned long upload_stamp = 0, plan_hits = 0;
 };
+
+static bool same_gate_list(const std::vector<QGate> &a, const std::vector<QGate> &b)
+{
+    return a.size() == b.size() && (a.empty() || memcmp(a.data(), b.data(), a.size() * sizeof(QGate)) == 0);
+}
 
 static void queue_free(GateQueue *gq)
 {
@@ -128,14 +165,6 @@ static bool camodc_closed_form(unsigned n, unsigned M, unsigned C, unsigned A, u
 }
 
 
-struct FuseAction {
-    int      fused;          // 0: stand-alone gate `gate`, 1: fused pass
-    size_t   gate;
-    FusePass P;
-    size_t   op_off, op_cnt, ngates, first_gate;
-    int      nopipe;         // phase-dominated pass (planned on the smaller tile of fuse_T_phase); reported by qcx_fusion_plan
-    uint8_t  tl[16];         // the qubit that is tile-local bit j (the records' numbering)
-};
 
 static int launch_standalone(qcx_register *r, const QGate &g)
 {
@@ -1450,6 +1479,7 @@ static int upload_ops(qcx_register *r, GateQueue *gq, const std::vector<FuseOp> 
     memcpy(gq->h_ops, all_ops.data(), all_ops.size() * sizeof(FuseOp));
     memset(gq->h_ops + all_ops.size(), 0, sizeof(FuseOp));
     HIP_TRY(hipMemcpyAsync(gq->d_ops, gq->h_ops, need_ops * sizeof(FuseOp), hipMemcpyHostToDevice, r->stream));
+    gq->upload_stamp++;
     return QCX_NO_ERROR;
 }
 
@@ -1556,7 +1586,13 @@ static int compact_chain(qcx_register *r, GateQueue *gq, const Tune &tn, const B
     }
     std::vector<uint16_t> orbit;
     unsigned cb = 0;
-    if (!compact_orbit(Bf, M, orbit, &cb)) return QCX_NO_ERROR;
+    // (the plan cache, GateQueue::pc: the same front and the same gate list under the same knobs as the last chain -- the next
+    //  attempt of a period-finding run -- take orbit, actions and records from there)
+    const bool hit = tn.fuse_plan_cache && gq->pc.valid && gq->pc.kind == 2 && gq->pc.n == n && gq->pc.M == M && gq->pc.fusion == r->fusion
+                     && gq->pc.kfront == kfront && memcmp(&gq->pc.tn, &tn, sizeof tn) == 0 && memcmp(&gq->pc.Bf, &Bf, sizeof Bf) == 0
+                     && same_gate_list(gq->pc.gates, gates);
+    if (hit) { orbit = gq->pc.orbit; cb = gq->pc.cb; }
+    else if (!compact_orbit(Bf, M, orbit, &cb)) return QCX_NO_ERROR;
     const uint32_t Cn = Bf.ncam ? Bf.C[0] : 0u, f0 = (uint32_t)(Bf.basis & lowmask);
     const unsigned nv = L + cb;
     if (nv < 14 || L < 8) return QCX_NO_ERROR;
@@ -1573,6 +1609,8 @@ static int compact_chain(qcx_register *r, GateQueue *gq, const Tune &tn, const B
     v.own_stream = r->own_stream; v.stream = r->stream; v.fusion = r->fusion;
     std::vector<FuseAction> acts;
     std::vector<FuseOp> all_ops;
+    if (hit) { acts = gq->pc.acts; gq->plan_hits++; }
+    else {
     fuse_plan(&v, tn, vg, acts, all_ops, r->fusion == 2, true, (r->fusion == 2 && tn.fuse_cols_tol) ? 2 : 1);
     if (acts.empty() || !acts[0].fused) return QCX_NO_ERROR;
     {
@@ -1633,6 +1671,12 @@ static int compact_chain(qcx_register *r, GateQueue *gq, const Tune &tn, const B
         acts[0].P.zskip = 0;
         acts[0].P.gen_rec_off = (uint32_t)(at - acts[0].op_off);
     }
+    gq->pc.valid = false;
+    if (tn.fuse_plan_cache) {               // (valid once the records are uploaded, below)
+        gq->pc.kind = 2; gq->pc.n = n; gq->pc.M = M; gq->pc.fusion = r->fusion; gq->pc.chain = true; gq->pc.tn = tn; gq->pc.Bf = Bf; gq->pc.kfront = kfront;
+        gq->pc.gates = gates; gq->pc.acts = acts; gq->pc.all_ops = all_ops; gq->pc.orbit = orbit; gq->pc.cb = cb;
+    }
+    }
     // Round 5: when the chain's last pass is a k_fused_x8 pass whose tile holds the column bits, that pass can store the REAL
     // register itself (FusePass::xp_on) -- k_expand_compact's extra read and write of the compact form (8.6 of its 21.5 GB at
     // n = 30, M = 5) disappear.  keep = false: it does.  keep = true (a whole-circuit entry point: measure_state may come next and
@@ -1656,7 +1700,12 @@ static int compact_chain(qcx_register *r, GateQueue *gq, const Tune &tn, const B
             } else { acts.back().P = PL; expanded = true; }
         }
     }
-    QCX_TRY(upload_ops(r, gq, all_ops));
+    if (hit) {
+        if (gq->pc.stamp != gq->upload_stamp) { QCX_TRY(upload_ops(r, gq, gq->pc.all_ops)); gq->pc.stamp = gq->upload_stamp; }
+    } else {
+        QCX_TRY(upload_ops(r, gq, all_ops));
+        if (tn.fuse_plan_cache) { gq->pc.stamp = gq->upload_stamp; gq->pc.valid = true; }
+    }
     for (size_t ai = 0; ai < acts.size(); ai++) {
         const FuseAction &act = acts[ai];
         if (!act.fused) { QCX_TRY(launch_standalone(&v, vg[act.gate])); continue; }
@@ -1778,8 +1827,20 @@ static int fuse_flush(qcx_register *r, bool keep_compact = false)
         }
         return true;
     };
+    // (the plan cache, GateQueue::pc: a flush without a front whose inputs are those of the last one takes its plan from there)
+    const bool cacheable = tn.fuse_plan_cache && !front_flush && !gen_try;
+    bool hit = false;
+    if (cacheable && gq->pc.valid && gq->pc.kind == 1 && gq->pc.n == r->n && gq->pc.M == (unsigned)r->M && gq->pc.fusion == r->fusion && gq->pc.chain == chain
+        && memcmp(&gq->pc.tn, &tn, sizeof tn) == 0 && same_gate_list(gq->pc.gates, gates)) {
+        bool needs_scratch = false;
+        for (const FuseAction &a : gq->pc.acts) needs_scratch |= a.fused && a.P.chained;
+        hit = !needs_scratch || r->scratch;
+    }
+    if (hit) { acts = gq->pc.acts; all_ops.clear(); gq->plan_hits++; }
+    else {
     fuse_plan(r, tn, gates, acts, all_ops, r->fusion == 2, chain, maxcols != 0);
     if (maxcols && !cols_shape_ok()) { maxcols = 0; acts.clear(); all_ops.clear(); fuse_plan(r, tn, gates, acts, all_ops, r->fusion == 2, chain); }
+    }
     bool chained_any = false;
     for (const FuseAction &a : acts) chained_any |= a.fused && a.P.chained;
     if (chained_any && !r->scratch) {
@@ -1820,7 +1881,19 @@ static int fuse_flush(qcx_register *r, bool keep_compact = false)
         }
         gq->gates_fused += kfront;
     }
-    QCX_TRY(upload_ops(r, gq, all_ops));
+    if (hit) {
+        // the cached records: still on the device unless something was uploaded in between
+        if (gq->pc.stamp != gq->upload_stamp) { QCX_TRY(upload_ops(r, gq, gq->pc.all_ops)); gq->pc.stamp = gq->upload_stamp; }
+    } else {
+        QCX_TRY(upload_ops(r, gq, all_ops));
+        gq->pc.valid = false;
+        if (cacheable) {
+            gq->pc.kind = 1; gq->pc.n = r->n; gq->pc.M = (unsigned)r->M; gq->pc.fusion = r->fusion; gq->pc.chain = chain; gq->pc.tn = tn;
+            gq->pc.gates = gates; gq->pc.acts = acts; gq->pc.all_ops = all_ops; gq->pc.stamp = gq->upload_stamp;
+            gq->pc.valid = true;
+        }
+    }
+    const bool any_records = hit ? !gq->pc.all_ops.empty() : !all_ops.empty();
     for (const FuseAction &act : acts) {
         if (!act.fused) { QCX_TRY(launch_standalone(r, gates[act.gate])); continue; }
         if (act.P.chained) {
@@ -1834,7 +1907,7 @@ static int fuse_flush(qcx_register *r, bool keep_compact = false)
         gq->passes_launched++;
         gq->gates_fused += act.ngates;
     }
-    if (!all_ops.empty()) {
+    if (any_records) {
         if (!gq->ev_valid) { HIP_TRY(hipEventCreateWithFlags(&gq->ev, hipEventDisableTiming)); gq->ev_valid = true; }
         HIP_TRY(hipEventRecord(gq->ev, r->stream));
     }

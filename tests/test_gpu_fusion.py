@@ -447,3 +447,75 @@ def test_exact_walk_generates_the_circuit_front(qc, ob, x8_guard, C, L, M, a):
             assert np.array_equal(bits(reg.read()), bits(want))
     finally:
         qc.tune(fuse_compact=old, fuse_gen_cols=1)
+
+
+# ---- round 5: the plan cache -------------------------------------------------------------------------------------------------
+def _plan_hits(qc, reg):
+    import ctypes as C
+    out = C.c_ulong(0)
+    qc.lib().qcx_plan_cache_stats(reg._h, C.byref(out))
+    return out.value
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["whole-circuit calls", "every gate queued", "tolerance"])
+def test_plan_cache_reuses_a_plan_only_for_identical_inputs(qc, ob, mode):
+    """a flush whose inputs are those of the last one (shape, mode, knobs, front, gate list) reuses its plan and records; anything
+    else plans afresh.  Same bits as without the cache, on different states, across interleaved other flushes."""
+    n, M, Cn, a = 17, 5, 21, 2
+    L = n - M
+    old = {k: qc.lib().qcx_tune_get(k.encode()) for k in ("fuse_plan_cache", "fuse_T")}
+    try:
+        outs = {}
+        for cache in (1, 0):
+            qc.tune(fuse_plan_cache=cache)
+            res = []
+            with qc.Register(L, M) as reg:
+                reg.set_fusion(mode)
+                h0 = _plan_hits(qc, reg)
+                # (1) the inverse QFT on three different dense states: one plan, two hits
+                for seed in (3, 4, 5):
+                    reg.fill_random(seed); qc.inverse_QFT(reg); res.append(reg.read())
+                h1 = _plan_hits(qc, reg)
+                # (2) a different list in between (a Hadamard sweep), then the inverse QFT again: planned afresh, then a hit
+                reg.fill_random(6)
+                for q in range(n):
+                    qc.hadamard_gate(q, reg)
+                res.append(reg.read())
+                reg.fill_random(7); qc.inverse_QFT(reg); res.append(reg.read())
+                reg.fill_random(8); qc.inverse_QFT(reg); res.append(reg.read())
+                h2 = _plan_hits(qc, reg)
+                # (3) a knob changes the plan: no hit
+                qc.tune(fuse_T=10 if old["fuse_T"] != 10 else 11)
+                reg.fill_random(9); qc.inverse_QFT(reg); res.append(reg.read())
+                h3 = _plan_hits(qc, reg)
+                qc.tune(fuse_T=old["fuse_T"])
+                # (4) period-finding attempts: the same circuit behind a reset, measured (compact chains); then read
+                picks = []
+                for r in (0.11, 0.52, 0.93):
+                    qc.reset_register(reg); qc.quantum_computation(Cn, a, reg); picks.append(qc.measure_state(reg, r))
+                qc.reset_register(reg); qc.quantum_computation(Cn, a, reg); res.append(reg.read())
+                h4 = _plan_hits(qc, reg)
+                # (5) a collapse to another basis state gives another front: the plan of the reset state must not be reused blindly
+                for l in range(M, n):
+                    qc.hadamard_gate(l, reg)
+                qc.inverse_QFT(reg); res.append(reg.read())
+                if cache:
+                    # (mode 0 queues only the whole-circuit calls: the sweep in between runs gate by gate and leaves the cached plan alone)
+                    assert h1 - h0 == 2 and h2 - h1 == (2 if mode == 0 else 1) and h3 == h2, (h0, h1, h2, h3)
+                    assert h4 - h3 >= 3, (h3, h4)
+                else:
+                    assert h4 == h0
+            outs[cache] = (res, picks)
+        for x, y in zip(outs[1][0], outs[0][0]):
+            assert np.array_equal(bits(x), bits(y))
+        assert outs[1][1] == outs[0][1]
+        # and against the oracle: the first inverse QFT and the circuit
+        want = ob.fill_random(n, 3); ob.iqft(want, n, M, 8)
+        w2 = np.zeros(2 << n); ob.reset(w2, n); ob.quantum_computation(w2, n, M, Cn, a, threads=8)
+        if mode == 2:
+            assert float(np.max(np.abs(outs[1][0][0] - want))) <= 1e-12 and float(np.max(np.abs(outs[1][0][7] - w2))) <= 1e-12
+        else:
+            assert np.array_equal(bits(outs[1][0][0]), bits(want)) and np.array_equal(bits(outs[1][0][7]), bits(w2))
+            assert outs[1][1][0] == ob.measure(w2.copy(), n, 0.11)
+    finally:
+        qc.tune(**old)

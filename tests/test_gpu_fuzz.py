@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-12
 KNOBS = ("fuse_T", "fuse_c", "fuse_x8", "fuse_x8_min_tiles_log2", "fuse_chain", "fuse_chain_min_n", "fuse_chain_dir", "fuse_compact",
-         "fuse_compact_lazy", "fuse_expand_fused", "fuse_gen", "fuse_gen_cols", "meas_parallel", "meas_min_log2", "meas_block_log", "meas_fast")
+         "fuse_compact_lazy", "fuse_expand_fused", "fuse_gen", "fuse_gen_cols", "fuse_plan_cache", "meas_parallel", "meas_min_log2", "meas_block_log", "meas_fast")
 
 
 def bits(a):
@@ -65,6 +65,7 @@ def one_case(qc, ob, seed):
                  fuse_x8_min_tiles_log2=int(rs.choice([0, 2])), fuse_chain=int(rs.randint(0, 4) != 0), fuse_chain_min_n=13,
                  fuse_chain_dir=int(rs.choice([-1, 0, 1])), fuse_compact=int(rs.randint(0, 5) != 0), fuse_compact_lazy=int(rs.randint(0, 3) != 0),
                  fuse_expand_fused=int(rs.randint(0, 4) != 0), fuse_gen=int(rs.randint(0, 6) != 0), fuse_gen_cols=int(rs.randint(0, 6) != 0),
+                 fuse_plan_cache=int(rs.randint(0, 4) != 0),
                  meas_parallel=1, meas_min_log2=10, meas_block_log=int(rs.choice([0, 8, 9, 11])), meas_fast=int(rs.randint(0, 4) != 0))
     kind = int(rs.randint(0, 3)) if M else 0
     # one case in five on a register SHARDED by this process (the C host: virtual shards of the one GPU): the exchange step,
@@ -79,50 +80,55 @@ def one_case(qc, ob, seed):
     scale = 1.0
     with (qc.Register(L, M, shards=shards, devices=qc.spread_devices(shards)) if shards > 1 else qc.Register(L, M)) as reg:
         reg.set_fusion(mode)
-        if kind == 0:                                   # a random program on a random dense state
-            want = ob.fill_random(n, seed & 0xFFFF); reg.fill_random(seed & 0xFFFF)
-            prog = gate_mix(rs, n, M, Cn, int(rs.randint(20, 260)), 0, float(rs.choice([0.3, 0.6, 0.9])))
-            apply(qc, ob, reg, want, n, M, Cn, prog)
-        else:                                           # behind a reset: the circuit front, then the inverse QFT (1) or a random tail on the L register (2)
-            want = np.zeros(2 << n); ob.reset(want, n)
-            qc.reset_register(reg)
-            if kind == 1:
-                qc.quantum_computation(Cn, a, reg); ob.quantum_computation(want, n, M, Cn, a, threads=8)
-            else:
-                for l in range(M, n):
-                    qc.hadamard_gate(l, reg); ob.hadamard(want, n, l, 8)
-                x = a % Cn
-                for l in range(M, n):
-                    qc.c_amodc_gate(Cn, x, l, reg); ob.camodc(want, n, M, Cn, x, l, 8); x = (x * x) % Cn
-                apply(qc, ob, reg, want, n, M, Cn, gate_mix(rs, n, M, Cn, int(rs.randint(10, 200)), M, float(rs.choice([0.5, 0.8, 0.95]))))
-        # observers, in random order; each must see the reference's state
-        for obs in rs.permutation(["read", "norm", "window", "measure", "more"])[:int(rs.randint(1, 5))]:
-            if obs == "read":
-                same(reg.read(), want, mode, tag + " read")
-            elif obs == "norm":
-                # (two different summation orders -- the oracle's is the sequential one: 1.1e-11 apart at n = 25 -- so this observer
-                #  only checks that the flush it triggers leaves the right state behind; the reads do the comparing)
-                assert abs(reg.norm2() - ob.norm2(want, n)) < 1e-9, tag + " norm"
-            elif obs == "window":
-                s = int(rs.randint(0, (1 << n) - 64)); cnt = int(rs.randint(1, min(1 << n, 5000) - 63))
-                cnt = min(cnt, (1 << n) - s)
-                same(reg.read(s, cnt), want[2 * s:2 * (s + cnt)], mode, tag + " window")
-            elif obs == "measure":
-                r = float(rs.uniform(0, 1)) if rs.randint(0, 4) else float(rs.choice([0.0, 1.0, 1e-9, 0.999999999]))
-                got = qc.measure_state(reg, r)
-                if mode == 2:
-                    # the tolerance mode's probabilities differ in the last bits: the draw must land next to the same boundary
-                    cum = np.cumsum((want.reshape(-1, 2) ** 2).sum(axis=1))
-                    lo, hi = int(np.searchsorted(cum, r - 1e-9)), int(np.searchsorted(cum, r + 1e-9))
-                    assert (r <= 0.0 and got == 0) or lo <= got <= max(hi, lo) or got == (1 << n) - 1, tag + f" measure r={r!r}: {got} not in [{lo}, {hi}]"
-                    want[:] = 0.0; want[2 * got] = 1.0
+        # the SAME circuit up to three times on the same register (different states, different observers): the plan cache's case
+        reps = int(rs.choice([1, 1, 2, 3]))
+        prog0 = gate_mix(rs, n, M, Cn, int(rs.randint(20, 260)), 0, float(rs.choice([0.3, 0.6, 0.9])))
+        tail2 = gate_mix(rs, n, M, Cn, int(rs.randint(10, 200)), M, float(rs.choice([0.5, 0.8, 0.95])))
+        for rep_i in range(reps):
+            if kind == 0:                                   # a random program on a random dense state
+                sd = (seed + 977 * rep_i) & 0xFFFF
+                want = ob.fill_random(n, sd); reg.fill_random(sd)
+                apply(qc, ob, reg, want, n, M, Cn, prog0)
+            else:                                           # behind a reset: the circuit front, then the inverse QFT (1) or a random tail on the L register (2)
+                want = np.zeros(2 << n); ob.reset(want, n)
+                qc.reset_register(reg)
+                if kind == 1:
+                    qc.quantum_computation(Cn, a, reg); ob.quantum_computation(want, n, M, Cn, a, threads=8)
                 else:
-                    assert got == ob.measure(want, n, r), tag + f" measure r={r!r}"
-                same(reg.read(), want, 0, tag + " collapsed state")
-            else:
-                prog = gate_mix(rs, n, M, Cn, int(rs.randint(1, 60)), 0, 0.6)
-                apply(qc, ob, reg, want, n, M, Cn, prog)
-                same(reg.read(), want, mode, tag + " more gates")
+                    for l in range(M, n):
+                        qc.hadamard_gate(l, reg); ob.hadamard(want, n, l, 8)
+                    x = a % Cn
+                    for l in range(M, n):
+                        qc.c_amodc_gate(Cn, x, l, reg); ob.camodc(want, n, M, Cn, x, l, 8); x = (x * x) % Cn
+                    apply(qc, ob, reg, want, n, M, Cn, tail2)
+            # observers, in random order; each must see the reference's state
+            for obs in rs.permutation(["read", "norm", "window", "measure", "more"])[:int(rs.randint(1, 5))]:
+                if obs == "read":
+                    same(reg.read(), want, mode, tag + " read")
+                elif obs == "norm":
+                    # (two different summation orders -- the oracle's is the sequential one: 1.1e-11 apart at n = 25 -- so this observer
+                    #  only checks that the flush it triggers leaves the right state behind; the reads do the comparing)
+                    assert abs(reg.norm2() - ob.norm2(want, n)) < 1e-9, tag + " norm"
+                elif obs == "window":
+                    s = int(rs.randint(0, (1 << n) - 64)); cnt = int(rs.randint(1, min(1 << n, 5000) - 63))
+                    cnt = min(cnt, (1 << n) - s)
+                    same(reg.read(s, cnt), want[2 * s:2 * (s + cnt)], mode, tag + " window")
+                elif obs == "measure":
+                    r = float(rs.uniform(0, 1)) if rs.randint(0, 4) else float(rs.choice([0.0, 1.0, 1e-9, 0.999999999]))
+                    got = qc.measure_state(reg, r)
+                    if mode == 2:
+                        # the tolerance mode's probabilities differ in the last bits: the draw must land next to the same boundary
+                        cum = np.cumsum((want.reshape(-1, 2) ** 2).sum(axis=1))
+                        lo, hi = int(np.searchsorted(cum, r - 1e-9)), int(np.searchsorted(cum, r + 1e-9))
+                        assert (r <= 0.0 and got == 0) or lo <= got <= max(hi, lo) or got == (1 << n) - 1, tag + f" measure r={r!r}: {got} not in [{lo}, {hi}]"
+                        want[:] = 0.0; want[2 * got] = 1.0
+                    else:
+                        assert got == ob.measure(want, n, r), tag + f" measure r={r!r}"
+                    same(reg.read(), want, 0, tag + " collapsed state")
+                else:
+                    prog = gate_mix(rs, n, M, Cn, int(rs.randint(1, 60)), 0, 0.6)
+                    apply(qc, ob, reg, want, n, M, Cn, prog)
+                    same(reg.read(), want, mode, tag + " more gates")
     return scale
 
 

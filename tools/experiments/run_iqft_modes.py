@@ -7,6 +7,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import quantumcomputer_amd as qc  # noqa: E402
 
+if len(sys.argv) > 1:
+    qc.tune(**{k: int(v) for k, v in (kv.split("=") for kv in sys.argv[1:])})
 with qc.Register(28, 0) as reg:
     for mode in (0, 2):
         reg.set_fusion(mode)

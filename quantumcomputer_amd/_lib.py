@@ -116,6 +116,7 @@ _EXTRA = {
     "qcx_compact_measure_stats": (_i, [_p, C.POINTER(_ul)]),
     "qcx_expanding_store_stats": (_i, [_p, C.POINTER(_ul)]),
     "qcx_plan_cache_stats": (_i, [_p, C.POINTER(_ul)]),
+    "qcx_expand_store_plan": (_i, [_u, _p, _p, _u, _u, _p, _p, _p, C.POINTER(_i)]),
 }
 
 

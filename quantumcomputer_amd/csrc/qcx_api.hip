@@ -1379,6 +1379,23 @@ extern "C" int qcx_compact_stats(qcx_register *r, unsigned long *compact_chains)
     return QCX_NO_ERROR;
 }
 
+// host logic only (no GPU): the expanding-store tables compact_chain would give the last pass of a compact chain -- T = 12, the
+// pass's store order (st_pos / st_loc as qcx_fusion_plan reports them for the plan of the VIRTUAL register, mode | 8), an M
+// register of M bits and cb column bits.  *ok = 0: that pass does not qualify (the separate expansion runs).
+extern "C" int qcx_expand_store_plan(unsigned T, const unsigned char *st_pos, const unsigned char *st_loc, unsigned M, unsigned cb,
+                                     unsigned char *xp_pos24, unsigned char *xp_loc24, unsigned char *xp_colloc4, int *ok)
+{
+    if (!st_pos || !st_loc || !xp_pos24 || !xp_loc24 || !xp_colloc4 || !ok || T > 16) return QCX_BAD_ARGUMENTS;
+    FusePass P;
+    memset(&P, 0, sizeof P);
+    P.T = T;
+    memcpy(P.st_pos, st_pos, 16); memcpy(P.st_loc, st_loc, 16);
+    const std::vector<uint16_t> none;
+    *ok = xp_setup(P, M, cb, none) ? 1 : 0;
+    memcpy(xp_pos24, P.xp_pos, 24); memcpy(xp_loc24, P.xp_loc, 24); memcpy(xp_colloc4, P.xp_colloc, 4);
+    return QCX_NO_ERROR;
+}
+
 // diagnostics: flushes that took their plan from the plan cache (GateQueue::pc)
 extern "C" int qcx_plan_cache_stats(qcx_register *r, unsigned long *hits)
 {

@@ -1570,6 +1570,21 @@ static int expand_pending(qcx_register *r)
     return QCX_NO_ERROR;
 }
 
+// the expanding store of a compact chain's last pass (FusePass::xp_*; k_fused_x8): possible when the pass's output order starts
+// with the column bits (they are the cb lowest bits of the virtual register and all inside the tile).  An expanded store
+// index is [the tile's store-order bits above the column bits][f: M bits]; bit i >= M of it lands on REAL index bit
+// st_pos - cb + M and selects tile-local bit st_loc of the store-order bit it stands for.
+static bool xp_setup(FusePass &PL, unsigned M, unsigned cb, const std::vector<uint16_t> &orbit)
+{
+    if (PL.T != 12 || M > 9 || cb > 4 || cb > PL.T || orbit.size() > 16 || M + PL.T - cb > 24) return false;
+    for (unsigned j = 0; j < cb; j++) if (PL.st_pos[j] != j) return false;
+    PL.xp_on = 1; PL.xp_M = (uint8_t)M; PL.xp_cb = (uint8_t)cb; PL.xp_ncols = (uint8_t)orbit.size();
+    for (size_t j = 0; j < orbit.size(); j++) PL.xp_orbit[j] = orbit[j];
+    for (unsigned j = 0; j < cb; j++) PL.xp_colloc[j] = PL.st_loc[j];
+    for (unsigned i = M; i < M + PL.T - cb; i++) { PL.xp_pos[i] = (uint8_t)(PL.st_pos[cb + i - M] - cb + M); PL.xp_loc[i] = PL.st_loc[cb + i - M]; }
+    return true;
+}
+
 // keep: leave the result in its compact form (r->compact_pending; measure_state reads it there, everything else expands it first)
 static int compact_chain(qcx_register *r, GateQueue *gq, const Tune &tn, const BasisFront &Bf, size_t kfront, const std::vector<QGate> &gates, bool keep, bool *done)
 {
@@ -1685,13 +1700,7 @@ static int compact_chain(qcx_register *r, GateQueue *gq, const Tune &tn, const B
     bool expanded = false, deferred = false;
     if (tn.fuse_expand_fused && acts.size() > 1 && acts.back().fused && pass_is_x8(acts.back().P, tn) && M <= 9 && cb <= 4) {
         FusePass PL = acts.back().P;
-        bool ok = true;
-        for (unsigned j = 0; j < cb; j++) if (PL.st_pos[j] != j) ok = false;
-        if (ok) {
-            PL.xp_on = 1; PL.xp_M = (uint8_t)M; PL.xp_cb = (uint8_t)cb; PL.xp_ncols = (uint8_t)orbit.size();
-            for (size_t j = 0; j < orbit.size(); j++) PL.xp_orbit[j] = orbit[j];
-            for (unsigned j = 0; j < cb; j++) PL.xp_colloc[j] = PL.st_loc[j];
-            for (unsigned i = M; i < M + PL.T - cb; i++) { PL.xp_pos[i] = (uint8_t)(PL.st_pos[cb + i - M] - cb + M); PL.xp_loc[i] = PL.st_loc[cb + i - M]; }
+        if (xp_setup(PL, M, cb, orbit)) {
             if (keep) {
                 deferred = true;
                 gq->last.P = acts.back().P; gq->last.Pxp = PL;

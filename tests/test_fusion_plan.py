@@ -594,3 +594,68 @@ def test_compact_register_premise(qc, ob, chain_guard, C, L, M, a, mode):
     else:
         assert float(np.max(np.abs(got - want))) <= 1e-12
     assert not np.any(cc[(np.arange(1 << nv) & ((1 << cb) - 1)) >= len(orbit)]), "unused columns stay zero"
+
+
+# ---- round 5: the expanding store of a compact chain's last pass (FusePass::xp_*, k_fused_x8) -----------------------------------
+@pytest.mark.parametrize("mode", [1, 2], ids=["exact", "tolerance"])
+@pytest.mark.parametrize("C,L,M,a", [(21, 25, 5, 2), (21, 19, 5, 2), (15, 16, 4, 7), (255, 15, 8, 2), (35, 20, 6, 2)])
+def test_expanding_store_tables_address_the_real_register(qc, chain_guard, C, L, M, a, mode):
+    """what compact_chain hands the last pass of a chain so that it writes the REAL register itself, without a GPU: the planner's
+    last action on the virtual register [L register][orbit column] (mode | 8), the host's tables for it (qcx_expand_store_plan),
+    and the kernel's store loop restated here.  Every store index of a tile must land on the real index of the amplitude it
+    carries -- (L part << M) | orbit[column] for the threads whose f lies on the orbit, a +0 everywhere else -- and the stores of
+    a tile must cover its 2^(T - cb + M) real amplitudes exactly once."""
+    import ctypes as Ct
+    orbit = sorted({pow(a, e, C) for e in range(4 * C)})
+    cb = max(2, (len(orbit) - 1).bit_length())
+    nv = L + cb
+    acts, recs, _ = qc.fusion_plan(nv, cb, iqft_descs(qc, nv, cb), mode | 4 | 8)
+    last = acts[-1]
+    st_pos = (Ct.c_ubyte * 16)(*last.st_pos); st_loc = (Ct.c_ubyte * 16)(*last.st_loc)
+    xp_pos, xp_loc, xp_col = (Ct.c_ubyte * 24)(), (Ct.c_ubyte * 24)(), (Ct.c_ubyte * 4)()
+    ok = Ct.c_int(-1)
+    assert qc.lib().qcx_expand_store_plan(last.T, st_pos, st_loc, M, cb, xp_pos, xp_loc, xp_col, Ct.byref(ok)) == 0
+    kinds = {recs[last.rec_off + k].type & 0xFF for k in range(last.nops)} if last.fused else set()
+    if not (last.fused and last.T == 12 and list(last.st_pos[:cb]) == list(range(cb))):
+        assert ok.value == 0 or not last.fused
+        pytest.skip("the plan's last action does not qualify for the expanding store")
+    assert ok.value == 1 and kinds & {8, 9}
+    T, LB = 12, 9                                           # 2^12 tile, 512 threads
+    tl = list(last.tl[:T])                                  # tile-local bit j carries virtual qubit tl[j]
+    ebits = T - cb + M
+    e = np.arange(1 << ebits, dtype=np.int64)
+    thread, it = e & 511, e >> LB
+    f = thread & ((1 << M) - 1)
+    off = f.copy(); loc = np.zeros_like(e)
+    for i in range(M, LB):                                  # the thread's bits above f
+        on = (thread >> i) & 1
+        off |= on << xp_pos[i]; loc |= on << xp_loc[i]
+    for b in range(ebits - LB):                             # the iteration's bits
+        on = (it >> b) & 1
+        off |= on << xp_pos[LB + b]; loc |= on << xp_loc[LB + b]
+    col_of = {v: j for j, v in enumerate(orbit)}
+    col = np.array([col_of.get(int(v), -1) for v in range(1 << M)])[f]
+    live = col >= 0
+    for b in range(cb):
+        loc |= np.where(live, ((col >> b) & 1) << xp_col[b], 0)
+    # (1) the stores of a tile cover its real amplitudes exactly once: the offsets are 2^ebits distinct values made of the M low
+    #     bits and the real positions of the tile's L-register qubits
+    real_bits = sorted([q - cb + M for q in tl if q >= cb])
+    span = set(range(M)) | set(real_bits)
+    assert len(np.unique(off)) == e.size and all(int(o) & ~sum(1 << p for p in span) == 0 for o in off[:: 97])
+    # (2) a live store carries the tile element whose qubits spell the same L part, in its column
+    want = np.zeros_like(e)
+    for j in range(T):
+        q = tl[j]
+        bitj = (loc >> j) & 1
+        if q >= cb:
+            want |= bitj << (q - cb + M)
+    want_live = want | np.array(orbit + [0] * 16)[np.clip(col, 0, None)]
+    assert np.array_equal(off[live], want_live[live])
+    colbits = np.zeros_like(e)
+    for j in range(T):
+        if tl[j] < cb:
+            colbits |= ((loc >> j) & 1) << tl[j]
+    assert np.array_equal(colbits[live], col[live])
+    # (3) and every element of the compact tile that holds an orbit column leaves exactly once
+    assert len(np.unique(loc[live])) == int(live.sum()) == len(orbit) << (T - cb)

@@ -845,6 +845,8 @@ struct qcx_register {
     unsigned   n_events;
     amp_t     *scratch;         // second buffer, allocated on first use (chained passes)
     int        no_chain;        // the buffer pointer was handed out (qcx_device_pointer) or no second buffer fits: passes work in place
+    int        nonfinite;       // the caller wrote a component that is not finite (or >= 2^500): every gate runs as a STRICT pass (K9: the
+                                // mat-vec's own products, identity rows included) until a reset, a fill or a measurement replaces the state
     int        zeros_dirty;     // the caller wrote amplitudes (qcx_state_write / _load): they may hold -0, which the reference's gates would
                                 // canonicalise (Q:393-413); one k_canon_zeros pass runs before the next gate
     int        fusion;          // 1: every gate call is queued (fused passes, qcx_fuse.inc.h); 0: only the whole-circuit entry points; -1: nothing
@@ -1439,11 +1441,50 @@ extern "C" int qcx_synchronize(qcx_register *r)
     return QCX_NO_ERROR;
 }
 
+// ---- strict gates (K9): a register that was handed non-finite amplitudes -------------------------------------------------------
+// did the caller just write something that is not finite (or >= 2^500) into [first, first + count)?  (scanned on the device)
+static int note_nonfinite(qcx_register *r, uint64_t first, uint64_t count)
+{
+    if (!count || r->nonfinite) return QCX_NO_ERROR;
+    Workspace *w;
+    QCX_TRY(workspace(&w));
+    std::lock_guard<std::mutex> use(g_ws_use[w - g_ws]);
+    HIP_TRY(hipMemsetAsync(w->meas_stats, 0, sizeof(unsigned), r->stream));
+    hipLaunchKernelGGL(k_scan_nonfinite, dim3(grid_for(count, 256 * 8, 65536, 256)), dim3(256), 0, r->stream, (const amp_t *)(r->amp + first), count, w->meas_stats);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(w->h_meas_stats, w->meas_stats, sizeof(unsigned), hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    if (w->h_meas_stats[0]) r->nonfinite = 1;
+    w->h_meas_stats[0] = 0;
+    return QCX_NO_ERROR;
+}
+
+static int strict_gate(qcx_register *r, const QGate &g)
+{
+    FLUSH(r);                                       // (nothing is queued in this mode; a pending reset would have cleared it)
+    r->zeros_dirty = 0;                             // every strict pass rewrites every amplitude as 0 + ...: canonical zeros
+    const uint64_t dim = r->dim;
+    if (g.type == FUSE_H) {
+        if (r->n < 1) return QCX_BAD_ARGUMENTS;
+        hipLaunchKernelGGL(k_strict_h, dim3(grid_for(dim >> 1, 256, 65536, 256)), dim3(256), 0, r->stream, r->amp, r->n, g.q, M_SQRT1_2, 0.0);
+    } else if (g.type == FUSE_PHASE) {
+        hipLaunchKernelGGL(k_strict_phase, dim3(grid_for(dim, 256, 65536, 256)), dim3(256), 0, r->stream, r->amp, dim, g.mask, g.c, g.s, 1.0, 0.0);
+    } else {
+        const unsigned M = (unsigned)r->M;
+        if (M > 12) { set_error("c_amodc_gate on a state with non-finite amplitudes: M = %u > 12 is not supported", M); return QCX_UNSUPPORTED; }
+        const size_t lds = ((size_t)16 << M) + ((size_t)2 << M);
+        hipLaunchKernelGGL(k_strict_camodc, dim3(grid_for(dim >> M, 1, 65536, 256)), dim3(256), lds, r->stream, r->amp, r->n, M, g.C, g.A, (int)g.q, 1.0, 0.0);
+    }
+    HIP_TRY(hipGetLastError());
+    return QCX_NO_ERROR;
+}
+
 extern "C" int qcx_reset_register(qcx_register *r)
 {
     if (!r) return QCX_BAD_ARGUMENTS;
     if (r->sh) return sh_reset(r->sh);
     if (r->queue) r->queue->gates.clear();         // pending gates act on a state that is being overwritten
+    r->nonfinite = 0;
     r->zeros_dirty = 0;
     r->compact_pending = 0;
     if (r->fusion >= 0 && r->n >= 1) {             // lazily: the write happens at the next flush, fused with the circuit front (K0b)
@@ -1459,6 +1500,7 @@ extern "C" int qcx_hadamard_gate(unsigned q, qcx_register *r)
     if (!r) return QCX_BAD_ARGUMENTS;
     if (q >= r->n) return QCX_BAD_QUBIT;
     if (r->sh) { SGate g; memset(&g, 0, sizeof g); g.type = FUSE_H; g.q = q; return sh_push(r->sh, g); }
+    if (r->nonfinite) { QGate g; memset(&g, 0, sizeof g); g.type = FUSE_H; g.q = q; return strict_gate(r, g); }
     if (r->fusion > 0 || r->composite) { QGate g; memset(&g, 0, sizeof g); g.type = FUSE_H; g.q = q; return fuse_push(r, g); }
     FLUSH(r);                                         // (a lazily pending reset / collapse is written first)
     QCX_TRY(canon_if_dirty(r));
@@ -1484,6 +1526,11 @@ extern "C" int qcx_c_phase_shift_gate(unsigned c, unsigned t, double theta, qcx_
     double er, ei;
     qcx_polar(theta, &er, &ei);
     if (r->sh) { SGate g; memset(&g, 0, sizeof g); g.type = FUSE_PHASE; g.q = c; g.q2 = t; g.c = er; g.s = ei; return sh_push(r->sh, g); }
+    if (r->nonfinite) {
+        QGate g; memset(&g, 0, sizeof g);
+        g.type = FUSE_PHASE; g.mask = ((uint64_t)1 << c) | ((uint64_t)1 << t); g.c = er; g.s = ei;
+        return strict_gate(r, g);
+    }
     if (r->fusion > 0 || r->composite) {
         QGate g; memset(&g, 0, sizeof g);
         g.type = FUSE_PHASE; g.mask = ((uint64_t)1 << c) | ((uint64_t)1 << t); g.c = er; g.s = ei;
@@ -1499,6 +1546,7 @@ extern "C" int qcx_c_amodc_gate(unsigned C, unsigned long long atox, unsigned c,
     if (!r || C == 0) return QCX_BAD_ARGUMENTS;
     if (c >= r->n) return QCX_BAD_QUBIT;
     if (r->sh) { SGate g; memset(&g, 0, sizeof g); g.type = FUSE_CAMODC; g.q = c; g.C = C; g.A = (unsigned)(atox % C); return sh_push(r->sh, g); }
+    if (r->nonfinite) { QGate g; memset(&g, 0, sizeof g); g.type = FUSE_CAMODC; g.q = c; g.C = C; g.A = (unsigned)(atox % C); return strict_gate(r, g); }
     if (r->fusion > 0 || r->composite) {
         QGate g; memset(&g, 0, sizeof g);
         g.q = c; g.C = C; g.A = (unsigned)(atox % C);
@@ -1615,6 +1663,7 @@ extern "C" int qcx_measure_state_r(qcx_register *r, double rnd, unsigned long *s
     QCX_TRY(qcx_shard_measure_scan(r->amp, r->n, 0, r->dim - 1, 0.0, rnd, &found, &idx, &cum, r->stream));
     if (!found) idx = r->dim - 1;                                           // Q:283 fall-through
     r->zeros_dirty = 0;                                                     // (the collapse replaces the whole state)
+    r->nonfinite = 0;
     if (r->fusion >= 0) { r->basis_pending = 1; r->basis_index = idx; }     // Q:302-303, written at the next flush (or never: a reset may follow)
     else QCX_TRY(qcx_shard_collapse(r->amp, r->n, (int64_t)idx, r->stream));
     *state_num = (unsigned long)idx;
@@ -1645,7 +1694,11 @@ extern "C" int qcx_state_write(qcx_register *r, unsigned long first, unsigned lo
     if (r->sh) return sh_copy(r->sh, first, count, const_cast<double *>(in), false);
     FLUSH(r);
     HIP_TRY(hipStreamSynchronize(r->stream));
-    if (count) { HIP_TRY(hipMemcpy(r->amp + first, in, (size_t)count * sizeof(amp_t), hipMemcpyHostToDevice)); r->zeros_dirty = 1; }
+    if (count) {
+        HIP_TRY(hipMemcpy(r->amp + first, in, (size_t)count * sizeof(amp_t), hipMemcpyHostToDevice));
+        r->zeros_dirty = 1;
+        QCX_TRY(note_nonfinite(r, first, count));
+    }
     return QCX_NO_ERROR;
 }
 
@@ -1735,6 +1788,7 @@ extern "C" int qcx_state_load(qcx_register *r, const char *path)
     fclose(f);
     if (st == QCX_NO_ERROR && sum != h.checksum) st = QCX_UNKNOWN_ERROR;
     if (st != QCX_NO_ERROR) set_error("qcx_state_load: %s is truncated or corrupt (the register now holds a partial copy)", path);
+    if (!r->sh) { const int nf = note_nonfinite(r, 0, r->dim); if (st == QCX_NO_ERROR) st = nf; }
     return st;
 }
 
@@ -1781,6 +1835,7 @@ extern "C" int qcx_state_fill_random(qcx_register *r, uint64_t seed)
     if (r->queue) r->queue->gates.clear();
     r->basis_pending = 0;                           // everything is overwritten
     r->compact_pending = 0;
+    r->nonfinite = 0;
     r->zeros_dirty = 0;
     // U(-0.5, 0.5) components have variance 1/12: this scale makes the expected norm 1
     return qcx_shard_fill_random(r->amp, r->n, 0, seed, sqrt(6.0 / (double)r->dim), r->stream);

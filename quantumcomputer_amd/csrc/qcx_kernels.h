@@ -381,6 +381,85 @@ __global__ __launch_bounds__(256) void k_fill_random(amp_t *__restrict__ amp, ui
 // (qcx_state_write / qcx_state_load) may break it, and is passed through this kernel once before the next gate.
 // Reads everything, stores only the amplitudes that change.
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// K9  STRICT gates for states that hold non-finite (or overflow-prone) amplitudes (round 5).  The gate kernels above give the
+// reference's bits for every FINITE state while skipping what the reference's mat-vec spends on nothing: the products with
+// the matrix entries' zero imaginary parts, and the rows whose entry is 1.  With an Inf or NaN in the state those are not
+// nothing: 0 * Inf = NaN poisons the other component of the SAME amplitude, through an identity row too (Q:409-412 runs
+// over every stored triplet).  A register that was handed such values (qcx_state_write / _load; the host sets
+// qcx_register::nonfinite from a scan of what was written) runs every gate through these kernels instead -- one plain pass
+// per gate over ALL amplitudes with the mat-vec's own four products and sums per triplet (the oracle's pairwise forms,
+// oracle/qcx_oracle.c, line for line) -- until a reset, a fill or a measurement replaces the state.  z and one arrive as
+// kernel arguments so that no compiler ever folds a product with them.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_strict_h(amp_t *__restrict__ amp, unsigned n, unsigned q, double s, double z)
+{
+    const uint64_t half = (uint64_t)1 << (n - 1), bitq = (uint64_t)1 << q, low = bitq - 1;
+    for (uint64_t p = (uint64_t)blockIdx.x * 256u + threadIdx.x; p < half; p += (uint64_t)gridDim.x * 256u) {
+        const uint64_t i0 = ((p & ~low) << 1) | (p & low), i1 = i0 | bitq;
+        const amp_t a = amp[i0], b = amp[i1];
+        double lo_r = 0.0, lo_i = 0.0, hi_r = 0.0, hi_i = 0.0;
+        lo_r += (s * a.x) - (z * a.y);    lo_i += (s * a.y) + (z * a.x);        // row i0, column i0
+        lo_r += (s * b.x) - (z * b.y);    lo_i += (s * b.y) + (z * b.x);        // row i0, column i1
+        hi_r += (s * a.x) - (z * a.y);    hi_i += (s * a.y) + (z * a.x);        // row i1, column i0
+        hi_r += (-s * b.x) - (z * b.y);   hi_i += (-s * b.y) + (z * b.x);       // row i1, column i1
+        amp_t lo, hi; lo.x = lo_r; lo.y = lo_i; hi.x = hi_r; hi.y = hi_i;
+        amp[i0] = lo; amp[i1] = hi;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_strict_phase(amp_t *__restrict__ amp, uint64_t count, uint64_t both, double er, double ei, double one, double z)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256u) {
+        const amp_t v = amp[i];
+        double nr = 0.0, ni = 0.0;
+        if ((i & both) == both) { nr += (er * v.x) - (ei * v.y);   ni += (er * v.y) + (ei * v.x); }
+        else                    { nr += (one * v.x) - (z * v.y);   ni += (one * v.y) + (z * v.x); }
+        amp_t o; o.x = nr; o.y = ni;
+        amp[i] = o;
+    }
+}
+
+// one workgroup per 2^M-block (M <= 12: the block and the destination of every row sit in LDS); destination g sums its sources
+// in ascending row order, every row of the block is written (the identity rows too: their entry 1 is a triplet like any other)
+__global__ __launch_bounds__(256) void k_strict_camodc(amp_t *__restrict__ amp, unsigned n, unsigned M, unsigned C, unsigned A, int ctl, double one, double z)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qcx_lds_raw[];
+    amp_t *blk = reinterpret_cast<amp_t *>(qcx_lds_raw);
+    const unsigned B = 1u << M;
+    unsigned short *dst_on = reinterpret_cast<unsigned short *>(blk + B);         // destination of row f when its control reads 1
+    for (unsigned f = threadIdx.x; f < B; f += 256u) dst_on[f] = (unsigned short)(f < C ? ((unsigned)(A * f) % C) & (B - 1u) : f);   // Q:645-647
+    const uint64_t nblk = (uint64_t)1 << (n - M);
+    for (uint64_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+        amp_t *g = amp + (b << M);
+        __syncthreads();
+        for (unsigned f = threadIdx.x; f < B; f += 256u) blk[f] = g[f];
+        __syncthreads();
+        const int on = (ctl >= (int)M) ? (int)(((b << M) >> ctl) & 1u) : -1;      // -1: the control is a bit of the row
+        for (unsigned d = threadIdx.x; d < B; d += 256u) {
+            double ar = 0.0, ai = 0.0;
+            for (unsigned f = 0; f < B; f++) {
+                const bool cbit = on >= 0 ? on != 0 : ((f >> ctl) & 1u) != 0;
+                const unsigned to = cbit ? dst_on[f] : f;
+                if (to == d) { const amp_t v = blk[f]; ar += (one * v.x) - (z * v.y); ai += (one * v.y) + (z * v.x); }
+            }
+            amp_t o; o.x = ar; o.y = ai;
+            g[d] = o;
+        }
+    }
+}
+
+// does [amp, amp + count) hold a component that is not finite, or so large (>= 2^500) that a circuit could overflow from it?
+__global__ __launch_bounds__(256) void k_scan_nonfinite(const amp_t *__restrict__ amp, uint64_t count, unsigned *flag)
+{
+    bool bad = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256u) {
+        const amp_t v = amp[i];
+        bad |= !(fabs(v.x) < 0x1p500) || !(fabs(v.y) < 0x1p500);
+    }
+    if (__ballot(bad) && (threadIdx.x & 63u) == 0u) atomicOr(flag, 1u);
+}
+
 __global__ __launch_bounds__(256) void k_canon_zeros(amp_t *__restrict__ amp, uint64_t count)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256) {

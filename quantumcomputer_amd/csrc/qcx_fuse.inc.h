@@ -120,6 +120,8 @@ struct GateQueue {
         unsigned n = 0, M = 0;
         int      fusion = 0;
         bool     chain = false;
+        bool     front_flush = false, gen_try = false;      // kind 1: the flush stood behind a lazily pending basis state / generated its front
+        bool     gen_built = false, gen2 = false;           // ... and how that went (what a hit replays)
         Tune     tn;
         BasisFront Bf;
         size_t   kfront = 0;
@@ -1836,10 +1838,13 @@ static int fuse_flush(qcx_register *r, bool keep_compact = false)
         }
         return true;
     };
-    // (the plan cache, GateQueue::pc: a flush without a front whose inputs are those of the last one takes its plan from there)
-    const bool cacheable = tn.fuse_plan_cache && !front_flush && !gen_try;
+    // (the plan cache, GateQueue::pc: a flush whose inputs are those of the last one -- the front it stands behind included --
+    //  takes its plan from there)
+    const bool cacheable = tn.fuse_plan_cache != 0;
     bool hit = false;
     if (cacheable && gq->pc.valid && gq->pc.kind == 1 && gq->pc.n == r->n && gq->pc.M == (unsigned)r->M && gq->pc.fusion == r->fusion && gq->pc.chain == chain
+        && gq->pc.front_flush == front_flush && gq->pc.gen_try == gen_try
+        && (!gen_try || (gq->pc.kfront == kfront && memcmp(&gq->pc.Bf, &Bf, sizeof Bf) == 0))
         && memcmp(&gq->pc.tn, &tn, sizeof tn) == 0 && same_gate_list(gq->pc.gates, gates)) {
         bool needs_scratch = false;
         for (const FuseAction &a : gq->pc.acts) needs_scratch |= a.fused && a.P.chained;
@@ -1865,20 +1870,31 @@ static int fuse_flush(qcx_register *r, bool keep_compact = false)
     // an inverse QFT touches the M register: whole waves of a tile hold nothing but +0.  Passes of such a flush map their wave
     // number onto M-register bits of the tile and let all-zero waves skip the rounds (FusePass::zskip; found at run time, so
     // any state is handled correctly)
-    if (front_flush && tn.fuse_zskip && r->M >= 2) {
+    if (!hit && front_flush && tn.fuse_zskip && r->M >= 2) {
         bool h_on_m = false;
         for (const QGate &g : gates) h_on_m |= (g.type == FUSE_H && g.q < (unsigned)r->M) || g.type == FUSE_CAMODC || g.type == 99;
         if (!h_on_m) zskip_setup(acts, all_ops, (unsigned)r->M, tn, maxcols != 0);
     }
-    if (gen_try) {
+    bool gen_built = false, gen2 = false;
+    if (gen_try && hit) {                            // what the cached flush did with its front, again
+        if (gq->pc.gen_built) {
+            r->basis_pending = 0; r->fronts++; gq->gen_fronts++; r->zeros_dirty = 0;
+            if (gq->pc.gen2) gq->gen_cols++;
+        } else {
+            QCX_TRY(launch_front(r, Bf, kfront));
+            r->zeros_dirty = 0;
+        }
+        gq->gates_fused += kfront;
+    } else if (gen_try) {
         GenFront G;
         if (!acts.empty() && gen_front_build(r->n, (unsigned)r->M, Bf, acts[0], &G)) {
+            gen_built = true;
             const size_t at = all_ops.size(), nrec = (sizeof(GenFront) + sizeof(FuseOp) - 1) / sizeof(FuseOp);
             all_ops.resize(at + nrec);
             memset(&all_ops[at], 0, nrec * sizeof(FuseOp));
             memcpy(&all_ops[at], &G, sizeof G);
             acts[0].P.gen = 1;
-            if (maxcols && G.cmpmask == (1u << r->M) - 1u && G.h == 8) { acts[0].P.gen = 2; acts[0].P.zpad = (uint16_t)maxcols; gq->gen_cols++; }
+            if (maxcols && G.cmpmask == (1u << r->M) - 1u && G.h == 8) { acts[0].P.gen = 2; acts[0].P.zpad = (uint16_t)maxcols; gq->gen_cols++; gen2 = true; }
             acts[0].P.gen_rec_off = (uint32_t)(at - acts[0].op_off);
             r->basis_pending = 0;                                 // (the pass that generates it is launched below; a failed launch returns its error)
             r->fronts++;
@@ -1898,6 +1914,8 @@ static int fuse_flush(qcx_register *r, bool keep_compact = false)
         gq->pc.valid = false;
         if (cacheable) {
             gq->pc.kind = 1; gq->pc.n = r->n; gq->pc.M = (unsigned)r->M; gq->pc.fusion = r->fusion; gq->pc.chain = chain; gq->pc.tn = tn;
+            gq->pc.front_flush = front_flush; gq->pc.gen_try = gen_try; gq->pc.gen_built = gen_built; gq->pc.gen2 = gen2;
+            if (gen_try) { gq->pc.Bf = Bf; gq->pc.kfront = kfront; }
             gq->pc.gates = gates; gq->pc.acts = acts; gq->pc.all_ops = all_ops; gq->pc.stamp = gq->upload_stamp;
             gq->pc.valid = true;
         }

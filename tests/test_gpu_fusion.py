@@ -457,11 +457,11 @@ def _plan_hits(qc, reg):
     return out.value
 
 
+@pytest.mark.parametrize("n,M,Cn,a", [(17, 5, 21, 2), (13, 4, 15, 7), (9, 4, 15, 7)], ids=["n=17: compact chains", "n=13: front generated in the first pass", "n=9: front written by its own pass"])
 @pytest.mark.parametrize("mode", [0, 1, 2], ids=["whole-circuit calls", "every gate queued", "tolerance"])
-def test_plan_cache_reuses_a_plan_only_for_identical_inputs(qc, ob, mode):
+def test_plan_cache_reuses_a_plan_only_for_identical_inputs(qc, ob, mode, n, M, Cn, a):
     """a flush whose inputs are those of the last one (shape, mode, knobs, front, gate list) reuses its plan and records; anything
     else plans afresh.  Same bits as without the cache, on different states, across interleaved other flushes."""
-    n, M, Cn, a = 17, 5, 21, 2
     L = n - M
     old = {k: qc.lib().qcx_tune_get(k.encode()) for k in ("fuse_plan_cache", "fuse_T")}
     try:

@@ -198,6 +198,7 @@ struct Workspace {
     double     *partials = nullptr;     // NORM_BLOCKS doubles + 1
     MeasureOut *mout = nullptr;
     MeasureOut *h_mout = nullptr;       // pinned
+    bool        meas_clean = false;     // the last parallel scan completed: its walk kernel left ticket and candidate count at zero
     double     *h_scalar = nullptr;     // pinned
     uint32_t   *tab = nullptr;          // camodc CSR table (off + srcs)
     size_t      tab_cap = 0;
@@ -768,7 +769,7 @@ extern "C" int qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_
             std::lock_guard<std::mutex> lock(g_ws_mutex);
             if (w->meas_cap < nblocks) {
                 if (w->meas_blocks) { HIP_TRY(hipFree(w->meas_blocks)); HIP_TRY(hipFree(w->meas_look)); HIP_TRY(hipFree(w->meas_up)); }
-                w->meas_blocks = nullptr; w->meas_cap = 0;
+                w->meas_blocks = nullptr; w->meas_cap = 0; w->meas_clean = false;
                 w->meas_look = nullptr; w->meas_up = nullptr;
                 HIP_TRY(hipMalloc(&w->meas_blocks, ((size_t)nblocks + 4) * sizeof(MeasBlock)));
                 HIP_TRY(hipMalloc(&w->meas_look, (2 * (size_t)nblocks + 4 * ((size_t)nblocks / 64 + 2) + 8) * sizeof(meas_slot_t)));
@@ -780,9 +781,11 @@ extern "C" int qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_
             const unsigned nwg = (nblocks + 3u) / 4u, ngrp = (nwg + 63u) / 64u;
             MeasLookback LB;
             LB.agg = w->meas_look; LB.incl = LB.agg + nwg; LB.gsum = LB.incl + nwg; LB.gincl = LB.gsum + ngrp;
-            LB.ticket = reinterpret_cast<unsigned *>(LB.gincl + ngrp);
+            LB.ticket = w->meas_cands->ticket;                       // (a fixed address: the scan's last kernel leaves it at zero for the next one)
             HIP_TRY(hipMemsetAsync(w->meas_look, 0xff, (2 * (size_t)nwg + 2 * (size_t)ngrp) * sizeof(meas_slot_t), st));
-            HIP_TRY(hipMemsetAsync(LB.ticket, 0, 2 * sizeof(meas_slot_t), st));
+            const bool clean = w->meas_clean;
+            w->meas_clean = false;                                  // (true again when this call has completed)
+            if (!clean) HIP_TRY(hipMemsetAsync(w->meas_cands, 0, 6 * sizeof(unsigned), st));       // candidate count + ticket
             const unsigned spin = (unsigned)std::max<long>(1000, tn.meas_spin_limit);
 #define QCX_ONEPASS(B) hipLaunchKernelGGL((k_meas_onepass<B>), dim3(nwg), dim3(256), 0, st, (const amp_t *)amp, count, cum_in, LB, w->meas_blocks, spin, (unsigned)tn.meas_dbg, r)
             switch (blog) {
@@ -796,7 +799,6 @@ extern "C" int qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_
             MeasBlock *up = w->meas_up;
             // the events of the scan go to k_meas_fast (the launch over the records lists them), the walk stands behind it
             const bool fast = tn.meas_fast != 0 && T.n[0] > 64u;
-            if (fast) HIP_TRY(hipMemsetAsync(w->meas_cands, 0, 2 * sizeof(unsigned), st));
             while (T.n[T.top] > 64u && T.top < 4) {
                 const unsigned nin = T.n[T.top], nout = (nin + 63u) / 64u;
                 hipLaunchKernelGGL(k_meas_groups, dim3(nout), dim3(64), 0, st, T.lv[T.top], nin, up, (fast && T.top == 0) ? w->meas_cands : (MeasCands *)nullptr);
@@ -805,16 +807,16 @@ extern "C" int qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_
                 up += nout;
             }
             if (fast)
-                hipLaunchKernelGGL(k_meas_fast, dim3(1), dim3(512), 0, st, (const amp_t *)amp, count, T, cum_in, r, w->mout, w->meas_stats, blog,
+                hipLaunchKernelGGL(k_meas_fast, dim3(1), dim3(512), 0, st, (const amp_t *)amp, count, T, cum_in, r, w->mout, w->mout->stats, blog,
                                    (const MeasCands *)w->meas_cands, w->meas_resume, (unsigned)tn.meas_dbg);
-            hipLaunchKernelGGL(k_meas_walk, dim3(1), dim3(64), 0, st, (const amp_t *)amp, count, T, cum_in, r, w->mout, w->meas_stats, blog,
-                               fast ? (const MeasResume *)w->meas_resume : (const MeasResume *)nullptr);
+            hipLaunchKernelGGL(k_meas_walk, dim3(1), dim3(64), 0, st, (const amp_t *)amp, count, T, cum_in, r, w->mout, w->mout->stats, blog,
+                               fast ? (const MeasResume *)w->meas_resume : (const MeasResume *)nullptr, w->meas_cands);
         }
     }
     HIP_TRY(hipGetLastError());
-    if (parallel) HIP_TRY(hipMemcpyAsync(w->h_meas_stats, w->meas_stats, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(w->h_mout, w->mout, sizeof(MeasureOut), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (parallel) { w->h_meas_stats[0] = w->h_mout->stats[0]; w->h_meas_stats[1] = w->h_mout->stats[1]; w->meas_clean = true; }
     *found = w->h_mout->found;
     *index = first_global + w->h_mout->index;
     *cum_out = w->h_mout->cum;

@@ -514,6 +514,7 @@ struct MeasureOut {
     int      found;
     uint64_t index;
     double   cum;
+    unsigned stats[2];          // K4c: [records looked at closely, records] of the scan (qcx_measure_last_stats): one copy back with the result
 };
 
 __device__ __forceinline__ double readlane_f64(double v, int lane)
@@ -798,7 +799,7 @@ __global__ __launch_bounds__(256) void k_meas_onepass(const amp_t *__restrict__ 
 // cands (the launch over the records themselves only): the records k_meas_fast has to look at closely -- flagged ones, and both
 // sides of every change of the binade guess (a crossing lies in one of the two)
 #define QCX_MEAS_CAND_CAP 192u
-struct MeasCands { unsigned count, pad; unsigned list[QCX_MEAS_CAND_CAP]; };
+struct MeasCands { unsigned count, pad; unsigned ticket[4]; unsigned list[QCX_MEAS_CAND_CAP]; };    // ticket: the look-back's workgroup counter (a fixed address whatever the scan's size)
 
 __global__ __launch_bounds__(64) void k_meas_groups(const MeasBlock *__restrict__ in, unsigned nin, MeasBlock *__restrict__ outg, MeasCands *cands)
 {
@@ -954,10 +955,14 @@ struct MeasLevels {
 struct MeasResume { uint32_t state, slow; uint64_t b; double cum; };
 
 __global__ __launch_bounds__(64) void k_meas_walk(const amp_t *__restrict__ amp, uint64_t count, MeasLevels T,
-                                                  double cum_in, double r, MeasureOut *out, unsigned *stats, unsigned rlog, const MeasResume *resume)
+                                                  double cum_in, double r, MeasureOut *out, unsigned *stats, unsigned rlog, const MeasResume *resume,
+                                                  MeasCands *cands)
 {
     const unsigned lane = threadIdx.x;
     const unsigned n0 = T.n[0];
+    // the last kernel of a scan leaves the look-back's ticket and the candidate count at zero for the next scan (two memset
+    // launches less per measurement: ~9 us of the ~100 an n = 20 attempt takes; the host falls back to memsets after a failed call)
+    if (lane == 0) { cands->count = 0u; cands->ticket[0] = cands->ticket[1] = cands->ticket[2] = cands->ticket[3] = 0u; }
     double cum = cum_in;
     unsigned slow = 0;
     uint64_t b = 0;                                   // next record

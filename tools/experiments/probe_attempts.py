@@ -9,10 +9,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import quantumcomputer_amd as qc  # noqa: E402
 
 M, C, a = 5, 21, 2
+extra = {k: int(v) for k, v in (kv.split("=") for kv in sys.argv[1:])}
 for L in (6, 9, 11, 13, 15, 17, 19, 21, 23, 25):
     row = []
     for cache in (1, 0):
-        qc.tune(fuse_plan_cache=cache)
+        qc.tune(fuse_plan_cache=cache, **extra)
         with qc.Register(L, M) as reg:
             reps = 200 if L < 17 else (40 if L < 23 else 10)
             def attempt(r):

@@ -128,7 +128,7 @@ struct Tune {
     long fuse_expand_fused = 1;  // the last pass of a compact chain stores the real register itself (k_fused_x8's expanding store) instead of k_expand_compact
     long fuse_cols_tol = 1;    // tolerance mode: the by-columns pass of a compact chain keeps its merged diagonals (fast rounds inside k_gen_cols)
     long fuse_cols_cap = 12288; // workgroups of a k_gen_cols launch (a workgroup's prologue is long; n = 30 Shor circuit 11.06-11.09 ms with 12288-24576, 11.14-11.3 with 65536, 12.07 with 1536; tolerance 7.4-7.8 against 8.1)
-    long fuse_cols_waves = 4;  // waves per workgroup of k_gen_cols (4 ... 8; the first four generate and store the tile)
+    long fuse_cols_waves = 0;  // waves per workgroup of k_gen_cols (4 ... 8; the first four generate and store the tile); 0: 8 for launches of at most 1024 tiles, else 4
     long fuse_expand_direct = 1; // k_expand_compact: 1 = gather the compact sources straight from memory (8 per thread in flight) instead of staging 64 blocks in LDS
     long fuse_gen_cols = 1;    // the generated first pass by COLUMNS of the four lowest M-register bits (K6g, k_gen_cols)
     long fuse_zskip  = 1;      // passes behind a circuit front: waves whose share of the tile is all +0 skip the rounds (FusePass::zskip)

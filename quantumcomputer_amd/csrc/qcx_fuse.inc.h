@@ -751,7 +751,10 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
         P.gen_lds_off = (uint32_t)((lds_cols - (size_t)P.zpad * QCX_COL_STRIDE * sizeof(amp_t) + 15) & ~(size_t)15);   // the residue -> column table of a compact chain
         lds_cols = (size_t)P.zpad * QCX_COL_STRIDE * sizeof(amp_t) + P.gen_lds_off + (P.gen == 3 ? P.gen_tab_bytes : 0);
         // (four waves; one wave per column -- six for the orbit of N = 21 -- is slower: 5.3 against 3.8 ms at n = 30, the extra waves idle through generation and store)
-        const unsigned waves = (unsigned)std::min<long>(8, std::max<long>(4, tn.fuse_cols_waves));
+        // ... while a launch that does not fill the chip (<= 1024 tiles: n <= 22 behind a six-residue front) is a latency chain per tile,
+        // which more waves shorten: attempts at n = 16 .. 22 take 88-127 us with eight waves against 97-138 with four
+        // (profiles/r05_attempts_cols_waves.txt).  fuse_cols_waves = 0: chosen here.
+        const unsigned waves = tn.fuse_cols_waves <= 0 ? (ntiles <= 1024 ? 8u : 4u) : (unsigned)std::min<long>(8, std::max<long>(4, tn.fuse_cols_waves));
         const unsigned gridc = grid_for(ntiles, 1, tn.fuse_cols_cap);
         if (P.dg_cnt) hipLaunchKernelGGL((k_gen_cols<6, true>), dim3(gridc), dim3(64 * waves), lds_cols, r->stream, amp_out, n, P, d_ops, ntiles, d_ops);
         else hipLaunchKernelGGL((k_gen_cols<6, false>), dim3(gridc), dim3(64 * waves), lds_cols, r->stream, amp_out, n, P, d_ops, ntiles, d_ops);

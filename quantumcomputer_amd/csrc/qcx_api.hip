@@ -1454,10 +1454,11 @@ static int note_nonfinite(qcx_register *r, uint64_t first, uint64_t count)
     HIP_TRY(hipMemsetAsync(w->meas_stats, 0, sizeof(unsigned), r->stream));
     hipLaunchKernelGGL(k_scan_nonfinite, dim3(grid_for(count, 256 * 8, 65536, 256)), dim3(256), 0, r->stream, (const amp_t *)(r->amp + first), count, w->meas_stats);
     HIP_TRY(hipGetLastError());
+    const unsigned keep = w->h_meas_stats[0];                // (the pinned word doubles as the last scan's statistics: put it back)
     HIP_TRY(hipMemcpyAsync(w->h_meas_stats, w->meas_stats, sizeof(unsigned), hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
     if (w->h_meas_stats[0]) r->nonfinite = 1;
-    w->h_meas_stats[0] = 0;
+    w->h_meas_stats[0] = keep;
     return QCX_NO_ERROR;
 }
 

@@ -539,7 +539,10 @@ def single_gpu_configs(qc, reps=3):
 
     # config 1 on the GPU (BASELINE config 1 is the reference's own CPU case, n = 12 Shor N = 15): whole period-finding
     # attempts -- reset, circuit (16 H + 8 C_AMODC + 28 CPHASE), measurement -- in a warm process, wall clock
-    for label, (L, M, Cn, a) in (("n7_C15_L3_M4", (3, 4, 15, 7)), ("n12_C15_L8_M4", (8, 4, 15, 7))):
+    # (and, beyond BASELINE's config 1, the same at n = 20 and n = 24 with N = 21: the sizes at which an attempt is mostly host time --
+    #  the plan of a repeated circuit is kept)
+    for label, (L, M, Cn, a) in (("n7_C15_L3_M4", (3, 4, 15, 7)), ("n12_C15_L8_M4", (8, 4, 15, 7)),
+                                 ("n20_C21_L15_M5", (15, 5, 21, 2)), ("n24_C21_L19_M5", (19, 5, 21, 2))):
         rng = qc.Rng(1)
         with qc.Register(L, M) as reg:
             def attempt():

@@ -21,6 +21,12 @@ def bits(a):
 
 
 def same(got, want, mode, what):
+    if mode == 3:                                   # poisoned states: NaN wherever the oracle has one, everything else bit for bit
+        gn, wn = np.isnan(got), np.isnan(want)
+        assert np.array_equal(gn, wn), f"{what}: NaN pattern differs at {np.nonzero(gn != wn)[0][:6]}"
+        bad = np.nonzero(bits(got[~gn]) != bits(want[~wn]))[0]
+        assert bad.size == 0, f"{what}: {bad.size} non-NaN doubles differ"
+        return
     if mode == 2:
         err = float(np.max(np.abs(got - want)))
         assert err <= TOL, f"{what}: max |delta| {err:.3e}"
@@ -74,7 +80,8 @@ def one_case(qc, ob, seed):
     k = shards.bit_length() - 1
     if shards > 1 and n - k - max(M, 6) < 2 * k:
         shards = 1
-    tag = f"case {seed}: n={n} M={M} C={Cn} mode={mode} kind={kind} shards={shards} {knobs}"
+    poisoned = kind == 0 and shards == 1 and n <= 18 and rs.randint(0, 8) == 0
+    tag = f"case {seed}: n={n} M={M} C={Cn} mode={mode} kind={kind} shards={shards} poisoned={int(poisoned)} {knobs}"
     print(tag, flush=True)
     qc.tune(**knobs)
     scale = 1.0
@@ -85,7 +92,13 @@ def one_case(qc, ob, seed):
         prog0 = gate_mix(rs, n, M, Cn, int(rs.randint(20, 260)), 0, float(rs.choice([0.3, 0.6, 0.9])))
         tail2 = gate_mix(rs, n, M, Cn, int(rs.randint(10, 200)), M, float(rs.choice([0.5, 0.8, 0.95])))
         for rep_i in range(reps):
-            if kind == 0:                                   # a random program on a random dense state
+            if kind == 0 and poisoned:                      # the same on a state with Inf / NaN / overflow-prone components: strict gates (K9)
+                want = ob.random_state(n, (seed + rep_i) & 0xFFFF)
+                for w_ in rs.choice(2 << n, size=int(rs.randint(1, 5)), replace=False):
+                    want[w_] = float(rs.choice([np.inf, -np.inf, np.nan, 1e308, -1.5e308]))
+                reg.write(want)
+                apply(qc, ob, reg, want, n, M, Cn, prog0[:60])
+            elif kind == 0:                                 # a random program on a random dense state
                 sd = (seed + 977 * rep_i) & 0xFFFF
                 want = ob.fill_random(n, sd); reg.fill_random(sd)
                 apply(qc, ob, reg, want, n, M, Cn, prog0)
@@ -103,8 +116,11 @@ def one_case(qc, ob, seed):
                     apply(qc, ob, reg, want, n, M, Cn, tail2)
             # observers, in random order; each must see the reference's state
             for obs in rs.permutation(["read", "norm", "window", "measure", "more"])[:int(rs.randint(1, 5))]:
+                cmp_mode = 3 if poisoned else mode
+                if poisoned and obs in ("norm", "more"):
+                    continue                                # (norm of a NaN state; "more" would run on a collapsed or still poisoned state: covered by the next case)
                 if obs == "read":
-                    same(reg.read(), want, mode, tag + " read")
+                    same(reg.read(), want, cmp_mode, tag + " read")
                 elif obs == "norm":
                     # (two different summation orders -- the oracle's is the sequential one: 1.1e-11 apart at n = 25 -- so this observer
                     #  only checks that the flush it triggers leaves the right state behind; the reads do the comparing)
@@ -112,11 +128,11 @@ def one_case(qc, ob, seed):
                 elif obs == "window":
                     s = int(rs.randint(0, (1 << n) - 64)); cnt = int(rs.randint(1, min(1 << n, 5000) - 63))
                     cnt = min(cnt, (1 << n) - s)
-                    same(reg.read(s, cnt), want[2 * s:2 * (s + cnt)], mode, tag + " window")
+                    same(reg.read(s, cnt), want[2 * s:2 * (s + cnt)], cmp_mode, tag + " window")
                 elif obs == "measure":
                     r = float(rs.uniform(0, 1)) if rs.randint(0, 4) else float(rs.choice([0.0, 1.0, 1e-9, 0.999999999]))
                     got = qc.measure_state(reg, r)
-                    if mode == 2:
+                    if mode == 2 and not poisoned:
                         # the tolerance mode's probabilities differ in the last bits: the draw must land next to the same boundary
                         cum = np.cumsum((want.reshape(-1, 2) ** 2).sum(axis=1))
                         lo, hi = int(np.searchsorted(cum, r - 1e-9)), int(np.searchsorted(cum, r + 1e-9))
@@ -125,6 +141,7 @@ def one_case(qc, ob, seed):
                     else:
                         assert got == ob.measure(want, n, r), tag + f" measure r={r!r}"
                     same(reg.read(), want, 0, tag + " collapsed state")
+                    poisoned = False                            # the collapse replaced the state
                 else:
                     prog = gate_mix(rs, n, M, Cn, int(rs.randint(1, 60)), 0, 0.6)
                     apply(qc, ob, reg, want, n, M, Cn, prog)

@@ -198,6 +198,8 @@ struct Workspace {
     double     *partials = nullptr;     // NORM_BLOCKS doubles + 1
     MeasureOut *mout = nullptr;
     MeasureOut *h_mout = nullptr;       // pinned
+    size_t      meas_slots_pending = 0;
+    size_t      meas_clean_slots = 0;   // ... and this many look-back slots from the start of meas_look are known to read "not published"
     bool        meas_clean = false;     // the last parallel scan completed: its walk kernel left ticket and candidate count at zero
     double     *h_scalar = nullptr;     // pinned
     uint32_t   *tab = nullptr;          // camodc CSR table (off + srcs)
@@ -769,7 +771,7 @@ extern "C" int qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_
             std::lock_guard<std::mutex> lock(g_ws_mutex);
             if (w->meas_cap < nblocks) {
                 if (w->meas_blocks) { HIP_TRY(hipFree(w->meas_blocks)); HIP_TRY(hipFree(w->meas_look)); HIP_TRY(hipFree(w->meas_up)); }
-                w->meas_blocks = nullptr; w->meas_cap = 0; w->meas_clean = false;
+                w->meas_blocks = nullptr; w->meas_cap = 0; w->meas_clean = false; w->meas_clean_slots = 0;
                 w->meas_look = nullptr; w->meas_up = nullptr;
                 HIP_TRY(hipMalloc(&w->meas_blocks, ((size_t)nblocks + 4) * sizeof(MeasBlock)));
                 HIP_TRY(hipMalloc(&w->meas_look, (2 * (size_t)nblocks + 4 * ((size_t)nblocks / 64 + 2) + 8) * sizeof(meas_slot_t)));
@@ -782,8 +784,10 @@ extern "C" int qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_
             MeasLookback LB;
             LB.agg = w->meas_look; LB.incl = LB.agg + nwg; LB.gsum = LB.incl + nwg; LB.gincl = LB.gsum + ngrp;
             LB.ticket = w->meas_cands->ticket;                       // (a fixed address: the scan's last kernel leaves it at zero for the next one)
-            HIP_TRY(hipMemsetAsync(w->meas_look, 0xff, (2 * (size_t)nwg + 2 * (size_t)ngrp) * sizeof(meas_slot_t), st));
             const bool clean = w->meas_clean;
+            const size_t nslots = 2 * (size_t)nwg + 2 * (size_t)ngrp;
+            if (!clean || nslots > w->meas_clean_slots) HIP_TRY(hipMemsetAsync(w->meas_look, 0xff, nslots * sizeof(meas_slot_t), st));
+            const size_t slots_after = clean ? std::max(w->meas_clean_slots, nslots) : nslots;
             w->meas_clean = false;                                  // (true again when this call has completed)
             if (!clean) HIP_TRY(hipMemsetAsync(w->meas_cands, 0, 6 * sizeof(unsigned), st));       // candidate count + ticket
             const unsigned spin = (unsigned)std::max<long>(1000, tn.meas_spin_limit);
@@ -801,7 +805,8 @@ extern "C" int qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_
             const bool fast = tn.meas_fast != 0 && T.n[0] > 64u;
             while (T.n[T.top] > 64u && T.top < 4) {
                 const unsigned nin = T.n[T.top], nout = (nin + 63u) / 64u;
-                hipLaunchKernelGGL(k_meas_groups, dim3(nout), dim3(64), 0, st, T.lv[T.top], nin, up, (fast && T.top == 0) ? w->meas_cands : (MeasCands *)nullptr);
+                hipLaunchKernelGGL(k_meas_groups, dim3(nout), dim3(64), 0, st, T.lv[T.top], nin, up, (fast && T.top == 0) ? w->meas_cands : (MeasCands *)nullptr,
+                                   T.top == 0 ? w->meas_look : (meas_slot_t *)nullptr, (unsigned)nslots);
                 T.top++;
                 T.lv[T.top] = up; T.n[T.top] = nout;
                 up += nout;
@@ -810,13 +815,15 @@ extern "C" int qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_
                 hipLaunchKernelGGL(k_meas_fast, dim3(1), dim3(512), 0, st, (const amp_t *)amp, count, T, cum_in, r, w->mout, w->mout->stats, blog,
                                    (const MeasCands *)w->meas_cands, w->meas_resume, (unsigned)tn.meas_dbg);
             hipLaunchKernelGGL(k_meas_walk, dim3(1), dim3(64), 0, st, (const amp_t *)amp, count, T, cum_in, r, w->mout, w->mout->stats, blog,
-                               fast ? (const MeasResume *)w->meas_resume : (const MeasResume *)nullptr, w->meas_cands);
+                               fast ? (const MeasResume *)w->meas_resume : (const MeasResume *)nullptr, w->meas_cands,
+                               T.top == 0 ? w->meas_look : (meas_slot_t *)nullptr, (unsigned)nslots);
+            w->meas_slots_pending = slots_after;
         }
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(w->h_mout, w->mout, sizeof(MeasureOut), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (parallel) { w->h_meas_stats[0] = w->h_mout->stats[0]; w->h_meas_stats[1] = w->h_mout->stats[1]; w->meas_clean = true; }
+    if (parallel) { w->h_meas_stats[0] = w->h_mout->stats[0]; w->h_meas_stats[1] = w->h_mout->stats[1]; w->meas_clean = true; w->meas_clean_slots = w->meas_slots_pending; }
     *found = w->h_mout->found;
     *index = first_global + w->h_mout->index;
     *cum_out = w->h_mout->cum;

@@ -801,9 +801,16 @@ __global__ __launch_bounds__(256) void k_meas_onepass(const amp_t *__restrict__ 
 #define QCX_MEAS_CAND_CAP 192u
 struct MeasCands { unsigned count, pad; unsigned ticket[4]; unsigned list[QCX_MEAS_CAND_CAP]; };    // ticket: the look-back's workgroup counter (a fixed address whatever the scan's size)
 
-__global__ __launch_bounds__(64) void k_meas_groups(const MeasBlock *__restrict__ in, unsigned nin, MeasBlock *__restrict__ outg, MeasCands *cands)
+__global__ __launch_bounds__(64) void k_meas_groups(const MeasBlock *__restrict__ in, unsigned nin, MeasBlock *__restrict__ outg, MeasCands *cands,
+                                                    meas_slot_t *look, unsigned nslots)
 {
     const unsigned lane = threadIdx.x, i = blockIdx.x * 64u + lane;
+    // (the launch over the records also puts the look-back's slots back to "not published" for the next scan -- k_meas_onepass is
+    //  through with them: one memset launch less per measurement.  The slots only feed guesses: a stale one costs time, never a result)
+    if (look) {
+        const unsigned per = (nslots + gridDim.x - 1u) / gridDim.x;
+        for (unsigned k = lane; k < per; k += 64u) { const unsigned idx = blockIdx.x * per + k; if (idx < nslots) look[idx] = ~0ULL; }
+    }
     MeasBlock m; m.S = 0; m.meta = MEAS_ALLZERO; m.pad = 0;
     if (i < nin) m = in[i];
     const bool zero = (m.meta & MEAS_ALLZERO) != 0;
@@ -956,10 +963,11 @@ struct MeasResume { uint32_t state, slow; uint64_t b; double cum; };
 
 __global__ __launch_bounds__(64) void k_meas_walk(const amp_t *__restrict__ amp, uint64_t count, MeasLevels T,
                                                   double cum_in, double r, MeasureOut *out, unsigned *stats, unsigned rlog, const MeasResume *resume,
-                                                  MeasCands *cands)
+                                                  MeasCands *cands, meas_slot_t *look, unsigned nslots)
 {
     const unsigned lane = threadIdx.x;
     const unsigned n0 = T.n[0];
+    if (look) for (unsigned k = lane; k < nslots; k += 64u) look[k] = ~0ULL;      // (a scan without a groups launch: at most 34 slots)
     // the last kernel of a scan leaves the look-back's ticket and the candidate count at zero for the next scan (two memset
     // launches less per measurement: ~9 us of the ~100 an n = 20 attempt takes; the host falls back to memsets after a failed call)
     if (lane == 0) { cands->count = 0u; cands->ticket[0] = cands->ticket[1] = cands->ticket[2] = cands->ticket[3] = 0u; }

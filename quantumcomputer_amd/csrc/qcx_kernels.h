@@ -388,8 +388,8 @@ __global__ __launch_bounds__(256) void k_fill_random(amp_t *__restrict__ amp, ui
 // nothing: 0 * Inf = NaN poisons the other component of the SAME amplitude, through an identity row too (Q:409-412 runs
 // over every stored triplet).  A register that was handed such values (qcx_state_write / _load; the host sets
 // qcx_register::nonfinite from a scan of what was written) runs every gate through these kernels instead -- one plain pass
-// per gate over ALL amplitudes with the mat-vec's own four products and sums per triplet (the oracle's pairwise forms,
-// oracle/qcx_oracle.c, line for line) -- until a reset, a fill or a measurement replaces the state.  z and one arrive as
+// per gate over ALL amplitudes with the mat-vec's own four products and sums per triplet (Q:396-413 applied to
+// the triplets each gate stores, Q:456-481 / Q:529-562 / Q:612-657) -- until a reset, a fill or a measurement replaces the state.  z and one arrive as
 // kernel arguments so that no compiler ever folds a product with them.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_strict_h(amp_t *__restrict__ amp, unsigned n, unsigned q, double s, double z)

@@ -113,6 +113,8 @@ struct Tune {
     long fuse_x8     = 1;      // bit-exact phase-dominated passes: the walk on 8 amplitudes per thread (k_fused_x8, round 5)
     long fuse_x8_T   = 12;     // ... on tiles of 2^this amplitudes (10 .. 12) with
     long fuse_x8_c   = 4;      // ... this many contiguous low bits
+    long fuse_streams_log2 = -1;   // which tile a workgroup of k_fused_q3 / k_fused_x8 / k_fused_rounds takes (fuse_stream_tile): the 2^this low bits of its slot number ...
+    long fuse_streams_pos  = -1;   // ... go to this bit of the tile number (+ 1; 0 = on top).  -1: by the kind of pass (launch_pass)
     long fuse_x8t    = 1;      // tolerance mode: radix-8 fast rounds run on the k_fused_x8 shell (hand-written round, K6x-t) instead of k_fused_q3
     long fuse_x8_min_tiles_log2 = 2;   // ... on registers of at least 2^this tiles
     long fuse_x8_ratio = 1;    // ... for passes without multiplies that hold at least this many phases per Hadamard
@@ -167,7 +169,7 @@ static Tune tune_now() { std::lock_guard<std::mutex> lock(g_tune_mutex); return 
 extern "C" int qcx_tune_set(const char *key, long value)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); g_tune.name = value; return QCX_NO_ERROR; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_spin_limit) K(meas_dbg) K(meas_fast) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_dir) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_gen_cols) K(fuse_cols_waves) K(fuse_cols_cap) K(fuse_cols_tol) K(fuse_compact) K(fuse_expand_direct) K(fuse_compact_lazy) K(fuse_expand_fused) K(fuse_plan_cache) K(fuse_zskip) K(fuse_zskip_maxw) K(fuse_x8) K(fuse_x8_T) K(fuse_x8_c) K(fuse_x8_map) K(fuse_x8_cap) K(fuse_x8_ratio) K(fuse_x8_min_tiles_log2) K(fuse_x8t)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_spin_limit) K(meas_dbg) K(meas_fast) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_dir) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_gen_cols) K(fuse_cols_waves) K(fuse_cols_cap) K(fuse_cols_tol) K(fuse_compact) K(fuse_expand_direct) K(fuse_compact_lazy) K(fuse_expand_fused) K(fuse_plan_cache) K(fuse_zskip) K(fuse_zskip_maxw) K(fuse_x8) K(fuse_x8_T) K(fuse_x8_c) K(fuse_x8_map) K(fuse_x8_cap) K(fuse_x8_ratio) K(fuse_x8_min_tiles_log2) K(fuse_x8t) K(fuse_streams_log2) K(fuse_streams_pos)
 #undef K
     return QCX_BAD_ARGUMENTS;
 }
@@ -175,7 +177,7 @@ extern "C" int qcx_tune_set(const char *key, long value)
 extern "C" long qcx_tune_get(const char *key)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); return g_tune.name; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_spin_limit) K(meas_dbg) K(meas_fast) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_dir) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_gen_cols) K(fuse_cols_waves) K(fuse_cols_cap) K(fuse_cols_tol) K(fuse_compact) K(fuse_expand_direct) K(fuse_compact_lazy) K(fuse_expand_fused) K(fuse_plan_cache) K(fuse_zskip) K(fuse_zskip_maxw) K(fuse_x8) K(fuse_x8_T) K(fuse_x8_c) K(fuse_x8_map) K(fuse_x8_cap) K(fuse_x8_ratio) K(fuse_x8_min_tiles_log2) K(fuse_x8t)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_spin_limit) K(meas_dbg) K(meas_fast) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_dir) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_gen_cols) K(fuse_cols_waves) K(fuse_cols_cap) K(fuse_cols_tol) K(fuse_compact) K(fuse_expand_direct) K(fuse_compact_lazy) K(fuse_expand_fused) K(fuse_plan_cache) K(fuse_zskip) K(fuse_zskip_maxw) K(fuse_x8) K(fuse_x8_T) K(fuse_x8_c) K(fuse_x8_map) K(fuse_x8_cap) K(fuse_x8_ratio) K(fuse_x8_min_tiles_log2) K(fuse_x8t) K(fuse_streams_log2) K(fuse_streams_pos)
 #undef K
     return -1;
 }

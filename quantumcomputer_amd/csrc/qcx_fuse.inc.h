@@ -708,6 +708,16 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
     size_t lut_bytes = lut_only + (size_t)P.cam_ctl_local[1];                      // + tables of folded multiply runs
     P.xm_off = 0;
     P.dbg = (uint32_t)tn.fuse_dbg | (((uint32_t)tn.fuse_swz & 7u) << 8);
+    {   // which tile a workgroup takes (fuse_stream_tile): memory-bound radix-8 passes (Hadamard sweeps, the tolerance mode's fast
+        // rounds) put the XCD number on tile-number bits 3-5 -- one XCD then stores 2^3 neighbouring runs back to back (n = 30
+        // sweep -6 %, n = 28 tolerance inverse QFT -1.6 %); the exact phase walk (FP64-bound) measures the same either way and
+        // keeps t = b (profiles/r05_streams.txt)
+        const bool membound = P.dg_slim == 2 && !P.gen;
+        long sl = tn.fuse_streams_log2 >= 0 ? tn.fuse_streams_log2 : (membound ? 3 : 0);
+        long pos1 = tn.fuse_streams_pos >= 0 ? tn.fuse_streams_pos : (membound ? 4 : 0);
+        sl = std::min<long>(std::min<long>(sl, 15), (long)(n - P.T));
+        P.dbg = (P.dbg & 0xfffu) | ((uint32_t)sl << 12) | (((uint32_t)pos1 & 31u) << 16);
+    }
     if ((P.dg_cnt || P.dg_slim == 2) && !P.has_cam) { lut_bytes = 16; P.cam_ctl_local[3] = 16; }       // tolerance-mode pass without multiplies: no scratch
     if (P.dg_slim == 3) {                 // the exact walk on 8 amplitudes per thread (k_fused_x8): the tile, then the records' outside-tile masks
         if (P.T < 10 || P.T > 12 || P.has_cam || P.gen > 1 || P.zskip || !tn.fuse_ldsdma) { set_error("radix-8 exact pass: unsupported shape (T = %u)", P.T); return QCX_UNKNOWN_ERROR; }

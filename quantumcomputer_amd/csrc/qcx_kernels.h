@@ -233,6 +233,7 @@ __global__ __launch_bounds__(BLOCK) void k_phase_lines(amp_t *__restrict__ amp, 
 // staged in LDS so the update is in place with coalesced global traffic; the
 // amplitudes whose control bit is 0 are never touched (camodc_tile).
 // ---------------------------------------------------------------------------
+
 struct CamodcParams {
     unsigned M, logT;
     int      ctl;        // local bit index, or -1: control lives in the rank id and is 1
@@ -1358,6 +1359,25 @@ struct FusePass {
     uint16_t xp_orbit[16];
 };
 
+// Which tile a workgroup takes (round 5, second half).  Workgroup slot b (blockIdx, or the b-th turn of a persistent workgroup) used
+// to take tile b; now the 2^s low bits of b -- under round-robin placement the XCD the workgroup runs on, for s >= 3 -- are moved
+// to bit position `pos` of the tile number: t = [b's bits above s + pos][b mod 2^s][the `pos` bits of b above s].  s = bits 12-15 of
+// FusePass::dbg, pos + 1 = bits 16-20 (0: on top, the per-gate kernels' "interleaved streams" of h_plan); launch_pass sets both
+// (fuse_streams_log2 / fuse_streams_pos).  Why: a chained memory-bound pass stores runs of 2^c amplitudes (128 B at c = 3), and the
+// tiles whose runs are NEIGHBOURS in the output are consecutive tile numbers (planner: tiles numbered by output position).  With
+// t = b, eight neighbouring runs leave from eight different XCDs, i.e. through eight different L2s; with s = 3, pos = 3 one XCD
+// takes the eight tiles whose runs make up 1 KiB of the output, back to back.  n = 30 fused Hadamard sweep 19.1-19.7 -> 18.0-18.4 ms
+// (same box each pair), n = 28 tolerance inverse QFT 5.02 -> 4.94; the FP64-bound exact walk does not care.  The gain swings with
+// pos (pos = 2, 4: none or a loss; 1, 3, 5: the gain) and needs s >= 3 (profiles/r05_streams.txt; the microbenchmark behind it,
+// a pass without gates: tools/experiments/tile_shell.hip, profiles/r05_tile_shell.txt).  Which tile a workgroup takes changes
+// nothing about what it does to it: same bits.
+__device__ __forceinline__ uint64_t fuse_stream_tile(uint64_t b, unsigned tiles_log2, unsigned slog, unsigned pos1)
+{
+    const unsigned pos = pos1 ? min(pos1 - 1u, tiles_log2 - slog) : tiles_log2 - slog;
+    const uint64_t r = b >> slog, sb = b & ((1u << slog) - 1u);
+    return (r & (((uint64_t)1 << pos) - 1u)) | (sb << pos) | ((r >> pos) << (pos + slog));
+}
+
 // The circuit front on a basis state (K0b, BasisFront below) evaluated per TILE of the first pass behind it (round 4): the
 // front's separate write pass and the first pass's read disappear.  Same closed form, same bits: after the front, the
 // 2^M-block of an amplitude index i (its bits >= M) is populated iff its non-Hadamard bits equal the basis state's, and then
@@ -2218,7 +2238,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
     // swz = s > 0: workgroups that share an XCD (blockIdx mod 8 under round-robin placement) take 2^s NEIGHBOURING tiles
     // instead of every eighth one -- their runs are then adjacent in memory (speed only; any order is correct)
     const unsigned swz = (P.dbg >> 8) & 7u;
-    for (uint64_t t0 = blockIdx.x; t0 < ntiles; t0 += gridDim.x) {
+    const unsigned slog = (P.dbg >> 12) & 15u;
+    for (uint64_t b0 = blockIdx.x; b0 < ntiles; b0 += gridDim.x) {
+        const uint64_t t0 = fuse_stream_tile(b0, n - TT, slog, (P.dbg >> 16) & 31u);
         uint64_t t = t0;
         if (swz && !((ntiles | gridDim.x) & ((8u << swz) - 1u))) {
             const uint64_t xcd = t0 & 7u, slot = t0 >> 3, in = slot & ((1u << swz) - 1u), grp = slot >> swz;
@@ -2641,7 +2663,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
         for (unsigned k = 0; k < 8; k++) packK[k] = gen_pack(k * BLOCK, GF, TT);
         __syncthreads();
     }
-    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const unsigned slog = (P.dbg >> 12) & 15u;
+    for (uint64_t b0 = blockIdx.x; b0 < ntiles; b0 += gridDim.x) {
+        const uint64_t t = fuse_stream_tile(b0, n - TT, slog, (P.dbg >> 16) & 31u);
         const uint64_t base_in = fuse_deposit(t, P.seg_in, P.nseg_in);
         uint64_t base = base_in, base_out = base_in;               // logical base (gate records), output base
         if (P.chained) { base = fuse_deposit(t, P.seg_lg, P.nseg_lg); base_out = fuse_deposit(t, P.seg_out, P.nseg_out); }
@@ -3288,7 +3312,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         for (unsigned k = 0; k < 8; k++) packK[k] = gen_pack(x8_swz(k * BLOCK), GF, TT);
         __syncthreads();
     }
-    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const unsigned slog = (P.dbg >> 12) & 15u;
+    for (uint64_t b0 = blockIdx.x; b0 < ntiles; b0 += gridDim.x) {
+        const uint64_t t = fuse_stream_tile(b0, n - TT, slog, (P.dbg >> 16) & 31u);
         const uint64_t base_in = fuse_deposit(t, P.seg_in, P.nseg_in);
         uint64_t base = base_in, base_out = base_in;               // logical base (gate records), output base
         if (P.chained) { base = fuse_deposit(t, P.seg_lg, P.nseg_lg); base_out = fuse_deposit(t, P.seg_out, P.nseg_out); }

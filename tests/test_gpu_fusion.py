@@ -393,6 +393,50 @@ def test_chained_passes_give_the_same_bits(qc, ob, chain_guard, L, M, Cn, mode):
         assert np.array_equal(bits(got), bits(w3)) if mode == 1 else float(np.max(np.abs(got - w3))) <= 1e-12
 
 
+# ---- round 5, second half: which tile a workgroup takes (fuse_stream_tile) ----------------------------------------------------
+@pytest.fixture()
+def streams_guard(qc):
+    keys = ("fuse_streams_log2", "fuse_streams_pos", "fuse_chain", "fuse_chain_min_n", "fuse_q3_cap_exact", "fuse_x8_cap", "fuse_grid_cap")
+    old = {k: qc.lib().qcx_tune_get(k.encode()) for k in keys}
+    yield
+    qc.tune(**old)
+
+
+@pytest.mark.parametrize("mode", [1, 2], ids=["exact", "tolerance"])
+@pytest.mark.parametrize("s,pos1", [(-1, -1), (0, 0), (1, 0), (3, 0), (3, 4), (3, 1), (4, 3), (6, 9), (15, 31)])
+def test_tile_order_changes_no_bit(qc, ob, streams_guard, s, pos1, mode):
+    """the slot -> tile map of the fused kernels (interleaved streams, the XCD number inside the tile number) is a permutation of
+    the tiles for every setting, clamped on small registers, also under persistent grids: Hadamard sweeps (k_fused_q3), the
+    inverse QFT (k_fused_x8, exact walk and tolerance round) and a Shor circuit (k_fused_rounds behind the front) against the
+    oracle"""
+    qc.tune(fuse_streams_log2=s, fuse_streams_pos=pos1, fuse_chain=1, fuse_chain_min_n=13)
+    threads = 8
+    for (L, M, Cn, a), caps in (((18, 0, 1, 1), (0, 24)), ((13, 0, 1, 1), (0, 3)), ((13, 5, 21, 2), (0, 40))):
+        n = L + M
+        for cap in caps:                                   # 0: one workgroup per tile; else persistent workgroups that walk the tiles
+            qc.tune(fuse_q3_cap_exact=cap, fuse_x8_cap=cap or 65536, fuse_grid_cap=cap)
+            with qc.Register(L, M) as reg:
+                reg.set_fusion(mode)
+                want = ob.fill_random(n, 33); reg.fill_random(33)
+                for q in range(n):
+                    qc.hadamard_gate(q, reg); ob.hadamard(want, n, q, threads)
+                reg.flush()
+                qc.inverse_QFT(reg); ob.iqft(want, n, M, threads)
+                got = reg.read()
+                if mode == 1:
+                    assert np.array_equal(bits(got), bits(want)), (n, cap)
+                else:
+                    assert float(np.max(np.abs(got - want))) <= 1e-12, (n, cap)
+                if M:
+                    qc.reset_register(reg); qc.quantum_computation(Cn, a, reg)
+                    w2 = np.zeros(2 << n); ob.reset(w2, n); ob.quantum_computation(w2, n, M, Cn, a, threads=threads)
+                    got = reg.read()
+                    if mode == 1:
+                        assert np.array_equal(bits(got), bits(w2)), (n, cap)
+                    else:
+                        assert float(np.max(np.abs(got - w2))) <= 1e-12, (n, cap)
+
+
 # ---- round 5: the exact walk on 8 amplitudes per thread (k_fused_x8) and the tolerance round on the same shell ---------------
 @pytest.fixture()
 def x8_guard(qc):

@@ -304,7 +304,9 @@ def main():
                              "tiles (radix-8 rounds): 3 passes per 30-qubit sweep, CHAINED through the register's second buffer "
                              "(round 4): every pass reads whole 64-KiB tiles and stores 128-B runs under the layout the next pass "
                              "reads contiguously; the last one stores the identity layout.  In place (round 3) the same passes took "
-                             "22.7 ms; with the gates skipped the chained passes take 19.9-20.7 ms (DESIGN.md s4)"}
+                             "22.7 ms, chained 19.2-19.4; round 5: the workgroups of one XCD take the tiles whose 128-B runs are neighbours in "
+                             "the output (fuse_stream_tile): 18.0-18.4 ms.  A pass WITHOUT gates in the same shell moves its tiles at "
+                             "5.0-5.5 TB/s with 128-B runs (tools/experiments/tile_shell.hip, profiles/r05_tile_shell.txt): memory-bound"}
             reg.set_fusion(False)
         reg.close()
         exchanges = 0

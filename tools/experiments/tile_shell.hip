@@ -15,6 +15,7 @@
 
 typedef double2 amp_t;
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
 constexpr unsigned TT = 12, TS = 1u << TT;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -69,8 +70,14 @@ __device__ inline void store_tile(const amp_t *buf, amp_t *out, uint64_t t, unsi
 }
 
 // the per-gate kernels deal their tiles as 2^s interleaved streams (h_plan): workgroup b takes tile (b mod 2^s) * ntiles / 2^s + b / 2^s
-__constant__ unsigned g_slog;
-__device__ inline uint64_t stream_tile(uint64_t b, uint64_t ntiles) { return ((b & ((1u << g_slog) - 1u)) * (ntiles >> g_slog)) + (b >> g_slog); }
+__constant__ unsigned g_slog, g_pos1;       // g_pos1 = position of the stream number in the tile number + 1 (0: on top) -- fuse_stream_tile of qcx_kernels.h
+__device__ inline uint64_t stream_tile(uint64_t b, uint64_t ntiles)
+{
+    const unsigned tl = 63u - (unsigned)__builtin_clzll(ntiles), sl = g_slog < tl ? g_slog : tl;
+    const unsigned pos = g_pos1 ? (g_pos1 - 1u < tl - sl ? g_pos1 - 1u : tl - sl) : tl - sl;
+    const uint64_t r = b >> sl, sb = b & ((1u << sl) - 1u);
+    return (r & (((uint64_t)1 << pos) - 1u)) | (sb << pos) | ((r >> pos) << (pos + sl));
+}
 
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")     // (__syncthreads() also waits for the stores to land)
 
@@ -144,6 +151,57 @@ __global__ __launch_bounds__(64) void k_shell_d(const amp_t *in, amp_t *out, uin
     }
 }
 
+// shell E: stores only (what a store-bound pass -- k_basis_front, the expanding store -- can hope for); E1: a workgroup of 512 threads
+// per 64-KiB tile; E2: a wave per 32 KiB (k_basis_front's form: 4 waves per workgroup, 1 KiB per store instruction)
+__global__ __launch_bounds__(512) void k_shell_e1(const amp_t *in, amp_t *out, uint64_t ntiles, unsigned c, unsigned nt)
+{
+    (void)in;
+    for (uint64_t b = blockIdx.x; b < ntiles; b += gridDim.x) {
+        const uint64_t t = stream_tile(b, ntiles);
+#pragma unroll
+        for (unsigned k = 0; k < 8; k++) {
+            const unsigned e = k * 512 + threadIdx.x;
+            const uint64_t i = (t << TT) | e;
+            d2 v; v.x = (double)i; v.y = -(double)i;
+            d2 *p = reinterpret_cast<d2 *>(out + out_index(t, e, c));
+            if (nt) __builtin_nontemporal_store(v, p); else *p = v;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_shell_e2(const amp_t *in, amp_t *out, uint64_t ntiles, unsigned c, unsigned nt)
+{
+    (void)in; (void)c;
+    const uint64_t nchunks = ntiles * 2;                    // 32 KiB = 2^11 amplitudes per wave
+    const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
+    for (uint64_t b = wave; b < nchunks; b += nwaves) {
+        const uint64_t w = stream_tile(b, nchunks);
+        for (unsigned j = 0; j < 32; j++) {
+            const uint64_t i = (w << 11) + j * 64 + (threadIdx.x & 63u);
+            d2 v; v.x = (double)i; v.y = -(double)i;
+            d2 *p = reinterpret_cast<d2 *>(out + i);
+            if (nt) __builtin_nontemporal_store(v, p); else *p = v;
+        }
+    }
+}
+// shell R: reads only (measure_state's scan): a workgroup of 512 threads per 64-KiB tile, 8 loads per thread in flight
+__global__ __launch_bounds__(512) void k_shell_r(const amp_t *in, amp_t *out, uint64_t ntiles, unsigned c, unsigned nt)
+{
+    (void)c;
+    double acc = 0.0;
+    for (uint64_t b = blockIdx.x; b < ntiles; b += gridDim.x) {
+        const uint64_t t = stream_tile(b, ntiles);
+        u4 v[8];
+#pragma unroll
+        for (unsigned k = 0; k < 8; k++) {
+            const u4 *p = reinterpret_cast<const u4 *>(in + (t << TT) + k * 512 + threadIdx.x);
+            v[k] = nt ? __builtin_nontemporal_load(p) : *p;
+        }
+#pragma unroll
+        for (unsigned k = 0; k < 8; k++) acc += (double)(v[k].x ^ v[k].w);
+    }
+    if (acc == 1.2345) out[0].x = acc;                      // (keeps the loads)
+}
+
 typedef void (*kern_t)(const amp_t *, amp_t *, uint64_t, unsigned, unsigned);
 
 static void run(const char *name, kern_t kfn, unsigned block, unsigned grid, size_t lds, const amp_t *in, amp_t *out, uint64_t ntiles, unsigned c,
@@ -180,6 +238,20 @@ int main(int argc, char **argv)
     CK(hipDeviceSynchronize());
     printf("# n = %u: 2^%u tiles of 2^12 amplitudes, %.1f GB moved per pass (read + written)\n", n, n - TT, 32.0 * dim * 1e-9);
     const unsigned G = (unsigned)ntiles;
+    if (argc > 2 && argv[2][0] == 'e') {          // store-only and read-only passes over streams x position
+        for (unsigned sl : {0u, 1u, 2u, 3u, 4u}) {
+            for (unsigned pos1 : {0u, 2u, 4u}) {
+                if (sl == 0 && pos1) continue;
+                CK(hipMemcpyToSymbol(HIP_SYMBOL(g_slog), &sl, 4)); CK(hipMemcpyToSymbol(HIP_SYMBOL(g_pos1), &pos1, 4));
+                printf("pos1=%u ", pos1); run("E1 stores only, 512 thr per 64-KiB tile", k_shell_e1, 512, G, 0, in, out, ntiles, 0, 1, bad_d);
+                printf("pos1=%u ", pos1); run("E1 stores only, plain stores", k_shell_e1, 512, G, 0, in, out, ntiles, 0, 0, bad_d);
+                printf("pos1=%u ", pos1); run("E2 stores only, a wave per 32 KiB", k_shell_e2, 256, G / 2, 0, in, out, ntiles, 0, 1, bad_d);
+                printf("pos1=%u ", pos1); run("R  reads only (bytes counted as 32/amp: x2)", k_shell_r, 512, G, 0, in, out, ntiles, 0, 1, bad_d);
+                printf("pos1=%u ", pos1); run("R  reads only, plain loads", k_shell_r, 512, G, 0, in, out, ntiles, 0, 0, bad_d);
+            }
+        }
+        return 0;
+    }
     if (argc > 2) {             // stream sweep only
         for (unsigned sl = 0; sl <= 6; sl++) {
             CK(hipMemcpyToSymbol(HIP_SYMBOL(g_slog), &sl, 4));

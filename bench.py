@@ -633,6 +633,8 @@ def single_gpu_configs(qc, reps=3):
         reg.set_fusion(0)
         circuit()
         c5["total_probability"] = reg.norm2()
+        qc.measure_state(reg, rng)        # warm-up: the first scan of a register of this size allocates its record arrays (0.4-0.5 ms)
+        circuit()                         # (flushed: the state is in the register, expanded -- the timed call is the scan of 16 * 2^n bytes alone)
         reg.synchronize()
         t0 = time.perf_counter()
         idx = qc.measure_state(reg, rng)

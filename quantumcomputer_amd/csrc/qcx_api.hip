@@ -158,6 +158,7 @@ struct Tune {
     long meas_parallel = 1;    // 0: always the single-wave sequential scan
     long meas_min_log2 = 12;   // shards below 2^this amplitudes use the single-wave scan (tools/experiments/probe_shots.py)
     long meas_dbg = 0;         // K4c diagnostics: bit 0 = no look-back (every binade guess from cum_in alone: times the pass without it); bit 1 = k_meas_fast hands over to the walk at its third candidate
+    long meas_host_out = 1;    // the scan's result is written straight into pinned host memory (no copy back on the stream)
     long meas_fast = 1;        // K4c: the scan's events by k_meas_fast (list of candidate records, 8 waves) with k_meas_walk as the fallback; 0: the walk alone
     long meas_spin_limit = 4000000;   // K4c: polls a look-back may spend on one window before it gives up (the block is then scanned exactly)
 };
@@ -169,7 +170,7 @@ static Tune tune_now() { std::lock_guard<std::mutex> lock(g_tune_mutex); return 
 extern "C" int qcx_tune_set(const char *key, long value)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); g_tune.name = value; return QCX_NO_ERROR; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_spin_limit) K(meas_dbg) K(meas_fast) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_dir) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_gen_cols) K(fuse_cols_waves) K(fuse_cols_cap) K(fuse_cols_tol) K(fuse_compact) K(fuse_expand_direct) K(fuse_compact_lazy) K(fuse_expand_fused) K(fuse_plan_cache) K(fuse_zskip) K(fuse_zskip_maxw) K(fuse_x8) K(fuse_x8_T) K(fuse_x8_c) K(fuse_x8_map) K(fuse_x8_cap) K(fuse_x8_ratio) K(fuse_x8_min_tiles_log2) K(fuse_x8t) K(fuse_streams_log2) K(fuse_streams_pos)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_spin_limit) K(meas_dbg) K(meas_fast) K(meas_host_out) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_dir) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_gen_cols) K(fuse_cols_waves) K(fuse_cols_cap) K(fuse_cols_tol) K(fuse_compact) K(fuse_expand_direct) K(fuse_compact_lazy) K(fuse_expand_fused) K(fuse_plan_cache) K(fuse_zskip) K(fuse_zskip_maxw) K(fuse_x8) K(fuse_x8_T) K(fuse_x8_c) K(fuse_x8_map) K(fuse_x8_cap) K(fuse_x8_ratio) K(fuse_x8_min_tiles_log2) K(fuse_x8t) K(fuse_streams_log2) K(fuse_streams_pos)
 #undef K
     return QCX_BAD_ARGUMENTS;
 }
@@ -177,7 +178,7 @@ extern "C" int qcx_tune_set(const char *key, long value)
 extern "C" long qcx_tune_get(const char *key)
 {
 #define K(name) if (!strcmp(key, #name)) { std::lock_guard<std::mutex> lock(g_tune_mutex); return g_tune.name; }
-    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_spin_limit) K(meas_dbg) K(meas_fast) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_dir) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_gen_cols) K(fuse_cols_waves) K(fuse_cols_cap) K(fuse_cols_tol) K(fuse_compact) K(fuse_expand_direct) K(fuse_compact_lazy) K(fuse_expand_fused) K(fuse_plan_cache) K(fuse_zskip) K(fuse_zskip_maxw) K(fuse_x8) K(fuse_x8_T) K(fuse_x8_c) K(fuse_x8_map) K(fuse_x8_cap) K(fuse_x8_ratio) K(fuse_x8_min_tiles_log2) K(fuse_x8t) K(fuse_streams_log2) K(fuse_streams_pos)
+    K(h_variant) K(h_ppt) K(h_nt) K(h_wave_nt) K(h_wc) K(h_block) K(h_streams_log2) K(h_skew) K(h_grid_cap) K(h_wave_r) K(h_wave_block) K(h_wave_maxq) K(ph_apt) K(ph_grid_cap) K(ph_block) K(ph_nt) K(ph_streams_log2) K(ph_lines) K(cam_grid_cap) K(cam_skip) K(cam_nt_lines) K(cam_logT) K(cam_block) K(cam_stage_mb) K(meas_parallel) K(meas_min_log2) K(meas_block_log) K(meas_spin_limit) K(meas_dbg) K(meas_fast) K(meas_host_out) K(fuse_T) K(fuse_c) K(fuse_grid_cap) K(fuse_max_queue) K(fuse_ldsdma) K(fuse_rounds) K(fuse_dbg) K(fuse_hsweep_T) K(fuse_hsweep_c) K(fuse_camruns) K(fuse_T_phase) K(fuse_c_phase) K(fuse_phase_ratio) K(fuse_rounds_occ) K(fuse_tol_occ) K(fuse_qround) K(fuse_swz) K(fuse_tol_T) K(fuse_front) K(fuse_q3) K(fuse_q3_cap) K(fuse_q3_cap_exact) K(fuse_chain) K(fuse_chain_dir) K(fuse_chain_min_n) K(fuse_q3_c3) K(fuse_lowtile) K(fuse_gen) K(fuse_gen_cols) K(fuse_cols_waves) K(fuse_cols_cap) K(fuse_cols_tol) K(fuse_compact) K(fuse_expand_direct) K(fuse_compact_lazy) K(fuse_expand_fused) K(fuse_plan_cache) K(fuse_zskip) K(fuse_zskip_maxw) K(fuse_x8) K(fuse_x8_T) K(fuse_x8_c) K(fuse_x8_map) K(fuse_x8_cap) K(fuse_x8_ratio) K(fuse_x8_min_tiles_log2) K(fuse_x8t) K(fuse_streams_log2) K(fuse_streams_pos)
 #undef K
     return -1;
 }
@@ -753,9 +754,13 @@ extern "C" int qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_
     if (count == 0) { *found = 0; *index = 0; *cum_out = cum_in; return QCX_NO_ERROR; }
     const Tune tn = tune_now();
     const bool parallel = tn.meas_parallel != 0 && count >= ((uint64_t)1 << tn.meas_min_log2);
+    // The scan's last kernel writes its result (a MeasureOut, 32 bytes) STRAIGHT into pinned host memory (meas_host_out, round 5): the
+    // copy back used to be one more operation on the stream -- a blit kernel, 6-10 us of an attempt that takes 27 us at n = 7 and
+    // 100 us at n = 20.  The kernels only write it (what the fast scan leaves for the walk travels in MeasResume, device memory).
+    MeasureOut *const res = tn.meas_host_out ? w->h_mout : w->mout;
     if (!parallel) {
         // small shards: the strictly sequential single-wave scan
-        hipLaunchKernelGGL(k_measure_scan, dim3(1), dim3(64), 0, st, (const amp_t *)amp, count, cum_in, r, w->mout);
+        hipLaunchKernelGGL(k_measure_scan, dim3(1), dim3(64), 0, st, (const amp_t *)amp, count, cum_in, r, res);
     } else {
         // exact parallel form (qcx_kernels.h, K4c): one read of the state (look-back for the binade guesses), a few tiny group
         // launches, the tree walk.  A "block" of 2^blog amplitudes is one RECORD (one wave); a workgroup takes four of them.
@@ -814,16 +819,16 @@ extern "C" int qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_
                 up += nout;
             }
             if (fast)
-                hipLaunchKernelGGL(k_meas_fast, dim3(1), dim3(512), 0, st, (const amp_t *)amp, count, T, cum_in, r, w->mout, w->mout->stats, blog,
+                hipLaunchKernelGGL(k_meas_fast, dim3(1), dim3(512), 0, st, (const amp_t *)amp, count, T, cum_in, r, res, res->stats, blog,
                                    (const MeasCands *)w->meas_cands, w->meas_resume, (unsigned)tn.meas_dbg);
-            hipLaunchKernelGGL(k_meas_walk, dim3(1), dim3(64), 0, st, (const amp_t *)amp, count, T, cum_in, r, w->mout, w->mout->stats, blog,
+            hipLaunchKernelGGL(k_meas_walk, dim3(1), dim3(64), 0, st, (const amp_t *)amp, count, T, cum_in, r, res, res->stats, blog,
                                fast ? (const MeasResume *)w->meas_resume : (const MeasResume *)nullptr, w->meas_cands,
                                T.top == 0 ? w->meas_look : (meas_slot_t *)nullptr, (unsigned)nslots);
             w->meas_slots_pending = slots_after;
         }
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(w->h_mout, w->mout, sizeof(MeasureOut), hipMemcpyDeviceToHost, st));
+    if (res != w->h_mout) HIP_TRY(hipMemcpyAsync(w->h_mout, w->mout, sizeof(MeasureOut), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (parallel) { w->h_meas_stats[0] = w->h_mout->stats[0]; w->h_meas_stats[1] = w->h_mout->stats[1]; w->meas_clean = true; w->meas_clean_slots = w->meas_slots_pending; }
     *found = w->h_mout->found;

@@ -707,7 +707,7 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
     const size_t lut_only = P.has_cam ? cam_lut_bytes((unsigned)r->M) : 16;        // scratch of the modular-multiply steps
     size_t lut_bytes = lut_only + (size_t)P.cam_ctl_local[1];                      // + tables of folded multiply runs
     P.xm_off = 0;
-    P.dbg = (uint32_t)tn.fuse_dbg | (((uint32_t)tn.fuse_swz & 7u) << 8);
+    P.dbg = (uint32_t)tn.fuse_dbg & 0xffu;
     {   // which tile a workgroup takes (fuse_stream_tile): memory-bound radix-8 passes (Hadamard sweeps, the tolerance mode's fast
         // rounds) put the XCD number on tile-number bits 3-5 -- one XCD then stores 2^3 neighbouring runs back to back (n = 30
         // sweep -6 %, n = 28 tolerance inverse QFT -1.6 %); the exact phase walk (FP64-bound) measures the same either way and
@@ -779,15 +779,6 @@ static int launch_pass(qcx_register *r, const Tune &tn, const FusePass &P_in, co
         } else if (tn.fuse_ldsdma) hipLaunchKernelGGL((k_fused<B, TTv, true>), dim3(grid), dim3(B), lds, r->stream, amp_in, n, P, d_ops, ntiles, d_ops); \
         else hipLaunchKernelGGL((k_fused<B, TTv, false>), dim3(grid), dim3(B), lds, r->stream, amp_in, n, P, d_ops, ntiles, d_ops); } while (0)
     if (P.dg_slim == 2) {                 // tolerance mode, radix-8 fast rounds only
-        if (P.T == 13 && !P.dg_cnt && !P.gen) {
-            // EXPERIMENT (round 5, fuse_hsweep_T = 13): all-Hadamard passes on tiles of 2^13 amplitudes -- 9 hot bits next to c = 4,
-            // i.e. 256-byte store runs where the 2^12 geometry with c = 3 has 128-byte ones -- at the price of ONE 128-KiB workgroup
-            // per CU.  Measured slower; kept selectable so that the number can be reproduced.
-            const size_t lds13 = ((size_t)16 << 13) + 16;
-            hipLaunchKernelGGL((k_fused_q3<1024, 13, 4, true>), dim3(grid_for(ntiles, 1, tn.fuse_q3_cap_exact)), dim3(1024), lds13, r->stream, amp_in, amp_out, n, P, d_ops, ntiles);
-            HIP_TRY(hipGetLastError());
-            return QCX_NO_ERROR;
-        }
         if (P.T != 12) { set_error("radix-8 pass on a tile of 2^%u amplitudes", P.T); return QCX_UNKNOWN_ERROR; }
         if (P.dg_cnt && !P.gen && tn.fuse_x8t) {              // round 5: the hand-written round on the k_fused_x8 shell (K6x-t)
             P.dg_lds_off = 0;
@@ -1092,7 +1083,7 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
         const bool cols_pass = first_cols && first == 0 && n >= 14;
         {
             const unsigned Ta = (unsigned)tn.fuse_hsweep_T, ca = (unsigned)tn.fuse_hsweep_c;
-            bool tail_h = Ta >= 10 && Ta <= 13 && Ta <= n && ca <= Ta && tn.fuse_rounds;       // (13: experiment of round 5, 128-KiB tiles: see launch_pass)
+            bool tail_h = Ta >= 10 && Ta <= 12 && Ta <= n && ca <= Ta && tn.fuse_rounds;       // (2^13-amplitude tiles, one 128-KiB workgroup per CU: built in round 5, slower, removed -- DESIGN.md s4.6)
             for (size_t k = first; tail_h && k < gates.size(); k++) tail_h = gates[k].type == FUSE_H;
             if (tail_h) {
                 auto passes = [&](unsigned TT, unsigned cc) {
@@ -1110,7 +1101,7 @@ static void fuse_plan(const qcx_register *r, const Tune &tn, const std::vector<Q
                 };
                 if (passes(Ta, ca) * 123u < passes(T, c_def) * 100u) {
                     Tcur = Ta; ccur = ca;
-                    if ((Ta == 12 || Ta == 13) && q3_allowed && tn.fuse_q3) want_q3 = true;      // radix-8 rounds, exact butterflies (k_fused_q3<.., EXACT>)
+                    if (Ta == 12 && q3_allowed && tn.fuse_q3) want_q3 = true;      // radix-8 rounds, exact butterflies (k_fused_q3<.., EXACT>)
                 }
             }
         }

@@ -2235,17 +2235,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) vo
         for (unsigned k = 0; k < 4; k++) packK[k] = gen_pack(k * BLOCK, GF, TT);
         __syncthreads();
     }
-    // swz = s > 0: workgroups that share an XCD (blockIdx mod 8 under round-robin placement) take 2^s NEIGHBOURING tiles
-    // instead of every eighth one -- their runs are then adjacent in memory (speed only; any order is correct)
-    const unsigned swz = (P.dbg >> 8) & 7u;
     const unsigned slog = (P.dbg >> 12) & 15u;
     for (uint64_t b0 = blockIdx.x; b0 < ntiles; b0 += gridDim.x) {
-        const uint64_t t0 = fuse_stream_tile(b0, n - TT, slog, (P.dbg >> 16) & 31u);
-        uint64_t t = t0;
-        if (swz && !((ntiles | gridDim.x) & ((8u << swz) - 1u))) {
-            const uint64_t xcd = t0 & 7u, slot = t0 >> 3, in = slot & ((1u << swz) - 1u), grp = slot >> swz;
-            t = (((grp << 3) | xcd) << swz) | in;
-        }
+        const uint64_t t = fuse_stream_tile(b0, n - TT, slog, (P.dbg >> 16) & 31u);       // (round 3's fuse_swz, the same idea for this kernel alone, is gone)
         const uint64_t base_in = fuse_deposit(t, P.seg_in, P.nseg_in);
         uint64_t base = base_in, base_out = base_in;               // logical base (gate records), output base
         if (P.chained) { base = fuse_deposit(t, P.seg_lg, P.nseg_lg); base_out = fuse_deposit(t, P.seg_out, P.nseg_out); }

@@ -770,6 +770,9 @@ extern "C" int qcx_shard_measure_scan(const void *amp, unsigned n_local, uint64_
             blog = bits ? (bits - 1) / 2 : 8;
         }
         blog = std::min<unsigned>(std::max<unsigned>(blog, 8u), 11u);     // a record is one wave's 2^8 .. 2^11 amplitudes
+        // k_meas_onepass takes four records per 256-thread workgroup and a launch holds fewer than 2^32 threads: a record size
+        // forced too small for the register (meas_block_log = 8 at n = 34) is raised, not refused
+        while (blog < 11u && ((((count + (((uint64_t)1 << blog) - 1)) >> blog) + 3u) / 4u) * 256u > 0xffffffffULL) blog++;
         const uint64_t nb64 = (count + (((uint64_t)1 << blog) - 1)) >> blog;
         if (nb64 > 0x7fffffffULL) return QCX_UNSUPPORTED;
         const unsigned nblocks = (unsigned)nb64;
